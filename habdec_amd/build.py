@@ -1,0 +1,72 @@
+"""Build libhabdec_amd.so (HIP kernels + C-ABI engine) for gfx950, in-tree.
+
+    python -m habdec_amd.build          # or: from habdec_amd.build import build; build()
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is REQUIRED: the FIR/decimator sums must be separate
+IEEE multiply and add (no FMA) to be bit-identical to the reference's CPU arithmetic.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+OUT = HERE / "libhabdec_amd.so"
+SOURCES = ["engine.cpp", "host_api.cpp", "kernels/decimate.hip", "kernels/fir_demod.hip", "kernels/spectrum.hip", "kernels/symbols.hip"]
+ARCH = "gfx950"
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and Path(c).exists():
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale() -> bool:
+    if not OUT.exists():
+        return True
+    t = OUT.stat().st_mtime
+    deps = list(CSRC.rglob("*.hip")) + list(CSRC.rglob("*.cpp")) + list(CSRC.rglob("*.h")) + list(CSRC.rglob("*.hpp")) + \
+        list(CSRC.rglob("*.inc")) + [HERE.parent / "include" / "habdec_amd.h", Path(__file__)]
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not _stale():
+        return OUT
+    objs = []
+    build_dir = HERE / "build"
+    build_dir.mkdir(exist_ok=True)
+    common = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+              "-Wall", "-Wno-unused-function", "-I", str(HERE.parent / "include"), "-I", str(CSRC)]
+    procs = []
+    for src in SOURCES:
+        obj = build_dir / (src.replace("/", "_") + ".o")
+        cmd = common + ["-x", "hip", "-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(str(obj))
+    bad = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode:
+            bad = True
+            sys.stderr.write(f"--- {src} ---\n{out}\n")
+        elif verbose and out.strip():
+            print(out)
+    if bad:
+        raise RuntimeError("hipcc failed")
+    link = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(OUT)] + objs + \
+        ["-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(link, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,57 @@
+// Structures shared by the host engine (engine.cpp) and the gfx950 kernels (kernels/*.hip).
+#pragma once
+#include <stdint.h>
+
+namespace hd {
+
+constexpr int kFftBins = 4096;
+constexpr uint32_t kVentLimit = 30000;   // symbol-extractor overflow vent (reference SymbolExtractor.h:116)
+constexpr uint32_t kFirBatch = 256;      // FIR batch granularity (reference Decoder.h:492)
+
+// Per-stream, per-call launch parameters.  Everything here is a pure function of the sizes pushed so far,
+// so the host mirrors the reference's integer bookkeeping (Decoder.h:426-436, 461-495, 532-542;
+// Decimator.h:74-79; FirFilter.h:141-147, 185-194) and uploads one array of these per call.
+struct StreamCall {
+    uint32_t n_in;          // IQ samples consumed by stage 1 this call (multiple of the total factor)
+    uint32_t n1;            // samples after stage 1 (== n_in when there are no stages)
+    uint32_t n2;            // samples after the last stage = length of this call's decimated chunk
+    uint32_t zero_hist1;    // Q5: stage history restarts from zeros (first call / input grew)
+    uint32_t zero_hist2;
+    uint32_t pend_before;   // decimated samples already pending in front of the FIR
+    uint32_t fft_fill;      // samples already collected for the next spectrum
+    uint32_t fft_take;      // samples of this chunk's head to append (0..n2)
+    uint32_t fft_run;       // 1 = the spectrum buffer completes in this call
+    uint32_t fir_m;         // samples to filter/demodulate this call (0 = FIR does not run)
+    uint32_t fir_taps;      // tap count in use
+    uint32_t fir_zero_hist; // Q5 for the low-pass
+    uint32_t pend_after;    // pending decimated samples left for the next call
+    uint32_t dc_remove;     // 1 = per-chunk DC blocker on the decimated chunk
+    uint32_t clear_pending; // 1 = rate gate hit: drop everything pending (Decoder.h:522-527)
+    uint32_t _pad;
+};
+
+// Per-stream symbol-extractor constants (change only through the control plane).
+struct SymbolParams {
+    uint32_t spb;           // samples per bit = size_t(round(fsd / baud))       (SymbolExtractor.h:90)
+    uint32_t R;             // averaging half-window = max(4, int(spb / 4))      (SymbolExtractor.h:170)
+    uint32_t min_held;      // smallest backlog that satisfies `size >= fsd/baud*3` (SymbolExtractor.h:134); 0xFFFFFFFF = disabled
+    uint32_t float_abs;     // lookup context of the flip weight |avg_r - avg_l|, see DESIGN.md
+};
+
+// Header of a stream's result slot written by the symbol scan kernel, followed by packed bits.
+struct BitsHeader {
+    uint32_t nbits;         // symbols produced this call
+    uint32_t held_after;    // backlog kept by the symbol extractor after this call
+    uint32_t nflips;        // flip points found this call
+    uint32_t overflow;      // 1 = more bits/flips than the slot can hold (never with the derived capacities)
+};
+
+struct SpectrumStatsDev {   // must match hd::SpectrumStats (host/afc_tracker.hpp)
+    int32_t valid;
+    int32_t peak1, peak2;
+    float power1, power2;
+    float _pad;
+    double mean, sigma;
+};
+
+}  // namespace hd

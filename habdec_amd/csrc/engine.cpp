@@ -1,0 +1,696 @@
+// libhabdec_amd.so -- host side of the MI355X RTTY demodulation engine: the C ABI of include/habdec_amd.h.
+//
+// Responsibilities: mirror the reference Decoder's integer bookkeeping per stream (how many samples each stage
+// sees, when histories restart, when the spectrum buffer completes, when the low-pass is redesigned:
+// reference code/Decoder/Decoder.h:416-542), upload it as one small parameter array per call, launch the gfx950
+// kernels over all streams on one HIP stream, fetch the packed bits and spectrum statistics, and run the host
+// text stage (RTTY framing, sentence extraction, CRC, callbacks: Decoder.h:559-637) and the AFC state machine.
+// There is no CPU fallback: without a gfx950 device and the kernels in this library hd_engine_create fails.
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/habdec_amd.h"
+#include "dev_types.h"
+#include "host/afc_tracker.hpp"
+#include "host/decim_plan.hpp"
+#include "host/fir_design.hpp"
+#include "host/text_stage.hpp"
+#include "kernels/launch.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HD_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) return fail(HD_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count)
+    {
+        n = count;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) e = hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T));
+        return e;
+    }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+template <typename T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count)
+    {
+        n = count;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) std::memset(p, 0, std::max<size_t>(count, 1) * sizeof(T));
+        return e;
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+};
+
+struct StreamHost {
+    // control plane
+    double baud = 300;
+    float lp_bw = 1500, lp_trans = 0.025f;
+    bool dc = false;
+    // size bookkeeping mirrored from the reference
+    size_t stage_buf[2] = {0, 0};   // Decimator::p_buff_.size()
+    size_t pending = 0;             // iq_samples_decimated_.size()
+    size_t fft_fill = 0;            // freq_in_.size()
+    bool have_spectrum = false;     // freq_out_.size() == 4096
+    uint64_t spectra = 0;
+    size_t fir_buf = 0;             // FirFilter::buff_.size()
+    hd::LowpassDesigner lp;
+    bool taps_dirty = false;
+    // data-dependent state learned back from the device
+    uint32_t held = 0;
+    // host stages
+    hd::TextStage text;
+    hd::AfcTracker afc;
+    hd::SpectrumStats stats{};
+    // last call (for the getters)
+    uint32_t last_n2 = 0, last_pend_before = 0, last_m = 0, last_nbits = 0, last_nflips = 0;
+    int last_buf = 0;
+    std::vector<uint32_t> last_words;
+};
+
+}  // namespace
+
+struct hd_engine {
+    hd_engine_config cfg{};
+    double fs = 0, fsd = 0;
+    std::vector<hd::DecimStage> stages;
+    uint32_t S = 0, D = 1;
+    uint32_t n1_cap = 0, n2_cap = 0;        // per-call capacities after stage 1 / last stage
+    uint32_t taps_cap = 0, fir_hist_cap = 0; // low-pass tap capacity, history slots in front of the pending samples
+    size_t fbuf_stride = 0;
+    uint32_t tail_cap = 0, slot_words = 0, flips_cap = 0, max_R = 0;
+    int bins_sep = 8;
+    bool decode_enabled = true;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool timing_on = true;
+    hd_timing last_timing{};
+    rocfft_plan fft_plan = nullptr;
+    rocfft_execution_info fft_info = nullptr;
+    DevBuf<char> fft_work;
+
+    DevBuf<float2> staging, dec1, hist1, hist2, fbuf[2], fft_in, fft_raw, spec, filtered;
+    DevBuf<float> stage_taps[2], lp_taps, power, demod, tail, weight;
+    DevBuf<unsigned long long> flipmask;
+    DevBuf<uint32_t> held, slots, flips_dbg;
+    DevBuf<hd::DemodCarry> carry[2];
+    DevBuf<hd::StreamCall> d_call;
+    DevBuf<hd::SymbolParams> d_sym;
+    DevBuf<hd::SpectrumStatsDev> d_stats;
+    PinBuf<hd::StreamCall> h_call;
+    PinBuf<hd::SymbolParams> h_sym;
+    PinBuf<uint32_t> h_slots;
+    PinBuf<hd::SpectrumStatsDev> h_stats;
+    PinBuf<float> h_taps;
+    int cur = 0;          // which fbuf receives this call's chunk
+    int carry_cur = 0;
+    bool sym_dirty = true;
+
+    std::vector<StreamHost> st;
+    std::mutex mtx;
+    hd_sentence_cb sentence_cb = nullptr; void* sentence_user = nullptr;
+    hd_chars_cb chars_cb = nullptr; void* chars_user = nullptr;
+    uint64_t sentences_ok = 0;
+
+    ~hd_engine()
+    {
+        if (fft_plan) rocfft_plan_destroy(fft_plan);
+        if (fft_info) rocfft_execution_info_destroy(fft_info);
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+std::once_flag g_rocfft_once;
+
+hd::SymbolParams symbol_params(const hd_engine* e, const StreamHost& s)
+{
+    hd::SymbolParams p{};
+    p.float_abs = e->cfg.lookup_mode ? 1u : 0u;
+    p.min_held = 0xFFFFFFFFu;
+    p.spb = 0; p.R = 4;
+    if (e->fsd > 0 && s.baud > 0) {
+        const double spb = std::round(e->fsd / s.baud);
+        if (spb >= 1 && spb < 1e9) {
+            p.spb = (uint32_t)spb;
+            p.R = (uint32_t)std::max(4, int(p.spb / 4));
+            p.min_held = (uint32_t)std::ceil(e->fsd / s.baud * 3);
+        }
+    }
+    return p;
+}
+
+float cutoff_rel(const hd_engine* e, const StreamHost& s) { return (float)(s.lp_bw / e->fsd); }
+
+int check_stream(const hd_engine* e, uint32_t s)
+{
+    if (!e) return fail(HD_ERR_INVALID, "null engine");
+    if (s >= e->S) return fail(HD_ERR_INVALID, "stream index out of range");
+    return HD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hd_last_error(void) { return g_err.c_str(); }
+
+void hd_engine_config_default(hd_engine_config* c)
+{
+    std::memset(c, 0, sizeof(*c));
+    c->device = 0; c->n_streams = 1; c->max_chunk = 65536; c->sampling_rate = 2.048e6; c->decimation = 64;
+    c->baud = 300; c->rtty_bits = 8; c->rtty_stops = 2; c->lowpass_bw_hz = 1500; c->lowpass_trans = 0.025f;
+    c->dc_remove = 0; c->lookup_mode = 1; c->enable_spectrum = 1; c->ungated = 0; c->keep_filtered = 0;
+}
+
+int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
+{
+    if (!cfg || !out) return fail(HD_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->n_streams < 1) return fail(HD_ERR_INVALID, "n_streams must be >= 1");
+    if (!(cfg->sampling_rate > 0)) return fail(HD_ERR_INVALID, "sampling_rate must be > 0");
+    if (cfg->max_chunk < 1) return fail(HD_ERR_INVALID, "max_chunk must be >= 1");
+    std::unique_ptr<hd_engine> e(new hd_engine);
+    e->cfg = *cfg;
+    if (!hd::decim_plan(cfg->decimation, e->stages))
+        return fail(HD_ERR_INVALID, "Unsupported decimation factor: " + std::to_string(cfg->decimation));   // Decoder.h:317-319
+    e->S = cfg->n_streams;
+    e->D = cfg->decimation;
+    if (cfg->max_chunk % e->D) return fail(HD_ERR_INVALID, "max_chunk must be a multiple of the decimation factor");
+    e->fs = (double)(float)cfg->sampling_rate;        // Decoder::init(const float) (Decoder.h:223-225)
+    e->fsd = e->fs / (double)e->D;
+    e->decode_enabled = cfg->ungated || !(e->fsd > 4 * 40e3);   // Decoder.h:522
+    {   // AFC::FindPeaks separation in bins (AFC.h:110-111, 299-300)
+        const float rel = (float)(500.0f / e->fsd);
+        e->bins_sep = std::max(8, (int)std::round((double)rel * (double)hd::kFftBins));
+    }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device || cfg->device < 0)
+        return fail(HD_ERR_DEVICE, "no HIP device " + std::to_string(cfg->device) + " (this library has no CPU path)");
+    HD_HIP(hipSetDevice(cfg->device));
+    HD_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    for (auto& ev : e->ev) HD_HIP(hipEventCreate(&ev));
+
+    const uint32_t S = e->S;
+    const uint32_t r0 = e->stages.size() > 0 ? e->stages[0].ratio : 1;
+    e->n1_cap = cfg->max_chunk / r0;
+    e->n2_cap = cfg->max_chunk / e->D;
+    // low-pass tap capacity: the design clamps to the batch length m <= pending_max and forces odd (FirFilter.h:185-188)
+    const uint32_t m_cap = ((e->n2_cap + hd::kFirBatch - 1) / hd::kFirBatch) * hd::kFirBatch + hd::kFirBatch;
+    e->taps_cap = (m_cap | 1u) + 1u;
+    e->fir_hist_cap = (e->taps_cap + 1u) & ~1u;       // even, so the chunk behind it stays 16-byte aligned
+    e->fbuf_stride = (size_t)e->fir_hist_cap + hd::kFirBatch + e->n2_cap + 2;
+    e->fbuf_stride = (e->fbuf_stride + 1) & ~(size_t)1;
+    e->tail_cap = ((hd::kVentLimit + 1 + m_cap + 63) / 64) * 64;
+
+    e->st.resize(S);
+    for (auto& s : e->st) {
+        s.baud = cfg->baud; s.lp_bw = cfg->lowpass_bw_hz; s.lp_trans = cfg->lowpass_trans; s.dc = cfg->dc_remove != 0;
+        s.text.framer.nbits = cfg->rtty_bits; s.text.framer.nstops = cfg->rtty_stops;
+        s.lp.float_trig = cfg->lookup_mode != 0;
+    }
+    {   // result slot: header + packed bits.  bits per call <= 3*backlog/spb (SymbolExtractor run lengths)
+        const hd::SymbolParams p = symbol_params(e.get(), e->st[0]);
+        const uint32_t spb = std::max<uint32_t>(p.spb, 1);
+        uint32_t bits = 3u * e->tail_cap / spb + 64u;
+        bits = std::max<uint32_t>(256u, (bits + 31u) & ~31u);
+        e->slot_words = (uint32_t)(sizeof(hd::BitsHeader) / 4) + bits / 32;
+        e->max_R = std::max<uint32_t>(p.R, 4);
+    }
+    e->flips_cap = cfg->keep_filtered ? 256 : 0;
+
+    // device memory
+    HD_HIP(e->staging.alloc((size_t)S * cfg->max_chunk));
+    if (e->stages.size() == 2) HD_HIP(e->dec1.alloc((size_t)S * e->n1_cap));
+    if (e->stages.size() >= 1) {
+        HD_HIP(e->hist1.alloc((size_t)S * (e->stages[0].taps.size() - 1)));
+        HD_HIP(e->stage_taps[0].alloc(e->stages[0].taps.size()));
+        HD_HIP(hipMemcpy(e->stage_taps[0].p, e->stages[0].taps.data(), e->stages[0].taps.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (e->stages.size() == 2) {
+        HD_HIP(e->hist2.alloc((size_t)S * (e->stages[1].taps.size() - 1)));
+        HD_HIP(e->stage_taps[1].alloc(e->stages[1].taps.size()));
+        HD_HIP(hipMemcpy(e->stage_taps[1].p, e->stages[1].taps.data(), e->stages[1].taps.size() * 4, hipMemcpyHostToDevice));
+    }
+    for (auto& b : e->fbuf) HD_HIP(b.alloc((size_t)S * e->fbuf_stride));
+    HD_HIP(e->lp_taps.alloc((size_t)S * e->taps_cap));
+    HD_HIP(e->demod.alloc((size_t)S * m_cap));
+    if (cfg->keep_filtered) HD_HIP(e->filtered.alloc((size_t)S * m_cap));
+    HD_HIP(e->tail.alloc((size_t)S * e->tail_cap));
+    HD_HIP(e->weight.alloc((size_t)S * e->tail_cap));
+    HD_HIP(e->flipmask.alloc((size_t)S * (e->tail_cap / 64)));
+    HD_HIP(e->held.alloc(S));
+    HD_HIP(e->slots.alloc((size_t)S * e->slot_words));
+    if (e->flips_cap) HD_HIP(e->flips_dbg.alloc((size_t)S * e->flips_cap));
+    for (auto& c : e->carry) HD_HIP(c.alloc(S));
+    HD_HIP(e->d_call.alloc(S));
+    HD_HIP(e->d_sym.alloc(S));
+    HD_HIP(e->h_call.alloc(S));
+    HD_HIP(e->h_sym.alloc(S));
+    HD_HIP(e->h_slots.alloc((size_t)S * e->slot_words));
+    HD_HIP(e->h_taps.alloc((size_t)e->taps_cap));
+    if (cfg->enable_spectrum) {
+        HD_HIP(e->fft_in.alloc((size_t)S * hd::kFftBins));
+        HD_HIP(e->fft_raw.alloc((size_t)S * hd::kFftBins));
+        HD_HIP(e->spec.alloc((size_t)S * hd::kFftBins));
+        HD_HIP(e->power.alloc((size_t)S * hd::kFftBins));
+        HD_HIP(e->d_stats.alloc(S));
+        HD_HIP(e->h_stats.alloc(S));
+        std::call_once(g_rocfft_once, [] { rocfft_setup(); });
+        const size_t len = hd::kFftBins;
+        if (rocfft_plan_create(&e->fft_plan, rocfft_placement_notinplace, rocfft_transform_type_complex_forward,
+                               rocfft_precision_single, 1, &len, S, nullptr) != rocfft_status_success)
+            return fail(HD_ERR_DEVICE, "rocfft_plan_create failed");
+        if (rocfft_execution_info_create(&e->fft_info) != rocfft_status_success)
+            return fail(HD_ERR_DEVICE, "rocfft_execution_info_create failed");
+        size_t wsz = 0;
+        rocfft_plan_get_work_buffer_size(e->fft_plan, &wsz);
+        if (wsz) {
+            HD_HIP(e->fft_work.alloc(wsz));
+            rocfft_execution_info_set_work_buffer(e->fft_info, e->fft_work.p, wsz);
+        }
+        rocfft_execution_info_set_stream(e->fft_info, e->stream);
+    }
+    HD_HIP(hipDeviceSynchronize());
+    *out = e.release();
+    return HD_OK;
+}
+
+void hd_engine_destroy(hd_engine* e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    delete e;
+}
+
+uint32_t hd_engine_streams(const hd_engine* e) { return e ? e->S : 0; }
+uint32_t hd_engine_decimation(const hd_engine* e) { return e ? e->D : 0; }
+double hd_engine_decimated_rate(const hd_engine* e) { return e ? e->fsd : 0; }
+uint64_t hd_engine_sentences_ok(const hd_engine* e) { return e ? e->sentences_ok : 0; }
+void hd_engine_set_timing(hd_engine* e, int on) { if (e) e->timing_on = on != 0; }
+int hd_engine_timing(hd_engine* e, hd_timing* out)
+{
+    if (!e || !out) return fail(HD_ERR_INVALID, "null argument");
+    *out = e->last_timing;
+    return HD_OK;
+}
+
+void hd_set_sentence_callback(hd_engine* e, hd_sentence_cb cb, void* user) { if (e) { e->sentence_cb = cb; e->sentence_user = user; } }
+void hd_set_chars_callback(hd_engine* e, hd_chars_cb cb, void* user) { if (e) { e->chars_cb = cb; e->chars_user = user; } }
+
+/* ---------------------------------------------------------------- control plane -------------------------------- */
+
+int hd_stream_set_baud(hd_engine* e, uint32_t s, double baud)
+{
+    if (int r = check_stream(e, s)) return r;
+    std::lock_guard<std::mutex> l(e->mtx);
+    StreamHost probe = e->st[s];
+    probe.baud = baud;
+    const hd::SymbolParams p = symbol_params(e, probe);
+    if (p.spb) {
+        const uint32_t need = 3u * e->tail_cap / p.spb + 64u;
+        if (need > (e->slot_words - sizeof(hd::BitsHeader) / 4) * 32)
+            return fail(HD_ERR_CAPACITY, "baud too high for the result slots sized at engine creation");
+        if (p.R > e->max_R) e->max_R = p.R;
+    }
+    e->st[s].baud = baud;
+    e->sym_dirty = true;
+    return HD_OK;
+}
+int hd_stream_set_rtty(hd_engine* e, uint32_t s, uint32_t bits, float stops)
+{
+    if (int r = check_stream(e, s)) return r;
+    std::lock_guard<std::mutex> l(e->mtx);
+    e->st[s].text.framer.nbits = bits;
+    e->st[s].text.framer.nstops = stops;
+    return HD_OK;
+}
+int hd_stream_set_lowpass_bw(hd_engine* e, uint32_t s, float hz)         // Decoder.h:238-243
+{
+    if (int r = check_stream(e, s)) return r;
+    std::lock_guard<std::mutex> l(e->mtx);
+    StreamHost& st = e->st[s];
+    st.lp_bw = hz;
+    if (st.lp.design(cutoff_rel(e, st), st.lp_trans)) st.taps_dirty = true;
+    return HD_OK;
+}
+int hd_stream_set_lowpass_trans(hd_engine* e, uint32_t s, float trans)   // Decoder.h:252-257
+{
+    if (int r = check_stream(e, s)) return r;
+    std::lock_guard<std::mutex> l(e->mtx);
+    StreamHost& st = e->st[s];
+    st.lp_trans = trans;
+    if (st.lp.design(cutoff_rel(e, st), st.lp_trans)) st.taps_dirty = true;
+    return HD_OK;
+}
+int hd_stream_set_dc_remove(hd_engine* e, uint32_t s, int on)
+{
+    if (int r = check_stream(e, s)) return r;
+    std::lock_guard<std::mutex> l(e->mtx);
+    e->st[s].dc = on != 0;
+    return HD_OK;
+}
+int hd_stream_reset_frequency_correction(hd_engine* e, uint32_t s, double c)
+{
+    if (int r = check_stream(e, s)) return r;
+    std::lock_guard<std::mutex> l(e->mtx);
+    e->st[s].afc.reset(c, hd::kFftBins, e->fsd);
+    return HD_OK;
+}
+
+/* ---------------------------------------------------------------- data path ------------------------------------ */
+
+int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint32_t* n_per_stream, uint32_t n_uniform)
+{
+    if (!e) return fail(HD_ERR_INVALID, "null engine");
+    if (!d_iq) return fail(HD_ERR_INVALID, "null IQ pointer");
+    if ((reinterpret_cast<uintptr_t>(d_iq) & 15) || (stride & 1)) return fail(HD_ERR_INVALID, "IQ base must be 16-byte aligned and stream_stride even");
+    std::lock_guard<std::mutex> lock(e->mtx);
+    HD_HIP(hipSetDevice(e->cfg.device));
+    const uint32_t S = e->S;
+    const size_t nst = e->stages.size();
+    const uint32_t T1 = nst > 0 ? (uint32_t)e->stages[0].taps.size() : 0, T2 = nst > 1 ? (uint32_t)e->stages[1].taps.size() : 0;
+    const uint32_t R1 = nst > 0 ? e->stages[0].ratio : 1, R2 = nst > 1 ? e->stages[1].ratio : 1;
+
+    // ---- host mirror of the reference's size bookkeeping -> one StreamCall per stream
+    uint32_t max_in = 0, max_n1 = 0, max_n2 = 0, max_m = 0, max_taps = 0, max_held = 0;
+    bool any_fft = false, any_dc = false;
+    uint64_t total_in = 0;
+    for (uint32_t s = 0; s < S; ++s) {
+        StreamHost& st = e->st[s];
+        hd::StreamCall c{};
+        const uint32_t n = n_per_stream ? n_per_stream[s] : n_uniform;
+        if (n > e->cfg.max_chunk) return fail(HD_ERR_CAPACITY, "more samples than max_chunk");
+        if (n % e->D) return fail(HD_ERR_INVALID, "sample count must be a multiple of the decimation factor (queue the remainder)");
+        c.n_in = n;
+        c.n1 = n / R1;
+        c.n2 = c.n1 / R2;
+        if (n) {
+            if (nst > 0 && n + 1 < T1) return fail(HD_ERR_UNSUPPORTED, "chunk shorter than the first stage's history (undefined in the reference)");
+            if (nst > 1 && c.n1 + 1 < T2) return fail(HD_ERR_UNSUPPORTED, "chunk shorter than the second stage's history (undefined in the reference)");
+            if (nst > 0) { const size_t want = (size_t)n + T1 + R1; if (st.stage_buf[0] < want) { st.stage_buf[0] = want; c.zero_hist1 = 1; } }
+            if (nst > 1) { const size_t want = (size_t)c.n1 + T2 + R2; if (st.stage_buf[1] < want) { st.stage_buf[1] = want; c.zero_hist2 = 1; } }
+        }
+        c.dc_remove = st.dc && c.n2;
+        c.pend_before = (uint32_t)st.pending;
+        st.pending += c.n2;
+        // spectrum collection (Decoder.h:467-489)
+        c.fft_fill = (uint32_t)st.fft_fill;
+        if (e->cfg.enable_spectrum && n && st.fft_fill < (size_t)hd::kFftBins && c.n2) {
+            c.fft_take = (uint32_t)std::min<size_t>(hd::kFftBins - st.fft_fill, c.n2);
+            st.fft_fill += c.fft_take;
+        }
+        if (e->cfg.enable_spectrum && n && st.fft_fill >= (size_t)hd::kFftBins) { c.fft_run = 1; st.fft_fill = 0; any_fft = true; }
+        // batch gate, rate gate, low-pass batch (Decoder.h:492-542)
+        const bool past_batch_gate = n && st.pending >= hd::kFirBatch;
+        st.last_m = 0;
+        if (past_batch_gate && !e->decode_enabled) { c.clear_pending = 1; st.pending = 0; }
+        else if (past_batch_gate) {
+            const uint32_t m = (uint32_t)(st.pending - st.pending % hd::kFirBatch);
+            st.lp.batch = m;                                                       // FirFilter::setInput
+            if (st.lp.design(cutoff_rel(e, st), st.lp_trans)) st.taps_dirty = true; // LP_BlackmanHarris, Decoder.h:538
+            const uint32_t T = (uint32_t)st.lp.taps.size();
+            if (!T) return fail(HD_ERR_UNSUPPORTED, "low-pass transition width leaves no taps (reference filters nothing then)");
+            if (T > e->taps_cap) return fail(HD_ERR_CAPACITY, "low-pass tap count exceeds engine capacity");
+            if (st.fir_buf < (size_t)m + T) { st.fir_buf = (size_t)m + T; c.fir_zero_hist = 1; }   // FirFilter.h:141-147
+            c.fir_m = m; c.fir_taps = T;
+            st.pending -= m;
+            st.last_m = m;
+            max_m = std::max(max_m, m);
+            max_taps = std::max(max_taps, T);
+            const uint32_t hb = (st.held > hd::kVentLimit ? 0u : st.held) + m;
+            max_held = std::max(max_held, hb);
+        }
+        c.pend_after = (uint32_t)st.pending;
+        st.last_n2 = c.n2; st.last_pend_before = c.pend_before; st.last_buf = e->cur;
+        e->h_call.p[s] = c;
+        max_in = std::max(max_in, n); max_n1 = std::max(max_n1, c.n1); max_n2 = std::max(max_n2, c.n2);
+        any_dc |= c.dc_remove != 0;
+        total_in += n;
+    }
+    // ---- uploads: per-call parameters, changed low-pass designs, changed symbol parameters
+    hipStream_t q = e->stream;
+    HD_HIP(hipMemcpyAsync(e->d_call.p, e->h_call.p, S * sizeof(hd::StreamCall), hipMemcpyHostToDevice, q));
+    for (uint32_t s = 0; s < S; ++s) {
+        StreamHost& st = e->st[s];
+        if (!st.taps_dirty) continue;
+        // identical designs are common (all streams share defaults): upload from the first dirty stream's copy
+        HD_HIP(hipMemcpyAsync(e->lp_taps.p + (size_t)s * e->taps_cap, st.lp.taps.data(), st.lp.taps.size() * 4, hipMemcpyHostToDevice, q));
+        st.taps_dirty = false;
+    }
+    if (e->sym_dirty) {
+        uint32_t mr = 4;
+        for (uint32_t s = 0; s < S; ++s) { e->h_sym.p[s] = symbol_params(e, e->st[s]); mr = std::max(mr, e->h_sym.p[s].R); }
+        e->max_R = mr;
+        HD_HIP(hipMemcpyAsync(e->d_sym.p, e->h_sym.p, S * sizeof(hd::SymbolParams), hipMemcpyHostToDevice, q));
+        e->sym_dirty = false;
+    }
+    // ---- kernels
+    const float2* iq = static_cast<const float2*>(d_iq);
+    float2* fcur = e->fbuf[e->cur].p;
+    float2* fnext = e->fbuf[e->cur ^ 1].p;
+    if (e->timing_on) HD_HIP(hipEventRecord(e->ev[0], q));
+    if (nst == 0) {
+        hd::launch_passthrough(q, S, max_in, iq, stride, fcur, e->fbuf_stride, e->d_call.p, e->fir_hist_cap);
+        if (e->timing_on) { HD_HIP(hipEventRecord(e->ev[1], q)); HD_HIP(hipEventRecord(e->ev[2], q)); }
+    } else {
+        const bool single = nst == 1;
+        float2* out1 = single ? fcur : e->dec1.p;
+        const size_t out1_stride = single ? e->fbuf_stride : e->n1_cap;
+        if (e->timing_on) HD_HIP(hipEventRecord(e->ev[1], q));
+        if (!hd::launch_decimate(q, R1, T1, S, max_n1, iq, stride, e->hist1.p, e->stage_taps[0].p, out1, out1_stride, e->d_call.p, 0,
+                                 single ? 1 : 0, e->fir_hist_cap))
+            return fail(HD_ERR_INVALID, "no kernel for this decimation stage");
+        if (e->timing_on) HD_HIP(hipEventRecord(e->ev[2], q));
+        if (max_in)
+            hd::launch_decim_history(q, R1, T1, S, iq, stride, out1, out1_stride, e->hist1.p, e->d_call.p, 0, single ? 1 : 0, e->fir_hist_cap);
+        if (!single) {
+            if (!hd::launch_decimate(q, R2, T2, S, max_n2, e->dec1.p, e->n1_cap, e->hist2.p, e->stage_taps[1].p, fcur, e->fbuf_stride,
+                                     e->d_call.p, 1, 1, e->fir_hist_cap))
+                return fail(HD_ERR_INVALID, "no kernel for this decimation stage");
+            if (max_n1)
+                hd::launch_decim_history(q, R2, T2, S, e->dec1.p, e->n1_cap, fcur, e->fbuf_stride, e->hist2.p, e->d_call.p, 1, 1, e->fir_hist_cap);
+        }
+    }
+    if (any_dc) hd::launch_dc_remove(q, S, fcur, e->fbuf_stride, e->d_call.p, e->fir_hist_cap);
+    if (e->cfg.enable_spectrum && max_n2) {
+        hd::launch_fft_feed(q, S, fcur, e->fbuf_stride, e->fft_in.p, e->d_call.p, e->fir_hist_cap);
+        if (any_fft) {
+            void* in[1] = {e->fft_in.p};
+            void* outb[1] = {e->fft_raw.p};
+            if (rocfft_execute(e->fft_plan, in, outb, e->fft_info) != rocfft_status_success) return fail(HD_ERR_DEVICE, "rocfft_execute failed");
+            hd::launch_spectrum_commit(q, S, e->fft_raw.p, e->spec.p, e->power.p, e->d_stats.p, e->d_call.p, e->fsd, e->bins_sep);
+            HD_HIP(hipMemcpyAsync(e->h_stats.p, e->d_stats.p, S * sizeof(hd::SpectrumStatsDev), hipMemcpyDeviceToHost, q));
+        }
+    }
+    const int cin = e->carry_cur, cout = e->carry_cur ^ 1;
+    hd::launch_fir_demod(q, S, max_m, max_taps, fcur, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S,
+                         e->cfg.keep_filtered ? e->filtered.p : nullptr, e->carry[cin].p, e->carry[cout].p, e->d_call.p, e->fir_hist_cap);
+    hd::launch_fbuf_shift(q, S, fcur, fnext, e->fbuf_stride, e->d_call.p, e->fir_hist_cap);
+    hd::launch_symbols(q, S, max_m, max_held, e->max_R, e->demod.p, e->demod.n / S, e->tail.p, e->tail_cap, e->held.p, e->flipmask.p,
+                       e->weight.p, e->d_sym.p, e->d_call.p, e->slots.p, e->slot_words, e->flips_cap ? e->flips_dbg.p : nullptr, e->flips_cap);
+    HD_HIP(hipMemcpyAsync(e->h_slots.p, e->slots.p, (size_t)S * e->slot_words * 4, hipMemcpyDeviceToHost, q));
+    if (e->timing_on) HD_HIP(hipEventRecord(e->ev[3], q));
+    HD_HIP(hipGetLastError());
+    HD_HIP(hipStreamSynchronize(q));
+    e->cur ^= 1;
+    e->carry_cur ^= 1;
+    if (e->timing_on) {
+        float a = 0, b = 0;
+        HD_HIP(hipEventElapsedTime(&a, e->ev[0], e->ev[3]));
+        HD_HIP(hipEventElapsedTime(&b, e->ev[1], e->ev[2]));
+        e->last_timing.ms_total = a;
+        e->last_timing.ms_front = b;
+        e->last_timing.samples = total_in;
+        e->last_timing.front_bytes = total_in * 8 + (total_in / R1) * 8;
+    }
+
+    // ---- host stages, stream by stream (Decoder.h:501-515, 559-637)
+    for (uint32_t s = 0; s < S; ++s) {
+        StreamHost& st = e->st[s];
+        const hd::StreamCall& c = e->h_call.p[s];
+        if (c.fft_run) {
+            std::memcpy(&st.stats, &e->h_stats.p[s], sizeof(st.stats));
+            st.have_spectrum = true;
+            ++st.spectra;
+        }
+        const bool past_batch_gate = c.fir_m || c.clear_pending;
+        if (past_batch_gate && e->cfg.enable_spectrum) st.afc.step(st.have_spectrum, st.stats, hd::kFftBins, e->fsd);
+        const uint32_t* slot = e->h_slots.p + (size_t)s * e->slot_words;
+        const hd::BitsHeader* hdr = reinterpret_cast<const hd::BitsHeader*>(slot);
+        st.held = hdr->held_after;
+        st.last_nbits = hdr->nbits; st.last_nflips = hdr->nflips;
+        if (hdr->overflow) return fail(HD_ERR_CAPACITY, "symbol result slot overflow on stream " + std::to_string(s));
+        const uint32_t* words = slot + sizeof(hd::BitsHeader) / 4;
+        st.last_words.assign(words, words + (hdr->nbits + 31) / 32);
+        if (!c.fir_m) continue;
+        if (hdr->nbits) st.text.framer.push_packed(words, hdr->nbits);
+        const std::string chars = st.text.run(hdr->nbits != 0, [&](const hd::SentenceMatch& m) {
+            ++e->sentences_ok;
+            if (e->sentence_cb) e->sentence_cb(e->sentence_user, s, m.callsign.c_str(), m.data.c_str(), m.crc.c_str());
+        });
+        if (!chars.empty() && e->chars_cb) e->chars_cb(e->chars_user, s, chars.data(), chars.size());
+    }
+    return HD_OK;
+}
+
+int hd_process_host(hd_engine* e, const float* iq, size_t stride, const uint32_t* n_per_stream, uint32_t n_uniform)
+{
+    if (!e) return fail(HD_ERR_INVALID, "null engine");
+    if (!iq) return fail(HD_ERR_INVALID, "null IQ pointer");
+    HD_HIP(hipSetDevice(e->cfg.device));
+    const size_t dstride = e->cfg.max_chunk;
+    if (!n_per_stream) {
+        if (n_uniform > e->cfg.max_chunk) return fail(HD_ERR_CAPACITY, "more samples than max_chunk");
+        if (n_uniform)
+            HD_HIP(hipMemcpy2DAsync(e->staging.p, dstride * sizeof(float2), iq, stride * sizeof(float2), (size_t)n_uniform * sizeof(float2),
+                                    e->S, hipMemcpyHostToDevice, e->stream));
+    } else {
+        for (uint32_t s = 0; s < e->S; ++s) {
+            const uint32_t n = n_per_stream[s];
+            if (n > e->cfg.max_chunk) return fail(HD_ERR_CAPACITY, "more samples than max_chunk");
+            if (n) HD_HIP(hipMemcpyAsync(e->staging.p + (size_t)s * dstride, iq + 2 * (size_t)s * stride, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, e->stream));
+        }
+    }
+    return hd_process_device(e, e->staging.p, dstride, n_per_stream, n_uniform);
+}
+
+/* ---------------------------------------------------------------- results -------------------------------------- */
+
+static size_t copy_out(const std::string& s, char* buf, size_t cap)
+{
+    if (buf && cap) { const size_t n = std::min(cap - 1, s.size()); std::memcpy(buf, s.data(), n); buf[n] = 0; }
+    return s.size();
+}
+static size_t take_out(std::string& s, char* buf, size_t cap)
+{
+    const size_t n = copy_out(s, buf, cap);
+    if (buf && cap > n) s.clear();
+    return n;
+}
+
+size_t hd_stream_rtty(hd_engine* e, uint32_t s, char* buf, size_t cap)
+{ if (check_stream(e, s)) return 0; std::lock_guard<std::mutex> l(e->mtx); return copy_out(e->st[s].text.stream, buf, cap); }
+size_t hd_stream_last_sentence(hd_engine* e, uint32_t s, char* buf, size_t cap)
+{ if (check_stream(e, s)) return 0; std::lock_guard<std::mutex> l(e->mtx); return copy_out(e->st[s].text.last_sentence, buf, cap); }
+size_t hd_stream_take_sentences(hd_engine* e, uint32_t s, char* buf, size_t cap)
+{ if (check_stream(e, s)) return 0; std::lock_guard<std::mutex> l(e->mtx); return take_out(e->st[s].text.ok_log, buf, cap); }
+size_t hd_stream_take_matches(hd_engine* e, uint32_t s, char* buf, size_t cap)
+{ if (check_stream(e, s)) return 0; std::lock_guard<std::mutex> l(e->mtx); return take_out(e->st[s].text.match_log, buf, cap); }
+size_t hd_stream_take_chars(hd_engine* e, uint32_t s, char* buf, size_t cap)
+{ if (check_stream(e, s)) return 0; std::lock_guard<std::mutex> l(e->mtx); return take_out(e->st[s].text.char_log, buf, cap); }
+
+int hd_stream_afc(hd_engine* e, uint32_t s, hd_afc_info* out)
+{
+    if (int r = check_stream(e, s)) return r;
+    if (!out) return fail(HD_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> l(e->mtx);
+    const StreamHost& st = e->st[s];
+    out->frequency_correction = st.afc.correction; out->shift_hz = st.afc.shift_hz;
+    out->noise_floor = st.afc.noise_floor; out->noise_variance = st.afc.noise_sigma;
+    out->peak_left = st.afc.gui_left; out->peak_right = st.afc.gui_right; out->spectra = st.spectra;
+    return HD_OK;
+}
+
+static size_t fetch(hd_engine* e, const void* dev, size_t count, size_t elem, void* host, size_t cap)
+{
+    const size_t n = std::min(count, cap);
+    if (!n || !host) return count;
+    if (hipSetDevice(e->cfg.device) != hipSuccess) return 0;
+    if (hipMemcpy(host, dev, n * elem, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return count;
+}
+
+size_t hd_stream_spectrum(hd_engine* e, uint32_t s, float* iq, size_t cap)
+{
+    if (check_stream(e, s)) return 0;
+    std::lock_guard<std::mutex> l(e->mtx);
+    if (!e->cfg.enable_spectrum || !e->st[s].have_spectrum) return 0;
+    return fetch(e, e->spec.p + (size_t)s * hd::kFftBins, hd::kFftBins, sizeof(float2), iq, cap);
+}
+size_t hd_stream_power(hd_engine* e, uint32_t s, float* p, size_t cap)
+{
+    if (check_stream(e, s)) return 0;
+    std::lock_guard<std::mutex> l(e->mtx);
+    if (!e->cfg.enable_spectrum || !e->st[s].have_spectrum) return 0;
+    return fetch(e, e->power.p + (size_t)s * hd::kFftBins, hd::kFftBins, sizeof(float), p, cap);
+}
+size_t hd_stream_demodulated(hd_engine* e, uint32_t s, float* v, size_t cap)
+{
+    if (check_stream(e, s)) return 0;
+    std::lock_guard<std::mutex> l(e->mtx);
+    return fetch(e, e->demod.p + (size_t)s * (e->demod.n / e->S), e->st[s].last_m, sizeof(float), v, cap);
+}
+size_t hd_stream_decimated(hd_engine* e, uint32_t s, float* iq, size_t cap)
+{
+    if (check_stream(e, s)) return 0;
+    std::lock_guard<std::mutex> l(e->mtx);
+    const StreamHost& st = e->st[s];
+    const float2* src = e->fbuf[st.last_buf].p + (size_t)s * e->fbuf_stride + e->fir_hist_cap + st.last_pend_before;
+    return fetch(e, src, st.last_n2, sizeof(float2), iq, cap);
+}
+size_t hd_stream_filtered(hd_engine* e, uint32_t s, float* iq, size_t cap)
+{
+    if (check_stream(e, s)) return 0;
+    std::lock_guard<std::mutex> l(e->mtx);
+    if (!e->cfg.keep_filtered) return 0;
+    return fetch(e, e->filtered.p + (size_t)s * (e->demod.n / e->S), e->st[s].last_m, sizeof(float2), iq, cap);
+}
+size_t hd_stream_bits(hd_engine* e, uint32_t s, uint8_t* bits, size_t cap)
+{
+    if (check_stream(e, s)) return 0;
+    std::lock_guard<std::mutex> l(e->mtx);
+    const StreamHost& st = e->st[s];
+    for (uint32_t i = 0; i < st.last_nbits && i < cap; ++i) bits[i] = (st.last_words[i >> 5] >> (i & 31)) & 1u;
+    return st.last_nbits;
+}
+size_t hd_stream_flips(hd_engine* e, uint32_t s, uint32_t* flips, size_t cap)
+{
+    if (check_stream(e, s)) return 0;
+    std::lock_guard<std::mutex> l(e->mtx);
+    if (!e->flips_cap) return 0;
+    const size_t n = std::min<size_t>(e->st[s].last_nflips, e->flips_cap);
+    return fetch(e, e->flips_dbg.p + (size_t)s * e->flips_cap, n, sizeof(uint32_t), flips, cap);
+}
+size_t hd_stream_fir_taps(hd_engine* e, uint32_t s, float* taps, size_t cap)
+{
+    if (check_stream(e, s)) return 0;
+    std::lock_guard<std::mutex> l(e->mtx);
+    const auto& t = e->st[s].lp.taps;
+    if (taps) std::memcpy(taps, t.data(), std::min(cap, t.size()) * sizeof(float));
+    return t.size();
+}
+uint32_t hd_stream_symbol_backlog(hd_engine* e, uint32_t s)
+{
+    if (check_stream(e, s)) return 0;
+    std::lock_guard<std::mutex> l(e->mtx);
+    return e->st[s].held;
+}
+
+}  // extern "C"

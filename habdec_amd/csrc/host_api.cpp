@@ -1,0 +1,112 @@
+// C ABI over the host-side routines of the engine (include/habdec_amd_host.h).  No HIP calls in here.
+#include <algorithm>
+#include <cstring>
+#include <string>
+
+#include "../../include/habdec_amd_host.h"
+#include "host/afc_tracker.hpp"
+#include "host/decim_plan.hpp"
+#include "host/fir_design.hpp"
+#include "host/text_stage.hpp"
+#include "kernels/exact_math.h"
+
+struct hd_host_rtty { hd::RttyFramer f; };
+struct hd_host_text { hd::TextStage t; };
+struct hd_host_afc { hd::AfcTracker a; };
+
+static void put(char* dst, size_t cap, const std::string& s)
+{
+    if (!dst || !cap) return;
+    const size_t n = std::min(cap - 1, s.size());
+    std::memcpy(dst, s.data(), n);
+    dst[n] = 0;
+}
+
+extern "C" {
+
+int hd_host_decim_plan(unsigned total, int ratio[2], unsigned ntaps[2])
+{
+    std::vector<hd::DecimStage> st;
+    if (!hd::decim_plan(total, st)) return -1;
+    for (size_t i = 0; i < st.size(); ++i) { ratio[i] = st[i].ratio; ntaps[i] = (unsigned)st[i].taps.size(); }
+    return (int)st.size();
+}
+size_t hd_host_decim_taps(unsigned total, int stage, float* taps, size_t cap)
+{
+    std::vector<hd::DecimStage> st;
+    if (!hd::decim_plan(total, st) || stage < 0 || (size_t)stage >= st.size()) return 0;
+    const auto& t = st[stage].taps;
+    std::memcpy(taps, t.data(), std::min(cap, t.size()) * sizeof(float));
+    return t.size();
+}
+size_t hd_host_lowpass_design(float cutoff_rel, float transition, size_t batch, size_t prev_ntaps, int float_trig, float* taps, size_t cap)
+{
+    hd::LowpassDesigner d;
+    d.float_trig = float_trig != 0;
+    d.batch = batch;
+    d.taps.assign(prev_ntaps, 0.0f);
+    if (!d.design(cutoff_rel, transition)) return 0;
+    std::memcpy(taps, d.taps.data(), std::min(cap, d.taps.size()) * sizeof(float));
+    return d.taps.size();
+}
+
+hd_host_rtty* hd_host_rtty_new(size_t nbits, float nstops) { auto* r = new hd_host_rtty; r->f.nbits = nbits; r->f.nstops = nstops; return r; }
+void hd_host_rtty_free(hd_host_rtty* r) { delete r; }
+size_t hd_host_rtty_push_run(hd_host_rtty* r, const uint8_t* bits, size_t n, char* out, size_t cap)
+{
+    r->f.push_bits(bits, n);
+    std::string s;
+    r->f.frame(s);
+    std::memcpy(out, s.data(), std::min(cap, s.size()));
+    return s.size();
+}
+
+void hd_host_crc16(const char* s, size_t n, char out4[5])
+{
+    const std::string r = hd::crc16_ccitt_hex(std::string(s, n));
+    std::memcpy(out4, r.c_str(), 5);
+}
+int hd_host_extract_sentence(const char* stream, size_t n, char* callsign, char* data, char* crc, char* rest, size_t cap)
+{
+    hd::SentenceMatch m;
+    if (!hd::extract_sentence(std::string(stream, n), m)) return 0;
+    put(callsign, cap, m.callsign); put(data, cap, m.data); put(crc, cap, m.crc); put(rest, cap, m.rest);
+    return 1;
+}
+
+hd_host_text* hd_host_text_new(size_t nbits, float nstops) { auto* t = new hd_host_text; t->t.framer.nbits = nbits; t->t.framer.nstops = nstops; return t; }
+void hd_host_text_free(hd_host_text* t) { delete t; }
+void hd_host_text_push_bits(hd_host_text* t, const uint8_t* bits, size_t n)
+{
+    if (n) t->t.framer.push_bits(bits, n);
+    t->t.run(n != 0, [](const hd::SentenceMatch&) {});
+}
+size_t hd_host_text_get(hd_host_text* t, int which, char* buf, size_t cap)
+{
+    const std::string* s = &t->t.stream;
+    if (which == 1) s = &t->t.last_sentence; else if (which == 2) s = &t->t.ok_log; else if (which == 3) s = &t->t.match_log; else if (which == 4) s = &t->t.char_log;
+    put(buf, cap, *s);
+    return s->size();
+}
+
+hd_host_afc* hd_host_afc_new(void) { return new hd_host_afc; }
+void hd_host_afc_free(hd_host_afc* a) { delete a; }
+void hd_host_afc_step(hd_host_afc* a, int have, int valid, int p1, int p2, float pw1, float pw2, double mean, double sigma, size_t bins, double rate)
+{
+    hd::SpectrumStats st{};
+    st.valid = valid; st.peak1 = p1; st.peak2 = p2; st.power1 = pw1; st.power2 = pw2; st.mean = mean; st.sigma = sigma;
+    a->a.step(have != 0, st, bins, rate);
+}
+void hd_host_afc_reset(hd_host_afc* a, double c, size_t bins, double rate) { a->a.reset(c, bins, rate); }
+void hd_host_afc_get(hd_host_afc* a, double* c, double* sh, double* nf, double* ns, int* pl, int* pr)
+{
+    *c = a->a.correction; *sh = a->a.shift_hz; *nf = a->a.noise_floor; *ns = a->a.noise_sigma; *pl = a->a.gui_left; *pr = a->a.gui_right;
+}
+
+void hd_host_atan2f(const float* y, const float* x, float* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = hd::exact_atan2f(y[i], x[i]); }
+void hd_host_discriminate(const float* iq, size_t n, float pr, float pi, float* out)
+{
+    for (size_t i = 0; i < n; ++i) { out[i] = hd::discriminate(iq[2 * i], iq[2 * i + 1], pr, pi); pr = iq[2 * i]; pi = iq[2 * i + 1]; }
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// Host-callable launchers of the gfx950 kernels (defined in kernels/*.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../dev_types.h"
+
+namespace hd {
+
+struct DemodCarry {        // per-stream discriminator carry (previous filtered sample), ping-ponged per call
+    float re, im;
+    uint32_t primed;       // 0 until the stream's first FIR batch (FSK2_Demod.h:35 static initialiser)
+    uint32_t _pad;
+};
+
+// One FIR-decimate stage for all streams.  `final_stage`: output lands behind the FIR history in the
+// low-pass input buffer (offset fir_hist_cap + pend_before), else at offset 0 of `out`.
+// Returns false when (ratio, ntaps) is not one of the eight reference designs.
+bool launch_decimate(hipStream_t st, int ratio, int ntaps, uint32_t n_streams, uint32_t max_out,
+                     const float2* in, size_t in_stride, const float2* hist, const float* taps,
+                     float2* out, size_t out_stride, const StreamCall* call, int stage, int final_stage,
+                     uint32_t fir_hist_cap);
+// Carry the last ntaps-1 input samples of every stream into its history (Decimator.h:140-143, incl. Q4).
+void launch_decim_history(hipStream_t st, int ratio, int ntaps, uint32_t n_streams, const float2* in, size_t in_stride,
+                          const float2* out, size_t out_stride, float2* hist, const StreamCall* call, int stage,
+                          int final_stage, uint32_t fir_hist_cap);
+// factor 1: copy the chunk behind the FIR history.
+void launch_passthrough(hipStream_t st, uint32_t n_streams, uint32_t max_n, const float2* in, size_t in_stride,
+                        float2* out, size_t out_stride, const StreamCall* call, uint32_t fir_hist_cap);
+void launch_dc_remove(hipStream_t st, uint32_t n_streams, float2* fbuf, size_t stride, const StreamCall* call, uint32_t fir_hist_cap);
+void launch_fft_feed(hipStream_t st, uint32_t n_streams, const float2* fbuf, size_t stride, float2* fft_in,
+                     const StreamCall* call, uint32_t fir_hist_cap);
+void launch_spectrum_commit(hipStream_t st, uint32_t n_streams, const float2* raw, float2* spec, float* power,
+                            SpectrumStatsDev* stats, const StreamCall* call, double rate, int bins_sep);
+void launch_fir_demod(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_taps, const float2* fbuf, size_t stride,
+                      const float* taps, uint32_t taps_stride, float* demod, size_t demod_stride, float2* filtered /*or null*/,
+                      const DemodCarry* carry_in, DemodCarry* carry_out, const StreamCall* call, uint32_t fir_hist_cap);
+void launch_fbuf_shift(hipStream_t st, uint32_t n_streams, const float2* src, float2* dst, size_t stride,
+                       const StreamCall* call, uint32_t fir_hist_cap);
+void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_held, uint32_t max_R,
+                    const float* demod, size_t demod_stride, float* tail, uint32_t tail_cap, uint32_t* held,
+                    unsigned long long* flipmask, float* weight, const SymbolParams* sp, const StreamCall* call,
+                    uint32_t* slots, uint32_t slot_words, uint32_t* flips_dbg, uint32_t flips_cap);
+
+}  // namespace hd

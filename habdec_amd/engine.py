@@ -1,0 +1,138 @@
+"""Thin Python mirror of the C ABI: one `Engine` = one GPU, S independent IQ streams (tests and bench plumbing)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import capi
+from .capi import check, lib
+
+
+@dataclass
+class EngineConfig:
+    n_streams: int = 1
+    max_chunk: int = 65536
+    sampling_rate: float = 2.048e6
+    decimation: int = 64
+    baud: float = 300.0
+    rtty_bits: int = 8
+    rtty_stops: float = 2.0
+    lowpass_bw_hz: float = 1500.0
+    lowpass_trans: float = 0.025
+    dc_remove: bool = False
+    lookup_mode: int = 1
+    enable_spectrum: bool = True
+    ungated: bool = False
+    keep_filtered: bool = False
+    device: int = 0
+
+
+class Engine:
+    def __init__(self, cfg: EngineConfig | None = None, **kw):
+        cfg = cfg or EngineConfig(**kw)
+        self.cfg = cfg
+        L = lib()
+        c = capi.hd_engine_config()
+        L.hd_engine_config_default(C.byref(c))
+        for k in ("device", "n_streams", "max_chunk", "sampling_rate", "decimation", "baud", "rtty_bits", "rtty_stops",
+                  "lowpass_bw_hz", "lowpass_trans", "lookup_mode"):
+            setattr(c, k, getattr(cfg, k))
+        c.dc_remove, c.enable_spectrum, c.ungated, c.keep_filtered = int(cfg.dc_remove), int(cfg.enable_spectrum), int(cfg.ungated), int(cfg.keep_filtered)
+        h = C.c_void_p()
+        check(L.hd_engine_create(C.byref(c), C.byref(h)))
+        self.h, self.L = h, L
+        self.S = cfg.n_streams
+        self._cbs = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.hd_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- data path
+    def process_host(self, iq: np.ndarray, n: int | None = None):
+        """iq: complex64 [S, stride]; stream s hands over its first n samples."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        if iq.ndim == 1:
+            iq = iq[None, :]
+        assert iq.shape[0] == self.S
+        n = iq.shape[1] if n is None else n
+        check(self.L.hd_process_host(self.h, iq.ctypes.data, iq.shape[1], None, n))
+
+    def process_device(self, dev_ptr: int, stride: int, n: int):
+        check(self.L.hd_process_device(self.h, dev_ptr, stride, None, n))
+
+    # ---- control
+    def set_baud(self, s, baud): check(self.L.hd_stream_set_baud(self.h, s, baud))
+    def set_rtty(self, s, bits, stops): check(self.L.hd_stream_set_rtty(self.h, s, bits, stops))
+    def set_lowpass_bw(self, s, hz): check(self.L.hd_stream_set_lowpass_bw(self.h, s, hz))
+    def set_lowpass_trans(self, s, t): check(self.L.hd_stream_set_lowpass_trans(self.h, s, t))
+    def set_dc_remove(self, s, on): check(self.L.hd_stream_set_dc_remove(self.h, s, int(on)))
+    def reset_frequency_correction(self, s, c): check(self.L.hd_stream_reset_frequency_correction(self.h, s, c))
+
+    def on_sentence(self, fn):
+        cb = capi.SENTENCE_CB(lambda user, s, call, data, crc: fn(s, call.decode("latin-1"), data.decode("latin-1"), crc.decode("latin-1")))
+        self._cbs.append(cb)
+        self.L.hd_set_sentence_callback(self.h, cb, None)
+
+    # ---- results
+    def _text(self, fn, s, cap=1 << 16) -> str:
+        buf = C.create_string_buffer(cap)
+        n = fn(self.h, s, buf, cap)
+        if n >= cap:
+            return self._text(fn, s, n + 1)
+        return buf.raw[:n].decode("latin-1")
+
+    def rtty(self, s=0): return self._text(self.L.hd_stream_rtty, s)
+    def last_sentence(self, s=0): return self._text(self.L.hd_stream_last_sentence, s)
+    def take_sentences(self, s=0): return [x for x in self._text(self.L.hd_stream_take_sentences, s).split("\n") if x]
+    def take_matches(self, s=0): return [x for x in self._text(self.L.hd_stream_take_matches, s).split("\n") if x]
+    def take_chars(self, s=0): return self._text(self.L.hd_stream_take_chars, s)
+    def sentences_ok(self) -> int: return self.L.hd_engine_sentences_ok(self.h)
+
+    def afc(self, s=0) -> dict:
+        a = capi.hd_afc_info()
+        check(self.L.hd_stream_afc(self.h, s, C.byref(a)))
+        return {"correction": a.frequency_correction, "shift_hz": a.shift_hz, "noise_floor": a.noise_floor,
+                "noise_var": a.noise_variance, "peak_l": a.peak_left, "peak_r": a.peak_right, "spectra": a.spectra}
+
+    def _arr(self, fn, s, cplx, cap):
+        buf = np.zeros(cap * (2 if cplx else 1), np.float32)
+        n = fn(self.h, s, buf, cap)
+        if n > cap:
+            return self._arr(fn, s, cplx, n)
+        out = buf[: n * (2 if cplx else 1)]
+        return out.view(np.complex64) if cplx else out
+
+    def spectrum(self, s=0): return self._arr(self.L.hd_stream_spectrum, s, True, 4096)
+    def power(self, s=0): return self._arr(self.L.hd_stream_power, s, False, 4096)
+    def demodulated(self, s=0): return self._arr(self.L.hd_stream_demodulated, s, False, 1 << 15)
+    def decimated(self, s=0): return self._arr(self.L.hd_stream_decimated, s, True, 1 << 16)
+    def filtered(self, s=0): return self._arr(self.L.hd_stream_filtered, s, True, 1 << 15)
+    def fir_taps(self, s=0): return self._arr(self.L.hd_stream_fir_taps, s, False, 8192)
+
+    def bits(self, s=0) -> np.ndarray:
+        cap = 1 << 16
+        buf = np.zeros(cap, np.uint8)
+        n = self.L.hd_stream_bits(self.h, s, buf, cap)
+        return buf[:n].copy()
+
+    def flips(self, s=0) -> np.ndarray:
+        buf = np.zeros(4096, np.uint32)
+        n = self.L.hd_stream_flips(self.h, s, buf, 4096)
+        return buf[:n].copy()
+
+    def symbol_backlog(self, s=0) -> int: return self.L.hd_stream_symbol_backlog(self.h, s)
+
+    def timing(self) -> dict:
+        t = capi.hd_timing()
+        check(self.L.hd_engine_timing(self.h, C.byref(t)))
+        return {"ms_total": t.ms_total, "ms_front": t.ms_front, "front_bytes": t.front_bytes, "samples": t.samples}

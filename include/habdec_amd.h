@@ -1,0 +1,151 @@
+/*
+ * habdec_amd.h -- C ABI of the MI355X-native RTTY demodulation engine (libhabdec_amd.so).
+ *
+ * This is the drop-in boundary underneath a source-compatible `habdec::Decoder<T>`
+ * (habdec_amd/include/habdec/Decoder.h).  The reference has no FFI for this path -- its boundary is the
+ * public surface of the header-only class template `habdec::Decoder<TReal>` (reference
+ * code/Decoder/Decoder.h:65-141) -- so every entry point below names the reference member(s) it stands in
+ * for.  Plain C types only: no C++, no torch, no HIP types cross this line.
+ *
+ * Model: one *engine* per GPU owns S independent *streams* (S = 1 for the websocket server's single
+ * decoder, thousands for batch decoding).  All streams of an engine share the input sampling rate and
+ * the decimation plan; baud / framing / low-pass settings are per stream.  One `hd_process_*` call is one
+ * `pushSamples()+operator()()` round (reference code/websocketServer/main.cpp:240-245) for every stream.
+ *
+ * Threading: an engine is driven by ONE thread at a time for hd_process_* (like the reference's
+ * DECODER_THREAD); getters/setters may be called from other threads and are serialised by an internal
+ * mutex (reference Decoder.h:209,229,240,423).  Callbacks fire synchronously inside hd_process_*, in
+ * stream order, on the calling thread (reference Decoder.h:604-606,625-626).
+ *
+ * Errors: every function returning `int` returns HD_OK (0) or a negative HD_ERR_*; hd_last_error() gives
+ * the message of the last failure on the calling thread.  The reference itself reports problems by printing
+ * and carrying on (Decoder.h:272-276, FirFilter.h:121-137); conditions it tolerates are tolerated here too,
+ * conditions that are undefined behaviour there (an input shorter than a stage's history, Decimator.h:140-143)
+ * are rejected with HD_ERR_UNSUPPORTED.
+ */
+#ifndef HABDEC_AMD_H
+#define HABDEC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HD_OK 0
+#define HD_ERR_INVALID (-1)      /* bad argument */
+#define HD_ERR_DEVICE (-2)       /* HIP / rocFFT failure, or no gfx950 device */
+#define HD_ERR_UNSUPPORTED (-3)  /* input the reference has undefined behaviour on */
+#define HD_ERR_CAPACITY (-4)     /* more samples than the engine was sized for */
+
+#define HD_FFT_BINS 4096         /* reference Decoder.h:162 fft_bins_cnt_ */
+
+typedef struct hd_engine hd_engine;
+
+typedef struct hd_engine_config {
+    int32_t  device;            /* HIP device ordinal */
+    uint32_t n_streams;         /* S >= 1 */
+    uint32_t max_chunk;         /* most IQ samples one stream hands to one hd_process_* call (65536 in main.cpp:235) */
+    double   sampling_rate;     /* IQVector::samplingRate() latched by the first pushSamples (Decoder.h:215-216) */
+    uint32_t decimation;        /* total factor 1,2,4,...,256 = setupDecimationStagesFactor(2^dec) (Decoder.h:268-332) */
+    /* per-stream defaults; reference defaults in websocketServer/GLOBALS.h:87-100 and Decoder.h:172-173 */
+    double   baud;              /* Decoder::baud()           */
+    uint32_t rtty_bits;         /* Decoder::rtty_bits()  7|8 */
+    float    rtty_stops;        /* Decoder::rtty_stops() 1|2 */
+    float    lowpass_bw_hz;     /* Decoder::lowpass_bw()     */
+    float    lowpass_trans;     /* Decoder::lowpass_trans()  */
+    int32_t  dc_remove;         /* Decoder::dc_remove()      */
+    /* How the reference's unqualified sin/cos/abs calls resolved in the translation unit that compiled it
+     * (DESIGN.md "lookup context"): 1 = <math.h> context (float trig in the tap design, float |.| in the
+     * flip-point weights; default), 0 = <cmath>-only context (double trig, integer abs). */
+    int32_t  lookup_mode;
+    int32_t  enable_spectrum;   /* 1 = run the 4096-bin spectrum + AFC like the reference, 0 = skip (stage benchmarks) */
+    /* 0 = keep the reference's decode gate: above 160 kHz decimated rate only decimation/FFT/AFC run
+     * (Decoder.h:522-527).  1 = stage-level mode: FIR/demod/symbols run at any rate (BASELINE config 3). */
+    int32_t  ungated;
+    int32_t  keep_filtered;     /* 1 = also store the FIR output so hd_stream_filtered() works (parity tests) */
+} hd_engine_config;
+
+/* Fill `cfg` with the reference defaults (dec 64, 300 baud 8N2, low-pass 1500 Hz / 0.025, spectrum on). */
+void hd_engine_config_default(hd_engine_config* cfg);
+
+/* Decoder construction + setupDecimationStagesFactor (Decoder.h:268-332) for S streams on one GPU. */
+int  hd_engine_create(const hd_engine_config* cfg, hd_engine** out);
+void hd_engine_destroy(hd_engine* e);
+const char* hd_last_error(void);
+uint32_t hd_engine_streams(const hd_engine* e);
+/* getDecimationFactor / getDecimatedSamplingRate (Decoder.h:716-735) */
+uint32_t hd_engine_decimation(const hd_engine* e);
+double   hd_engine_decimated_rate(const hd_engine* e);
+
+/* ---- per-stream control plane: the reference setters of the same names (Decoder.h:238-257, 655-712) ---- */
+int hd_stream_set_baud(hd_engine* e, uint32_t stream, double baud);
+int hd_stream_set_rtty(hd_engine* e, uint32_t stream, uint32_t bits, float stops);
+int hd_stream_set_lowpass_bw(hd_engine* e, uint32_t stream, float hz);
+int hd_stream_set_lowpass_trans(hd_engine* e, uint32_t stream, float trans);
+int hd_stream_set_dc_remove(hd_engine* e, uint32_t stream, int on);
+/* resetFrequencyCorrection (Decoder.h:806-809 -> AFC.h:187-194) */
+int hd_stream_reset_frequency_correction(hd_engine* e, uint32_t stream, double correction);
+
+/* ---- callbacks: Decoder::sentence_callback_ / character_callback_ (Decoder.h:135-138) ---- */
+typedef void (*hd_sentence_cb)(void* user, uint32_t stream, const char* callsign, const char* data, const char* crc);
+typedef void (*hd_chars_cb)(void* user, uint32_t stream, const char* chars, size_t n);
+void hd_set_sentence_callback(hd_engine* e, hd_sentence_cb cb, void* user);   /* fires only on CRC match */
+void hd_set_chars_callback(hd_engine* e, hd_chars_cb cb, void* user);         /* printable chars of this call */
+
+/* ---- data path: pushSamples() + operator()() (Decoder.h:206-219, 416-638) for all S streams ----
+ * Stream s reads `n` cf32 samples (interleaved I,Q float32: the IQSource_File layout, IQSource_File.h:156-157)
+ * starting at `iq + 2*s*stream_stride` floats.  `n_per_stream` (S entries) overrides the uniform `n` when not
+ * NULL.  Every n must be <= max_chunk and a multiple of the decimation factor (the Decoder facade keeps the
+ * remainder queued on the host exactly like Decoder.h:429-435).  Returns after the decoded text of this
+ * call has been delivered (callbacks fired, getters updated). */
+int hd_process_host(hd_engine* e, const float* iq, size_t stream_stride, const uint32_t* n_per_stream, uint32_t n);
+/* Same, but `d_iq` is DEVICE memory on the engine's GPU (HBM-resident batches; base 16-byte aligned,
+ * stream_stride even). */
+int hd_process_device(hd_engine* e, const void* d_iq, size_t stream_stride, const uint32_t* n_per_stream, uint32_t n);
+
+/* ---- results: getRTTY / getLastSentence (Decoder.h:641-652) and the callback streams ---- */
+size_t hd_stream_rtty(hd_engine* e, uint32_t stream, char* buf, size_t cap);
+size_t hd_stream_last_sentence(hd_engine* e, uint32_t stream, char* buf, size_t cap);
+/* drain the log of CRC-valid sentences ("callsign,data*crc\n" each) / of all regex matches / of printable chars */
+size_t hd_stream_take_sentences(hd_engine* e, uint32_t stream, char* buf, size_t cap);
+size_t hd_stream_take_matches(hd_engine* e, uint32_t stream, char* buf, size_t cap);
+size_t hd_stream_take_chars(hd_engine* e, uint32_t stream, char* buf, size_t cap);
+uint64_t hd_engine_sentences_ok(const hd_engine* e);   /* CRC-valid sentences over all streams so far */
+
+/* ---- GUI data: getFFT / getDemodulated / getPowerSpectrum / getPeaks / getNoiseFloor / getShift /
+ *      getFrequencyCorrection (Decoder.h:751-803) ---- */
+typedef struct hd_afc_info {
+    double frequency_correction, shift_hz, noise_floor, noise_variance;
+    int32_t peak_left, peak_right;      /* sign encodes validity like AFC::getPeaks (AFC.h:146-162) */
+    uint64_t spectra;                    /* number of 4096-bin spectra computed so far */
+} hd_afc_info;
+int    hd_stream_afc(hd_engine* e, uint32_t stream, hd_afc_info* out);
+size_t hd_stream_spectrum(hd_engine* e, uint32_t stream, float* iq, size_t cap_complex);   /* freq_out_, fftshifted */
+size_t hd_stream_power(hd_engine* e, uint32_t stream, float* p, size_t cap);
+size_t hd_stream_demodulated(hd_engine* e, uint32_t stream, float* v, size_t cap);         /* last call */
+
+/* ---- parity taps (not in the reference API; the intermediates its process() holds in members) ---- */
+size_t hd_stream_decimated(hd_engine* e, uint32_t stream, float* iq, size_t cap_complex);  /* iq_samples_temp_ of the last call */
+size_t hd_stream_filtered(hd_engine* e, uint32_t stream, float* iq, size_t cap_complex);   /* iq_samples_filtered_ (keep_filtered=1) */
+size_t hd_stream_bits(hd_engine* e, uint32_t stream, uint8_t* bits, size_t cap);           /* symbols of the last call */
+size_t hd_stream_flips(hd_engine* e, uint32_t stream, uint32_t* flips, size_t cap);        /* flip points of the last call */
+size_t hd_stream_fir_taps(hd_engine* e, uint32_t stream, float* taps, size_t cap);
+uint32_t hd_stream_symbol_backlog(hd_engine* e, uint32_t stream);                          /* samples held by the symbol extractor */
+
+/* ---- measurement ---- */
+typedef struct hd_timing {
+    double ms_total;        /* HIP-event time of the whole kernel sequence of the last hd_process_* call */
+    double ms_front;        /* of its first-stage decimation kernel (the only kernel that touches full-rate IQ) */
+    uint64_t front_bytes;   /* algorithmic bytes of that launch: 8 B per input sample + 8 B per output sample */
+    uint64_t samples;       /* input samples consumed by the last call over all streams */
+} hd_timing;
+int hd_engine_timing(hd_engine* e, hd_timing* out);
+/* 1 = bracket kernels with HIP events on every call (default 1; tiny overhead) */
+void hd_engine_set_timing(hd_engine* e, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HABDEC_AMD_H */

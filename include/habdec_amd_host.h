@@ -1,0 +1,62 @@
+/*
+ * habdec_amd_host.h -- C ABI of the HOST-side pieces of the path (no GPU needed to call these).
+ *
+ * They are the exact routines the engine uses around its kernels: the decimation plan and coefficient tables,
+ * the low-pass design, RTTY framing, sentence extraction + CRC, the AFC state machine, and the float-only
+ * atan2f restatement the discriminator kernel runs.  Exported so integrators and the CPU test-suite can drive
+ * them directly; each names the reference routine it stands in for.
+ */
+#ifndef HABDEC_AMD_HOST_H
+#define HABDEC_AMD_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Decoder::setupDecimationStagesFactor's stage choice (Decoder.h:286-320): returns the stage count (0..2) or -1;
+ * ratio[i], ntaps[i] describe stage i. */
+int hd_host_decim_plan(unsigned total_factor, int ratio[2], unsigned ntaps[2]);
+/* coefficients of stage `stage` of that plan (filtercoef.h tables); returns the count copied */
+size_t hd_host_decim_taps(unsigned total_factor, int stage, float* taps, size_t cap);
+
+/* FirFilter::LP_BlackmanHarris (FirFilter.h:173-209): design for `batch` input samples; `prev_ntaps` is the tap
+ * count currently in use (a design of equal length is skipped -> returns 0).  float_trig: DESIGN.md lookup context. */
+size_t hd_host_lowpass_design(float cutoff_rel, float transition, size_t batch, size_t prev_ntaps, int float_trig,
+                              float* taps, size_t cap);
+
+/* RTTY<bool> (RTTY.h:59-137) */
+typedef struct hd_host_rtty hd_host_rtty;
+hd_host_rtty* hd_host_rtty_new(size_t nbits, float nstops);
+void hd_host_rtty_free(hd_host_rtty*);
+size_t hd_host_rtty_push_run(hd_host_rtty*, const uint8_t* bits, size_t n, char* out, size_t cap);
+
+/* CRC (CRC.cpp:21-47) and extractSentence (sentence_extract.cpp:58-98) */
+void hd_host_crc16(const char* s, size_t n, char out4[5]);
+int hd_host_extract_sentence(const char* stream, size_t n, char* callsign, char* data, char* crc, char* rest, size_t cap);
+
+/* Decoder text stage (Decoder.h:568-637) on raw framed bytes */
+typedef struct hd_host_text hd_host_text;
+hd_host_text* hd_host_text_new(size_t nbits, float nstops);
+void hd_host_text_free(hd_host_text*);
+void hd_host_text_push_bits(hd_host_text*, const uint8_t* bits, size_t n);
+size_t hd_host_text_get(hd_host_text*, int which /*0 rtty stream,1 last sentence,2 ok log,3 match log,4 chars log*/, char* buf, size_t cap);
+
+/* AFC::process after the spectrum reductions (AFC.h:108-184) + resetFrequencyCorrection (AFC.h:187-194) */
+typedef struct hd_host_afc hd_host_afc;
+hd_host_afc* hd_host_afc_new(void);
+void hd_host_afc_free(hd_host_afc*);
+void hd_host_afc_step(hd_host_afc*, int have_spectrum, int valid, int peak1, int peak2, float power1, float power2,
+                      double mean, double sigma, size_t bins, double rate);
+void hd_host_afc_reset(hd_host_afc*, double correction, size_t bins, double rate);
+void hd_host_afc_get(hd_host_afc*, double* correction, double* shift_hz, double* noise_floor, double* noise_sigma,
+                     int* peak_l, int* peak_r);
+
+/* the discriminator's arithmetic, compiled for the host: bit-identical to glibc atan2f (FSK2_Demod.h:38) */
+void hd_host_atan2f(const float* y, const float* x, float* out, size_t n);
+void hd_host_discriminate(const float* iq, size_t n, float prev_re, float prev_im, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -615,6 +615,7 @@ struct orc_decoder {
     int factor = 1;
     bool dc = false;
     bool with_fft = true;
+    bool ungated = false;       /* stage-level studies only: skip the 160 kHz decode gate */
     const size_t nbins = 1 << 12;
     std::vector<cf32> freq_in, freq_out;
     uint64_t fft_count = 0;
@@ -660,6 +661,7 @@ void orc_decoder_dc_remove(orc_decoder* d, int on) { d->dc = on != 0; }
  * float abs; default), 0 = <cmath>-only context (double trig, integer abs). */
 void orc_decoder_lookup_mode(orc_decoder* d, int mathh_context) { d->fir.float_trig = mathh_context; d->symex.float_abs = mathh_context; }
 void orc_decoder_with_fft(orc_decoder* d, int on) { d->with_fft = on != 0; }
+void orc_decoder_ungated(orc_decoder* d, int on) { d->ungated = on != 0; }
 void orc_decoder_lowpass_bw(orc_decoder* d, float hz)          /* Decoder.h:238-243 */
 {
     d->lp_bw = hz;
@@ -718,7 +720,7 @@ void orc_decoder_process(orc_decoder* d)                       /* Decoder.h:416-
             orc_afc_set_spectrum(&d->afc, reinterpret_cast<const float*>(d->freq_out.data()), d->nbins, d->dec_rate());
         orc_afc_process(&d->afc);
     }
-    if (d->dec_rate() > 4 * 40e3) {                            /* :522-527, Q11 */
+    if (!d->ungated && d->dec_rate() > 4 * 40e3) {             /* :522-527, Q11 */
         d->temp.clear();
         d->decimated.clear();
         return;

@@ -119,6 +119,7 @@ void orc_decoder_dc_remove(orc_decoder*, int on);
 /* 1 (default) = reference compiled in a <math.h> context, 0 = <cmath>-only context (Q9b/Q15b) */
 void orc_decoder_lookup_mode(orc_decoder*, int mathh_context);
 void orc_decoder_with_fft(orc_decoder*, int on);   /* 0 = skip spectrum/AFC (timing studies only) */
+void orc_decoder_ungated(orc_decoder*, int on);    /* 1 = run FIR/demod/symbols above the 160 kHz gate too (stage-level parity for BASELINE config 3) */
 void orc_decoder_push(orc_decoder*, const float* iq, size_t n, double sampling_rate);
 void orc_decoder_process(orc_decoder*);
 void orc_decoder_reset_correction(orc_decoder*, double correction);

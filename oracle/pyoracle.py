@@ -335,7 +335,7 @@ class Decoder:
 
     def __init__(self, kind: str = "oracle", *, factor: int = 64, baud: float = 300, bits: int = 8, stops: float = 2,
                  lowpass_bw: float | None = None, lowpass_trans: float | None = None, dc_remove: bool = False,
-                 with_fft: bool = True, mathh_context: int = 1):
+                 with_fft: bool = True, mathh_context: int = 1, ungated: bool = False):
         self.kind = kind
         if kind == "oracle":
             self.L = _Lib(_load(HERE / "liboracle.so"), "orc_decoder_")
@@ -357,6 +357,7 @@ class Decoder:
         if kind == "oracle":
             fn("with_fft", None, _vp, _int)(self.h, 1 if with_fft else 0)
             fn("lookup_mode", None, _vp, _int)(self.h, int(mathh_context))
+            fn("ungated", None, _vp, _int)(self.h, int(ungated))
             self._arrs["spectrum"] = fn("spectrum", _sz, _vp, _pf)
             self._arrs["fir_taps"] = fn("fir_taps", _sz, _vp, _pf)
             self._held = fn("symex_held", _sz, _vp)
