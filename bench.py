@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- batched RTTY demodulation throughput on MI355X (one process per GPU, no collective on the data path).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg1|cfg2|cfg3|cfg5] [--streams S]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pushSamples()+operator()() round for every stream of the batch (reference
+code/websocketServer/main.cpp:240-245): S streams x C IQ samples already resident in HBM go through the whole
+chain (decimation -> [DC] -> spectrum/AFC -> low-pass FIR -> FSK discriminator -> symbol extractor on the GPU;
+RTTY framing, sentence extraction, CRC on the host) and the decoded text of that step is delivered before the
+next step starts.  Metric: input complex samples consumed per second over all GPUs (IQ Msamples/s).
+
+The default workload is BASELINE.json configs[3] per GPU: 1024 streams @ 2.048 MS/s, /64, 50 baud 7N2, spectrum +
+AFC every call ("cfg4" in SURVEY.md's 1-based numbering) -- the batched 2.048 MS/s configuration that exists at
+1/2/4/8 GPUs, sharded 1024 streams per GPU (weak scaling).  Each stream carries its own CRC-valid telemetry
+sentence in a seamless ring of HBM-resident chunks; the line reports how many sentences were decoded.
+
+Output: ONE JSON line on rank 0 (contract in the round prompt) with `roofline` for the dominant kernel (the
+first-stage decimator, the only kernel that touches full-rate IQ; its duration is measured with HIP events on the
+engine's own stream) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample of the
+same streams, whose decoded sentences are also compared with the GPU's).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
+HBM_COPY_GBS = 6290.0          # measured float4 copy on gfx950 (same table)
+
+WORKLOADS = {
+    # name: fs, decimation, baud, bits, stops, streams/GPU, chunk, lowpass_bw, lowpass_trans, ungated, carrier offsets
+    "cfg4": dict(fs=2.048e6, D=64, baud=50, bits=7, stops=2, S=1024, C=65536, lp_bw=1500.0, lp_trans=0.025, ungated=False, offsets=True,
+                 desc="BASELINE configs[3] per GPU: 1024 streams @ 2.048 MS/s, /64 (/32 212 taps + /2 69 taps), 50 baud 7N2, 161-tap low-pass, spectrum+AFC every call"),
+    "cfg1": dict(fs=2.048e6, D=64, baud=300, bits=8, stops=2, S=1024, C=65536, lp_bw=1500.0, lp_trans=0.025, ungated=False, offsets=False,
+                 desc="configs[0] batched: 1024 streams @ 2.048 MS/s, /64, 300 baud 8N2"),
+    "cfg2": dict(fs=2.5e6, D=16, baud=300, bits=8, stops=2, S=1024, C=65536, lp_bw=3000.0, lp_trans=0.025, ungated=False, offsets=False,
+                 desc="configs[1] batched: 1024 streams @ 2.5 MS/s, /16 (/8 54 taps + /2), low-pass 3 kHz, 300 baud 8N2"),
+    "cfg3": dict(fs=2.048e6, D=4, baud=300, bits=8, stops=2, S=1024, C=65536, lp_bw=1500.0, lp_trans=0.025, ungated=True, offsets=False,
+                 desc="configs[2]: 1024 streams @ 2.048 MS/s, /4 (139 taps), stage-level FIR/demod/symbols at 512 kHz (reference's 160 kHz gate lifted)"),
+    "cfg5": dict(fs=10e6, D=256, baud=300, bits=8, stops=2, S=512, C=1 << 20, lp_bw=1500.0, lp_trans=4.0 / 4096, ungated=False, offsets=False,
+                 desc="configs[4] per GPU: 512 streams @ 10 MS/s, /256 (/64 348 taps + /4 139 taps), 4097-tap low-pass, 2^20-sample pushes"),
+}
+
+
+def bytes_per_sample(D: int) -> float:
+    """Algorithmic HBM bytes per input sample of the whole chain: 8 + 12/D."""
+    return 8.0 + 12.0 / D
+
+
+def stream_text(rank: int, s: int) -> str:
+    from habdec_amd import synth
+    return synth.make_sentence(f"R{rank}S{s:04d}", f"{s % 10},52,21")      # 23 characters: just above the 20-char scan threshold
+
+
+def generate_ring(torch, dev, w, S, rank, seed):
+    """HBM-resident synthetic IQ: [S, ring_len] cf32, stream s = its own sentence rendered as continuous-phase 2-FSK,
+    padded with mark idle to whole chunks; carrier nudged (< 0.5 Hz) so the ring wraps phase-continuously."""
+    from habdec_amd import synth
+    fs, baud, C = w["fs"], w["baud"], w["C"]
+    texts = [stream_text(rank, s) for s in range(S)]
+    bits = np.stack([synth.rtty_bits(t, w["bits"], w["stops"], 2, 0) for t in texts])          # equal lengths by construction
+    nb = bits.shape[1]
+    ring_chunks = int(math.ceil(nb * fs / baud / C))
+    L = ring_chunks * C
+    rng = np.random.default_rng(seed)
+    if w["offsets"]:   # 7/8 of the streams within the decodable +-200 Hz, 1/8 far off (AFC work only)
+        f0 = np.where(np.arange(S) % 8 == 7, rng.uniform(300, 2000, S) * rng.choice([-1, 1], S), rng.uniform(-200, 200, S))
+    else:
+        f0 = np.zeros(S)
+    out = torch.empty((S, L, 2), dtype=torch.float32, device=dev)
+    k = torch.arange(L, device=dev, dtype=torch.int64)
+    bit_idx = torch.clamp(torch.div(k * int(round(baud * 1000)), int(round(fs * 1000)), rounding_mode="floor"), max=nb)
+    bits_t = torch.from_numpy(np.concatenate([bits, np.ones((S, 1), np.uint8)], axis=1)).to(dev)   # index nb = idle mark
+    k1 = (k + 1).to(torch.float64)
+    B = max(1, min(S, int(2.0e9 // (L * 8))))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    for s0 in range(0, S, B):
+        s1 = min(S, s0 + B)
+        sgn = bits_t[s0:s1].index_select(1, bit_idx).to(torch.float64) * 2.0 - 1.0
+        cum = torch.cumsum(sgn, dim=1)
+        f0b = torch.from_numpy(f0[s0:s1]).to(dev)[:, None]
+        total = (f0b[:, 0] * L + 250.0 * cum[:, -1]) / fs
+        f0b = f0b + ((torch.round(total) - total) * fs / L)[:, None]
+        cyc = (f0b * k1 + 250.0 * cum) / fs
+        ph = (cyc - torch.floor(cyc)) * (2.0 * math.pi)
+        del sgn, cum, cyc
+        noise = torch.randn((s1 - s0, L, 2), device=dev, dtype=torch.float32, generator=gen) * 0.08
+        out[s0:s1, :, 0] = (0.5 * torch.cos(ph)).to(torch.float32) + noise[..., 0]
+        out[s0:s1, :, 1] = (0.5 * torch.sin(ph)).to(torch.float32) + noise[..., 1]
+        del ph, noise
+    return out, ring_chunks, texts
+
+
+def cpu_baseline(w, host_iq, chunks, C, lookup_mode=1):
+    """Oracle (CPU restatement of the reference chain, oracle/liboracle.so) on the host cores: one decoder per
+    thread (std::thread inside the library), each fed the same chunk sequence the GPU consumed, repeated with
+    fresh decoders to reach ~10-15 s of work.  Returns (MS/s, threads, sample description, first-pass sentences)."""
+    from oracle import pyoracle
+    kw = dict(fs=w["fs"], factor=w["D"], baud=w["baud"], bits=w["bits"], stops=w["stops"], lowpass_bw=w["lp_bw"],
+              lowpass_trans=w["lp_trans"], mathh_context=lookup_mode, ungated=w["ungated"])
+    t_one, _ = pyoracle.bench_run(host_iq[:1], chunks, C, 1, **kw)
+    repeats = int(min(max(round(12.0 / max(t_one, 1e-3)), 1), 500))
+    dt, sentences = pyoracle.bench_run(host_iq, chunks, C, repeats, **kw)
+    nthreads = len(host_iq)
+    total = nthreads * repeats * len(chunks) * C
+    sample = (f"{nthreads} streams x {len(chunks)} chunks of {C} samples x {repeats} repeats = {total / 1e6:.0f} MS; "
+              f"one oracle decoder per thread, {nthreads} threads; single-thread rate {len(chunks) * C / t_one / 1e6:.1f} MS/s")
+    return total / dt / 1e6, nthreads, sample, sentences
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: one pass over the HBM-resident ring)")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg4", choices=list(WORKLOADS))
+    ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path to time (the oracle is only the baseline leg)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import habdec_amd
+    w = dict(WORKLOADS[args.workload])
+    S = args.streams or w["S"]
+    C = w["C"]
+    ring, ring_chunks, texts = generate_ring(torch, dev, w, S, rank, seed=1234 + rank)
+    L = ring_chunks * C
+    K = args.steps or ring_chunks
+    W = args.warmup
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"],
+                            rtty_stops=w["stops"], lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"],
+                            device=local_rank)
+    base = ring.data_ptr()
+
+    def step(i):
+        eng.process_device(base + (i % ring_chunks) * C * 8, L, C)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    for i in range(W):
+        step(i)
+    front_ms = []
+    total_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+        t = eng.timing()
+        front_ms.append(t["ms_front"])
+        total_ms.append(t["ms_total"])
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    front_bytes = eng.timing()["front_bytes"]
+    sentences_ok = eng.sentences_ok()
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+            dist.destroy_process_group()
+        return
+
+    samples_per_step = world * S * C
+    value = samples_per_step * K / dt / 1e6
+    avg_front_ms = float(np.mean(front_ms))
+    achieved = front_bytes / (avg_front_ms * 1e-3) / 1e9
+    traffic = None
+    tf = ROOT / "profiles" / "traffic.json"
+    if tf.exists():
+        try:
+            traffic = json.loads(tf.read_text()).get(args.workload, {}).get("front_kernel_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    stage1 = {64: "k_decimate<32,212,128>", 16: "k_decimate<8,54,256>", 4: "k_decimate<4,139,256>", 256: "k_decimate<64,348,64>"}.get(w["D"], "k_decimate")
+    line = {
+        "metric": "IQ Msamples/s (batched 2.048 MS/s streams)" if w["fs"] == 2.048e6 else "IQ Msamples/s (batched streams)",
+        "value": round(value, 1), "unit": "MS/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic: per-stream CRC-valid RTTY sentence as continuous-phase 2-FSK + Gaussian noise, generated on the GPU, HBM-resident ring",
+        "config": {"workload": f"{args.workload}: {w['desc']}", "streams_per_gpu": S, "chunk_samples": C, "ring_chunks": ring_chunks,
+                   "sharding": f"{S} independent streams per GPU, no data-path collective"},
+        "roofline": {"bound": "hbm", "kernel": stage1, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": front_bytes, "avg_launch_ms": round(avg_front_ms, 5),
+                     "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 4)},
+        "pipeline": {"bytes_per_sample": round(bytes_per_sample(w["D"]), 3),
+                     "hbm_frac_end_to_end": round(value / world * 1e6 * bytes_per_sample(w["D"]) / 1e9 / HBM_PEAK_GBS, 4),
+                     "gpu_ms_per_step_all_kernels": round(float(np.mean(total_ms)), 4),
+                     "sentences_ok_rank0": int(sentences_ok)},
+    }
+    if not args.no_cpu_baseline:
+        cores = os.cpu_count() or 1
+        nthreads = int(min(cores, S, 64))
+        chunks = [i % ring_chunks for i in range(W + K)]
+        host_iq = [ring[s].cpu().numpy().view(np.complex64).reshape(-1) for s in range(nthreads)]
+        v, c, sample, sent = cpu_baseline(w, host_iq, chunks, C)
+        gpu_sent = [eng.take_sentences(s) for s in range(nthreads)]
+        line["cpu_baseline"] = {"value": round(v, 1), "unit": "MS/s", "cores": c, "kind": "port", "sample": sample,
+                                "gpu_matches_oracle_on_sample": bool(gpu_sent == sent),
+                                "sentences_in_sample": int(sum(len(x) for x in sent))}
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,7 +16,9 @@
 #include <cstring>
 #include <map>
 #include <regex>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "decim_taps_ref.inc"
@@ -785,3 +787,43 @@ void orc_decoder_afc(orc_decoder* d, double* c, double* sh, double* nf, double* 
 size_t orc_decoder_fir_taps(orc_decoder* d, const float** t) { return orc_fir_taps(&d->fir, t); }
 size_t orc_decoder_symex_held(orc_decoder* d) { return d->symex.v.size(); }
 uint64_t orc_decoder_fft_count(orc_decoder* d) { return d->fft_count; }
+
+/* ------------------------------------------------------------------------------------------------
+ * CPU baseline driver for bench.py: `nthreads` decoders, one per thread, each fed the same chunk
+ * sequence of its own stream exactly like DECODER_THREAD (main.cpp:240-245), `repeats` times with a
+ * fresh decoder.  Returns wall seconds; the sentence log of each thread's first pass is written to
+ * `sentences` separated by '\x1e'.
+ * ---------------------------------------------------------------------------------------------- */
+double orc_bench_run(const orc_bench_cfg* cfg, const float* const* iq, const uint32_t* chunk_idx, size_t nchunks,
+                     size_t chunk, int repeats, int nthreads, char* sentences, size_t cap)
+{
+    std::vector<std::string> logs(nthreads);
+    auto work = [&](int i) {
+        for (int r = 0; r < repeats; ++r) {
+            orc_decoder* d = orc_decoder_new();
+            orc_decoder_setup_factor(d, cfg->factor);
+            orc_decoder_baud(d, cfg->baud);
+            orc_decoder_rtty(d, cfg->bits, cfg->stops);
+            orc_decoder_lookup_mode(d, cfg->mathh_context);
+            d->ungated = cfg->ungated != 0;
+            d->with_fft = cfg->with_fft != 0;
+            orc_decoder_lowpass_bw(d, cfg->lowpass_bw);       /* before any input: stores the value (Q10) */
+            orc_decoder_lowpass_trans(d, cfg->lowpass_trans);
+            for (size_t c = 0; c < nchunks; ++c) {
+                orc_decoder_push(d, iq[i] + 2 * (size_t)chunk_idx[c] * chunk, chunk, cfg->sampling_rate);
+                orc_decoder_process(d);
+            }
+            if (r == 0) logs[i] = d->sentence_log;
+            orc_decoder_free(d);
+        }
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int i = 0; i < nthreads; ++i) th.emplace_back(work, i);
+    for (auto& t : th) t.join();
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::string all;
+    for (int i = 0; i < nthreads; ++i) { all += logs[i]; all.push_back('\x1e'); }
+    if (sentences && cap) { const size_t n = std::min(cap - 1, all.size()); std::memcpy(sentences, all.data(), n); sentences[n] = 0; }
+    return dt;
+}

@@ -142,6 +142,16 @@ size_t orc_decoder_fir_taps(orc_decoder*, const float** taps);
 size_t orc_decoder_symex_held(orc_decoder*);
 uint64_t orc_decoder_fft_count(orc_decoder*);
 
+/* ---- multi-threaded CPU baseline driver (bench.py cpu_baseline leg) ---- */
+typedef struct orc_bench_cfg {
+    double sampling_rate, baud;
+    size_t factor, bits;
+    float stops, lowpass_bw, lowpass_trans;
+    int mathh_context, ungated, with_fft;
+} orc_bench_cfg;
+double orc_bench_run(const orc_bench_cfg* cfg, const float* const* iq_per_thread, const uint32_t* chunk_idx, size_t nchunks,
+                     size_t chunk, int repeats, int nthreads, char* sentences, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

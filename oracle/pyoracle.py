@@ -435,3 +435,28 @@ class Decoder:
 
 def have_ref() -> bool:
     return (HERE / "_ref" / "libhabdec_ref.so").exists()
+
+
+class _BenchCfg(C.Structure):
+    _fields_ = [("sampling_rate", _dbl), ("baud", _dbl), ("factor", _sz), ("bits", _sz), ("stops", C.c_float),
+                ("lowpass_bw", C.c_float), ("lowpass_trans", C.c_float), ("mathh_context", _int), ("ungated", _int), ("with_fft", _int)]
+
+
+def bench_run(streams, chunk_idx, chunk, repeats, *, fs, factor, baud, bits, stops, lowpass_bw=1500.0, lowpass_trans=0.025,
+              mathh_context=1, ungated=False, with_fft=True):
+    """Time `len(streams)` oracle decoders on as many threads (C++ std::thread inside liboracle.so, no GIL).
+    streams: list of complex64 arrays; chunk_idx: which chunk of the array each call consumes.
+    Returns (seconds, [sentence list of each stream's first pass])."""
+    lib = _load(HERE / "liboracle.so")
+    fn = lib.orc_bench_run
+    fn.restype = _dbl
+    fn.argtypes = [C.POINTER(_BenchCfg), C.POINTER(C.c_void_p), C.c_void_p, _sz, _sz, _int, _int, C.c_char_p, _sz]
+    cfg = _BenchCfg(fs, baud, factor, bits, stops, lowpass_bw, lowpass_trans, int(mathh_context), int(ungated), int(with_fft))
+    keep = [_cf(x) for x in streams]
+    ptrs = (C.c_void_p * len(keep))(*[k.ctypes.data for k in keep])
+    idx = np.ascontiguousarray(chunk_idx, dtype=np.uint32)
+    cap = 1 << 22
+    buf = C.create_string_buffer(cap)
+    dt = fn(C.byref(cfg), ptrs, idx.ctypes.data, len(idx), chunk, repeats, len(keep), buf, cap)
+    parts = buf.value.decode("latin-1").split("\x1e")[:len(keep)]
+    return dt, [[s for s in p.split("\n") if s] for p in parts]
