@@ -111,7 +111,7 @@ struct hd_engine {
     rocfft_execution_info fft_info = nullptr;
     DevBuf<char> fft_work;
 
-    DevBuf<float2> staging, dec1, hist1, hist2, fbuf[2], fft_in, fft_raw, spec, filtered;
+    DevBuf<float2> staging, dec1, hist1[2], hist2[2], fbuf[2], fft_in, fft_raw, spec, filtered;
     DevBuf<float> stage_taps[2], lp_taps, power, demod, tail, weight;
     DevBuf<unsigned long long> flipmask;
     DevBuf<uint32_t> held, slots, flips_dbg;
@@ -125,6 +125,7 @@ struct hd_engine {
     PinBuf<hd::SpectrumStatsDev> h_stats;
     PinBuf<float> h_taps;
     int cur = 0;          // which fbuf receives this call's chunk
+    int hist_cur = 0;     // which stage-history buffers are read this call (the others are written)
     int carry_cur = 0;
     bool sym_dirty = true;
 
@@ -248,12 +249,12 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     HD_HIP(e->staging.alloc((size_t)S * cfg->max_chunk));
     if (e->stages.size() == 2) HD_HIP(e->dec1.alloc((size_t)S * e->n1_cap));
     if (e->stages.size() >= 1) {
-        HD_HIP(e->hist1.alloc((size_t)S * (e->stages[0].taps.size() - 1)));
+        for (auto& h : e->hist1) HD_HIP(h.alloc((size_t)S * (e->stages[0].taps.size() - 1)));
         HD_HIP(e->stage_taps[0].alloc(e->stages[0].taps.size()));
         HD_HIP(hipMemcpy(e->stage_taps[0].p, e->stages[0].taps.data(), e->stages[0].taps.size() * 4, hipMemcpyHostToDevice));
     }
     if (e->stages.size() == 2) {
-        HD_HIP(e->hist2.alloc((size_t)S * (e->stages[1].taps.size() - 1)));
+        for (auto& h : e->hist2) HD_HIP(h.alloc((size_t)S * (e->stages[1].taps.size() - 1)));
         HD_HIP(e->stage_taps[1].alloc(e->stages[1].taps.size()));
         HD_HIP(hipMemcpy(e->stage_taps[1].p, e->stages[1].taps.data(), e->stages[1].taps.size() * 4, hipMemcpyHostToDevice));
     }
@@ -484,18 +485,15 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         float2* out1 = single ? fcur : e->dec1.p;
         const size_t out1_stride = single ? e->fbuf_stride : e->n1_cap;
         if (e->timing_on) HD_HIP(hipEventRecord(e->ev[1], q));
-        if (!hd::launch_decimate(q, R1, T1, S, max_n1, iq, stride, e->hist1.p, e->stage_taps[0].p, out1, out1_stride, e->d_call.p, 0,
-                                 single ? 1 : 0, e->fir_hist_cap))
+        const int hin = e->hist_cur, hout = e->hist_cur ^ 1;
+        if (!hd::launch_decimate(q, R1, T1, S, max_n1, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
+                                 e->d_call.p, 0, single ? 1 : 0, e->fir_hist_cap))
             return fail(HD_ERR_INVALID, "no kernel for this decimation stage");
         if (e->timing_on) HD_HIP(hipEventRecord(e->ev[2], q));
-        if (max_in)
-            hd::launch_decim_history(q, R1, T1, S, iq, stride, out1, out1_stride, e->hist1.p, e->d_call.p, 0, single ? 1 : 0, e->fir_hist_cap);
         if (!single) {
-            if (!hd::launch_decimate(q, R2, T2, S, max_n2, e->dec1.p, e->n1_cap, e->hist2.p, e->stage_taps[1].p, fcur, e->fbuf_stride,
-                                     e->d_call.p, 1, 1, e->fir_hist_cap))
+            if (!hd::launch_decimate(q, R2, T2, S, max_n2, e->dec1.p, e->n1_cap, e->hist2[hin].p, e->hist2[hout].p, e->stage_taps[1].p, fcur,
+                                     e->fbuf_stride, e->d_call.p, 1, 1, e->fir_hist_cap))
                 return fail(HD_ERR_INVALID, "no kernel for this decimation stage");
-            if (max_n1)
-                hd::launch_decim_history(q, R2, T2, S, e->dec1.p, e->n1_cap, fcur, e->fbuf_stride, e->hist2.p, e->d_call.p, 1, 1, e->fir_hist_cap);
         }
     }
     if (any_dc) hd::launch_dc_remove(q, S, fcur, e->fbuf_stride, e->d_call.p, e->fir_hist_cap);
@@ -521,6 +519,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     HD_HIP(hipStreamSynchronize(q));
     e->cur ^= 1;
     e->carry_cur ^= 1;
+    if (max_in && nst) e->hist_cur ^= 1;
     if (e->timing_on) {
         float a = 0, b = 0;
         HD_HIP(hipEventElapsedTime(&a, e->ev[0], e->ev[3]));

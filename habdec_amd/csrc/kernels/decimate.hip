@@ -6,12 +6,18 @@
 // bit-identical to the CPU path).  The first stage is the only kernel of the pipeline that touches full-rate
 // IQ: 8 bytes read per input sample, 8/D written -- HBM-bound for D >= 8 (kernel table).
 //
-// Mapping: grid = (output tiles, streams); one lane = one output sample, so the T-term sum stays inside a lane
-// and in order.  A tile's (TO-1)*D + T input samples are staged through LDS with coalesced 16-byte global
-// loads.  In LDS the samples are laid out linearly with one 8-byte pad after every D samples: lane o then reads
-// address o*(D+1) + t + t/D, a stride of 2*(D+1) dwords -- odd multiples of 2 -- which spreads the 32 lanes of
-// each ds_read_b64 half-wave over all 64 banks (conflict-free), and the staging writes stay unit-stride.
+// Mapping: grid = (tile groups, streams); one lane = one output sample, so the T-term sum stays inside a lane and
+// in order.  A workgroup walks `tiles_per_wg` consecutive tiles of one stream.  Each tile's (TO-1)*D + T input
+// samples go global -> registers -> LDS with 16-byte accesses, and the NEXT tile's global loads are issued before
+// the current tile is computed, so HBM latency hides under the LDS/VALU phase (register prefetch, single LDS
+// buffer, two barriers per tile).
+// LDS layout: linear, with a 16-byte pad after every D samples (pitch D+2 samples per output).  Lane o reads
+// samples o*D + t as 16-byte pairs at o*(D+2) + ...: a lane stride of 2*(D+2) dwords = 4 mod 64, i.e. consecutive
+// lanes hit consecutive 16-byte bank groups -> ds_read_b128 / ds_write_b128 are conflict-free at full LDS rate.
+// The tile is shifted by JS = (T-1)&1 slots so that 16-byte-aligned global pairs land on 16-byte-aligned LDS pairs.
 // Taps are wave-uniform and come through the scalar cache (s_load), not LDS.
+// History: the workgroup that owns a stream's last tile also writes the stream's next history (last T-1 inputs)
+// into the OTHER history buffer (ping-pong, so the first tile of the same launch still reads the old one).
 #include <hip/hip_runtime.h>
 
 #include "launch.h"
@@ -20,83 +26,135 @@ namespace hd {
 
 template <int D, int T, int TO>
 __global__ __launch_bounds__(TO) void k_decimate(const float2* __restrict__ in, size_t in_stride,
-                                                   const float2* __restrict__ hist, const float* __restrict__ taps,
+                                                   const float2* __restrict__ hist_in, float2* __restrict__ hist_out,
+                                                   const float* __restrict__ taps,
                                                    float2* __restrict__ out, size_t out_stride,
                                                    const StreamCall* __restrict__ call, int stage, int final_stage,
-                                                   uint32_t fir_hist_cap)
+                                                   uint32_t fir_hist_cap, uint32_t tiles_per_wg)
 {
-    constexpr int NJ = (TO - 1) * D + T;       // samples a tile needs
-    constexpr int NL = NJ + NJ / D + 2;        // with one pad slot per D samples
-    __shared__ float2 tile[NL];
+    constexpr int JS = (T - 1) & 1;                // LDS slot jj = j + JS for tile-local sample j
+    constexpr int NJ = (TO - 1) * D + T;           // samples a tile needs
+    constexpr int NJJ = NJ + JS;
+    constexpr int NL = NJJ + 2 * (NJJ / D) + 4;    // + two pad slots per D samples
+    constexpr int NP = (NJJ + 1) / 2;              // 16-byte pairs per tile
+    constexpr int ITER = (NP + TO - 1) / TO;
+    __shared__ float4 tile4[(NL + 1) / 2 + TO / 2 + 1];
+    float2* tile = reinterpret_cast<float2*>(tile4);
+    float2* ytile = tile + ((NL + 1) & ~1);        // this tile's outputs (only needed for the Q4 history quirk)
 
     const uint32_t s = blockIdx.y;
     const StreamCall c = call[s];
     const uint32_t n = stage == 0 ? c.n_in : c.n1;
     const uint32_t nout = n / D;
-    const uint32_t o0 = blockIdx.x * TO;
-    if (o0 >= nout) return;
+    const uint32_t ntiles = (nout + TO - 1) / TO;
+    const uint32_t first = blockIdx.x * tiles_per_wg;
+    if (!n && blockIdx.x == 0)                             // idle stream: its history passes through unchanged
+        for (uint32_t j = threadIdx.x; j < (uint32_t)(T - 1); j += TO)
+            hist_out[(size_t)s * (T - 1) + j] = hist_in[(size_t)s * (T - 1) + j];
+    if (first >= ntiles) return;
+    const uint32_t last = min(first + tiles_per_wg, ntiles);
     const bool zero_hist = (stage == 0 ? c.zero_hist1 : c.zero_hist2) != 0;
     const float2* in_s = in + (size_t)s * in_stride;
-    const float2* hist_s = hist + (size_t)s * (T - 1);
+    const float2* hist_s = hist_in + (size_t)s * (T - 1);
     float2* out_s = out + (size_t)s * out_stride + (final_stage ? (size_t)fir_hist_cap + c.pend_before : 0);
 
-    // tile-local j <-> stream sample x0 + j (negative = history)
-    const long x0 = (long)o0 * D - (T - 1);
-    constexpr int JS = (T - 1) & 1;            // x0 - JS is even, so pairs are 16-byte aligned in global memory
-    auto fetch = [&](long xi) -> float2 {
-        if (xi < 0) {
-            if (zero_hist || xi < -(long)(T - 1)) return make_float2(0.f, 0.f);
-            return hist_s[xi + (T - 1)];
-        }
-        if (xi < (long)n) return in_s[xi];
-        return make_float2(0.f, 0.f);
+    // Edge tiles (the history tile of every stream): branch-free address selection so the loads still issue
+    // back to back -- out-of-range samples read a safe address and are zeroed afterwards.
+    auto locate = [&](long xi, bool& ok) -> const float2* {
+        const bool in_hist = xi < 0;
+        ok = in_hist ? (!zero_hist && xi >= -(long)(T - 1)) : (xi < (long)n);
+        const long hi = xi + (T - 1);
+        const float2* ph = hist_s + (hi < 0 ? 0 : hi);
+        const float2* pi = in_s + (xi < 0 ? 0 : (xi < (long)n ? xi : 0));
+        return in_hist ? ph : pi;
     };
-    for (int k = threadIdx.x; 2 * k - JS < NJ; k += TO) {
-        const int j = 2 * k - JS;
-        const long xi = x0 + j;
-        float2 a, b;
-        if (xi >= 0 && xi + 1 < (long)n) {
-            const float4 v = *reinterpret_cast<const float4*>(in_s + xi);
-            a = make_float2(v.x, v.y);
-            b = make_float2(v.z, v.w);
-        } else {
-            a = fetch(xi);
-            b = fetch(xi + 1);
-        }
-        if (j >= 0) tile[j + j / D] = a;
-        if (j + 1 < NJ) tile[(j + 1) + (j + 1) / D] = b;
-    }
-    __syncthreads();
-
-    const uint32_t o = o0 + threadIdx.x;
-    const float2* p = tile + threadIdx.x * (D + 1);
-    float ar = 0.f, ai = 0.f;
+    float4 r[ITER];
+    auto load_tile = [&](uint32_t tile_i) {
+        const long xe = (long)tile_i * TO * D - (T - 1) - JS;      // stream sample of LDS slot 0; even
+        const bool interior = (xe >= 0) && (xe + 2L * NP <= (long)n);   // wave-uniform
+        if (interior) {
+            const float4* src = reinterpret_cast<const float4*>(in_s + xe);
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const float2 x = p[t + t / D];
-        const float k = taps[t];
-        ar = ar + x.x * k;
-        ai = ai + x.y * k;
-    }
-    if (o < nout) out_s[o] = make_float2(ar, ai);
-}
+            for (int it = 0; it < ITER; ++it) {
+                const int k = threadIdx.x + it * TO;
+                if (k < NP) r[it] = src[k];
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int k = threadIdx.x + it * TO;
+                if (k < NP) {
+                    const long xi = xe + 2 * k;
+                    bool oka, okb;
+                    const float2* pa = locate(xi, oka);
+                    const float2* pb = locate(xi + 1, okb);
+                    float2 a = *pa, b = *pb;
+                    if (!oka) a = make_float2(0.f, 0.f);
+                    if (!okb) b = make_float2(0.f, 0.f);
+                    r[it] = make_float4(a.x, a.y, b.x, b.y);
+                }
+            }
+        }
+    };
 
-// History carry: hist <- last T-1 input samples.  Q4 (Decimator.h:140-143 with Decoder.h:443-444): the
-// reference decimates in place, so history positions that fall inside the first n/D samples hold OUTPUTS.
-__global__ void k_decim_history(int D, int T, const float2* __restrict__ in, size_t in_stride,
-                                const float2* __restrict__ out, size_t out_stride, float2* __restrict__ hist,
-                                const StreamCall* __restrict__ call, int stage, int final_stage, uint32_t fir_hist_cap)
-{
-    const uint32_t s = blockIdx.y;
-    const StreamCall c = call[s];
-    const uint32_t n = stage == 0 ? c.n_in : c.n1;
-    if (!n) return;
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= (uint32_t)(T - 1)) return;
-    const uint32_t nout = n / D;
-    const uint32_t idx = n - (T - 1) + j;      // host guarantees n >= T-1
-    const float2* out_s = out + (size_t)s * out_stride + (final_stage ? (size_t)fir_hist_cap + c.pend_before : 0);
-    hist[(size_t)s * (T - 1) + j] = idx < nout ? out_s[idx] : in[(size_t)s * in_stride + idx];
+    load_tile(first);
+    const float2* p = tile + threadIdx.x * (D + 2);
+    for (uint32_t tile_i = first; tile_i < last; ++tile_i) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int k = threadIdx.x + it * TO;
+            if (k < NP) {
+                const int jj = 2 * k;
+                *reinterpret_cast<float4*>(tile + jj + 2 * (jj / D)) = r[it];
+            }
+        }
+        __syncthreads();
+        if (tile_i + 1 < last) load_tile(tile_i + 1);      // in flight while this tile is computed
+
+        float ar = 0.f, ai = 0.f;
+        constexpr int T0 = JS ? 1 : 0;                      // first tap whose LDS slot is even
+        if (JS) {
+            const float2 x = p[JS];
+            const float k = taps[0];
+            ar = ar + x.x * k;
+            ai = ai + x.y * k;
+        }
+        constexpr int NPAIR = (T - T0) / 2;
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) {
+            const int t = T0 + 2 * q;
+            const int jj = t + JS;
+            const float4 x = *reinterpret_cast<const float4*>(p + jj + 2 * (jj / D));
+            const float k0 = taps[t], k1 = taps[t + 1];
+            ar = ar + x.x * k0;
+            ai = ai + x.y * k0;
+            ar = ar + x.z * k1;
+            ai = ai + x.w * k1;
+        }
+        if ((T - T0) & 1) {
+            const int t = T - 1;
+            const int jj = t + JS;
+            const float2 x = p[jj + 2 * (jj / D)];
+            const float k = taps[t];
+            ar = ar + x.x * k;
+            ai = ai + x.y * k;
+        }
+        const uint32_t o = tile_i * TO + threadIdx.x;
+        if (o < nout) out_s[o] = make_float2(ar, ai);
+        ytile[threadIdx.x] = make_float2(ar, ai);
+        __syncthreads();                                    // everyone is done with this tile's LDS image
+    }
+
+    // History carry for the next call (Decimator.h:140-143).  Q4: the reference decimates in place
+    // (Decoder.h:443-444), so history positions that fall inside the first n/D samples hold OUTPUTS; that can only
+    // happen for inputs so short that all outputs are in this (single) tile.
+    if (last == ntiles && n) {
+        float2* hout = hist_out + (size_t)s * (T - 1);
+        for (uint32_t j = threadIdx.x; j < (uint32_t)(T - 1); j += TO) {
+            const uint32_t idx = n - (T - 1) + j;           // host guarantees n >= T-1
+            hout[j] = idx < nout ? ytile[idx] : in_s[idx];
+        }
+    }
 }
 
 __global__ void k_passthrough(const float2* __restrict__ in, size_t in_stride, float2* __restrict__ out, size_t out_stride,
@@ -141,34 +199,30 @@ __global__ __launch_bounds__(64) void k_dc_remove(float2* __restrict__ fbuf, siz
 
 template <int D, int T, int TO>
 static void launch_one(hipStream_t st, uint32_t n_streams, uint32_t max_out, const float2* in, size_t in_stride,
-                       const float2* hist, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
-                       int stage, int final_stage, uint32_t fir_hist_cap)
+                       const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride,
+                       const StreamCall* call, int stage, int final_stage, uint32_t fir_hist_cap)
 {
-    dim3 grid((max_out + TO - 1) / TO, n_streams);
-    hipLaunchKernelGGL((k_decimate<D, T, TO>), grid, dim3(TO), 0, st, in, in_stride, hist, taps, out, out_stride, call, stage,
-                       final_stage, fir_hist_cap);
+    const uint32_t ntiles = (max_out + TO - 1) / TO;
+    // Walk several tiles per workgroup (prefetch pipelining) once there are enough workgroups to fill the chip:
+    // 256 CUs x ~4 resident workgroups; keep >= ~2048 workgroups when the batch allows it.
+    uint32_t per = 1;
+    while (per < 16 && (uint64_t)((ntiles + 2 * per - 1) / (2 * per)) * n_streams >= 2048) per *= 2;
+    dim3 grid((ntiles + per - 1) / per, n_streams);
+    hipLaunchKernelGGL((k_decimate<D, T, TO>), grid, dim3(TO), 0, st, in, in_stride, hist_in, hist_out, taps, out, out_stride, call,
+                       stage, final_stage, fir_hist_cap, per);
 }
 
 bool launch_decimate(hipStream_t st, int ratio, int ntaps, uint32_t n_streams, uint32_t max_out, const float2* in, size_t in_stride,
-                     const float2* hist, const float* taps, float2* out, size_t out_stride, const StreamCall* call, int stage,
-                     int final_stage, uint32_t fir_hist_cap)
+                     const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
+                     int stage, int final_stage, uint32_t fir_hist_cap)
 {
     if (!max_out) return true;
 #define HD_CASE(D, T, TO) \
-    if (ratio == D && ntaps == T) { launch_one<D, T, TO>(st, n_streams, max_out, in, in_stride, hist, taps, out, out_stride, call, stage, final_stage, fir_hist_cap); return true; }
+    if (ratio == D && ntaps == T) { launch_one<D, T, TO>(st, n_streams, max_out, in, in_stride, hist_in, hist_out, taps, out, out_stride, call, stage, final_stage, fir_hist_cap); return true; }
     HD_CASE(2, 69, 256) HD_CASE(4, 139, 256) HD_CASE(8, 280, 256) HD_CASE(8, 54, 256)
     HD_CASE(16, 107, 128) HD_CASE(32, 212, 128) HD_CASE(32, 174, 128) HD_CASE(64, 348, 64)
 #undef HD_CASE
     return false;
-}
-
-void launch_decim_history(hipStream_t st, int ratio, int ntaps, uint32_t n_streams, const float2* in, size_t in_stride,
-                          const float2* out, size_t out_stride, float2* hist, const StreamCall* call, int stage, int final_stage,
-                          uint32_t fir_hist_cap)
-{
-    dim3 grid((ntaps - 1 + 255) / 256, n_streams);
-    hipLaunchKernelGGL(k_decim_history, grid, dim3(256), 0, st, ratio, ntaps, in, in_stride, out, out_stride, hist, call, stage,
-                       final_stage, fir_hist_cap);
 }
 
 void launch_passthrough(hipStream_t st, uint32_t n_streams, uint32_t max_n, const float2* in, size_t in_stride, float2* out,

@@ -16,15 +16,13 @@ struct DemodCarry {        // per-stream discriminator carry (previous filtered 
 
 // One FIR-decimate stage for all streams.  `final_stage`: output lands behind the FIR history in the
 // low-pass input buffer (offset fir_hist_cap + pend_before), else at offset 0 of `out`.
-// Returns false when (ratio, ntaps) is not one of the eight reference designs.
+// Returns false when (ratio, ntaps) is not one of the eight reference designs.  The kernel also carries each
+// stream's last ntaps-1 inputs into `hist_out` (Decimator.h:140-143, incl. the in-place quirk Q4); hist_in/hist_out
+// are ping-ponged by the caller.
 bool launch_decimate(hipStream_t st, int ratio, int ntaps, uint32_t n_streams, uint32_t max_out,
-                     const float2* in, size_t in_stride, const float2* hist, const float* taps,
+                     const float2* in, size_t in_stride, const float2* hist_in, float2* hist_out, const float* taps,
                      float2* out, size_t out_stride, const StreamCall* call, int stage, int final_stage,
                      uint32_t fir_hist_cap);
-// Carry the last ntaps-1 input samples of every stream into its history (Decimator.h:140-143, incl. Q4).
-void launch_decim_history(hipStream_t st, int ratio, int ntaps, uint32_t n_streams, const float2* in, size_t in_stride,
-                          const float2* out, size_t out_stride, float2* hist, const StreamCall* call, int stage,
-                          int final_stage, uint32_t fir_hist_cap);
 // factor 1: copy the chunk behind the FIR history.
 void launch_passthrough(hipStream_t st, uint32_t n_streams, uint32_t max_n, const float2* in, size_t in_stride,
                         float2* out, size_t out_stride, const StreamCall* call, uint32_t fir_hist_cap);
