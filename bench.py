@@ -65,7 +65,8 @@ def stream_text(rank: int, s: int) -> str:
 
 
 def generate_ring(torch, dev, w, S, rank, seed):
-    """HBM-resident synthetic IQ: [S, ring_len] cf32, stream s = its own sentence rendered as continuous-phase 2-FSK,
+    """HBM-resident synthetic IQ as a ring of push slabs [ring_chunks][S][C] cf32 (one slab = what one batched push
+    hands over: S streams x C samples, contiguous).  Stream s = its own sentence rendered as continuous-phase 2-FSK,
     padded with mark idle to whole chunks; carrier nudged (< 0.5 Hz) so the ring wraps phase-continuously."""
     from habdec_amd import synth
     fs, baud, C = w["fs"], w["baud"], w["C"]
@@ -79,7 +80,7 @@ def generate_ring(torch, dev, w, S, rank, seed):
         f0 = np.where(np.arange(S) % 8 == 7, rng.uniform(300, 2000, S) * rng.choice([-1, 1], S), rng.uniform(-200, 200, S))
     else:
         f0 = np.zeros(S)
-    out = torch.empty((S, L, 2), dtype=torch.float32, device=dev)
+    out = torch.empty((ring_chunks, S, C, 2), dtype=torch.float32, device=dev)
     k = torch.arange(L, device=dev, dtype=torch.int64)
     bit_idx = torch.clamp(torch.div(k * int(round(baud * 1000)), int(round(fs * 1000)), rounding_mode="floor"), max=nb)
     bits_t = torch.from_numpy(np.concatenate([bits, np.ones((S, 1), np.uint8)], axis=1)).to(dev)   # index nb = idle mark
@@ -98,8 +99,9 @@ def generate_ring(torch, dev, w, S, rank, seed):
         ph = (cyc - torch.floor(cyc)) * (2.0 * math.pi)
         del sgn, cum, cyc
         noise = torch.randn((s1 - s0, L, 2), device=dev, dtype=torch.float32, generator=gen) * 0.08
-        out[s0:s1, :, 0] = (0.5 * torch.cos(ph)).to(torch.float32) + noise[..., 0]
-        out[s0:s1, :, 1] = (0.5 * torch.sin(ph)).to(torch.float32) + noise[..., 1]
+        nb_ = s1 - s0
+        out[:, s0:s1, :, 0] = ((0.5 * torch.cos(ph)).to(torch.float32) + noise[..., 0]).view(nb_, ring_chunks, C).transpose(0, 1)
+        out[:, s0:s1, :, 1] = ((0.5 * torch.sin(ph)).to(torch.float32) + noise[..., 1]).view(nb_, ring_chunks, C).transpose(0, 1)
         del ph, noise
     return out, ring_chunks, texts
 
@@ -159,7 +161,7 @@ def main():
     base = ring.data_ptr()
 
     def step(i):
-        eng.process_device(base + (i % ring_chunks) * C * 8, L, C)
+        eng.process_device(base + (i % ring_chunks) * S * C * 8, C, C)
 
     def barrier():
         if dist is not None:
@@ -224,7 +226,7 @@ def main():
         cores = os.cpu_count() or 1
         nthreads = int(min(cores, S, 64))
         chunks = [i % ring_chunks for i in range(W + K)]
-        host_iq = [ring[s].cpu().numpy().view(np.complex64).reshape(-1) for s in range(nthreads)]
+        host_iq = [ring[:, s].cpu().numpy().view(np.complex64).reshape(-1) for s in range(nthreads)]
         v, c, sample, sent = cpu_baseline(w, host_iq, chunks, C)
         gpu_sent = [eng.take_sentences(s) for s in range(nthreads)]
         line["cpu_baseline"] = {"value": round(v, 1), "unit": "MS/s", "cores": c, "kind": "port", "sample": sample,

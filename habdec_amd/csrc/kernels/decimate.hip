@@ -25,7 +25,7 @@
 namespace hd {
 
 template <int D, int T, int TO>
-__global__ __launch_bounds__(TO) void k_decimate(const float2* __restrict__ in, size_t in_stride,
+__global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_decimate(const float2* __restrict__ in, size_t in_stride,
                                                    const float2* __restrict__ hist_in, float2* __restrict__ hist_out,
                                                    const float* __restrict__ taps,
                                                    float2* __restrict__ out, size_t out_stride,
@@ -111,33 +111,50 @@ __global__ __launch_bounds__(TO) void k_decimate(const float2* __restrict__ in, 
         __syncthreads();
         if (tile_i + 1 < last) load_tile(tile_i + 1);      // in flight while this tile is computed
 
+        // The T-term sum, in tap order.  Taps are consumed in blocks of B LDS slots (B/2 ds_read_b128 issued
+        // together, then 2*B packed multiply/add) inside a rolled loop: that keeps ~B taps live in SGPRs instead
+        // of all T (which spilled SGPRs through v_writelane) and puts B/2 LDS reads in flight per wave.
         float ar = 0.f, ai = 0.f;
-        constexpr int T0 = JS ? 1 : 0;                      // first tap whose LDS slot is even
-        if (JS) {
-            const float2 x = p[JS];
-            const float k = taps[0];
-            ar = ar + x.x * k;
-            ai = ai + x.y * k;
-        }
-        constexpr int NPAIR = (T - T0) / 2;
+        auto mac = [&](float xr, float xi, float k) { ar = ar + xr * k; ai = ai + xi * k; };
+        constexpr int B = D >= 32 ? 32 : 16;               // slots per block; pad inside a block is compile-time
+        constexpr int NS = T + JS;                          // slots [JS, NS) carry taps [0, T)
+        constexpr int NFULL = NS / B;                       // full blocks; block 0 is peeled when JS (slot 0 unused)
+        // block 0 (peeled): slots [0, B) or the whole filter when it is shorter than a block
+        {
+            constexpr int END = NS < B ? NS : B;
 #pragma unroll
-        for (int q = 0; q < NPAIR; ++q) {
-            const int t = T0 + 2 * q;
-            const int jj = t + JS;
-            const float4 x = *reinterpret_cast<const float4*>(p + jj + 2 * (jj / D));
-            const float k0 = taps[t], k1 = taps[t + 1];
-            ar = ar + x.x * k0;
-            ai = ai + x.y * k0;
-            ar = ar + x.z * k1;
-            ai = ai + x.w * k1;
+            for (int jj = 0; jj + 1 < END + 1; jj += 2) {
+                if (jj + 1 < END || jj < END) {
+                    const float4 x = *reinterpret_cast<const float4*>(p + jj + 2 * (jj / D));
+                    if (jj >= JS && jj < END) mac(x.x, x.y, taps[jj - JS]);
+                    if (jj + 1 < END) mac(x.z, x.w, taps[jj + 1 - JS]);
+                }
+            }
         }
-        if ((T - T0) & 1) {
-            const int t = T - 1;
-            const int jj = t + JS;
-            const float2 x = p[jj + 2 * (jj / D)];
-            const float k = taps[t];
-            ar = ar + x.x * k;
-            ai = ai + x.y * k;
+        if (NFULL > 1) {
+#pragma unroll 1
+            for (int b = 1; b < NFULL; ++b) {
+                const int j0 = b * B;
+                const float2* pb = p + j0 + 2 * (j0 / D);
+                const float* tb = taps + (j0 - JS);
+                float4 x[B / 2];
+#pragma unroll
+                for (int q = 0; q < B / 2; ++q) x[q] = *reinterpret_cast<const float4*>(pb + 2 * q + 2 * ((2 * q) / D));
+#pragma unroll
+                for (int q = 0; q < B / 2; ++q) {
+                    mac(x[q].x, x[q].y, tb[2 * q]);
+                    mac(x[q].z, x[q].w, tb[2 * q + 1]);
+                }
+            }
+        }
+        if (NS >= B && NS % B) {                            // tail block: slots [NFULL*B, NS)
+            constexpr int J0 = NFULL * B;
+#pragma unroll
+            for (int jj = J0; jj < NS; jj += 2) {
+                const float4 x = *reinterpret_cast<const float4*>(p + jj + 2 * (jj / D));
+                mac(x.x, x.y, taps[jj - JS]);
+                if (jj + 1 < NS) mac(x.z, x.w, taps[jj + 1 - JS]);
+            }
         }
         const uint32_t o = tile_i * TO + threadIdx.x;
         if (o < nout) out_s[o] = make_float2(ar, ai);
