@@ -36,6 +36,16 @@ struct SymbolParams {
     uint32_t R;             // averaging half-window = max(4, int(spb / 4))      (SymbolExtractor.h:170)
     uint32_t min_held;      // smallest backlog that satisfies `size >= fsd/baud*3` (SymbolExtractor.h:134); 0xFFFFFFFF = disabled
     uint32_t float_abs;     // lookup context of the flip weight |avg_r - avg_l|, see DESIGN.md
+    uint32_t reset;         // 1 = parameters changed: cached window results are stale, recompute the whole backlog
+};
+
+// Per-stream symbol-extractor ring state (device resident, updated by the scan kernel only).  Positions are
+// monotonic 32-bit counters; a sample's slot in the per-stream rings is (position & (ring_cap - 1)).
+struct SymState {
+    uint32_t base;          // position of backlog sample 0
+    uint32_t held;          // backlog length (SymbolExtractor::samples_.size())
+    uint32_t cached;        // window flags / weights are final for every position p with base + R <= p < cached
+    uint32_t _pad;
 };
 
 // Header of a stream's result slot written by the symbol scan kernel, followed by packed bits.
@@ -44,6 +54,8 @@ struct BitsHeader {
     uint32_t held_after;    // backlog kept by the symbol extractor after this call
     uint32_t nflips;        // flip points found this call
     uint32_t overflow;      // 1 = more bits/flips than the slot can hold (never with the derived capacities)
+    uint32_t uncached;      // backlog samples whose windows are not final yet (sizes the next call's window kernel)
+    uint32_t _pad[3];
 };
 
 struct SpectrumStatsDev {   // must match hd::SpectrumStats (host/afc_tracker.hpp)

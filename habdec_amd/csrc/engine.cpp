@@ -79,7 +79,8 @@ struct StreamHost {
     hd::LowpassDesigner lp;
     bool taps_dirty = false;
     // data-dependent state learned back from the device
-    uint32_t held = 0;
+    uint32_t held = 0, uncached = 0;
+    bool sym_reset = true;          // symbol parameters changed since the window cache was built
     // host stages
     hd::TextStage text;
     hd::AfcTracker afc;
@@ -100,7 +101,7 @@ struct hd_engine {
     uint32_t n1_cap = 0, n2_cap = 0;        // per-call capacities after stage 1 / last stage
     uint32_t taps_cap = 0, fir_hist_cap = 0; // low-pass tap capacity, history slots in front of the pending samples
     size_t fbuf_stride = 0;
-    uint32_t tail_cap = 0, slot_words = 0, flips_cap = 0, max_R = 0;
+    uint32_t tail_cap = 0, backlog_cap = 0, slot_words = 0, flips_cap = 0, max_R = 0;
     int bins_sep = 8;
     bool decode_enabled = true;
     hipStream_t stream = nullptr;
@@ -114,7 +115,8 @@ struct hd_engine {
     DevBuf<float2> staging, dec1, hist1[2], hist2[2], fbuf[2], fft_in, fft_raw, spec, filtered;
     DevBuf<float> stage_taps[2], lp_taps, power, demod, tail, weight;
     DevBuf<unsigned long long> flipmask;
-    DevBuf<uint32_t> held, slots, flips_dbg;
+    DevBuf<uint32_t> slots, flips_dbg;
+    DevBuf<hd::SymState> d_symstate;
     DevBuf<hd::DemodCarry> carry[2];
     DevBuf<hd::StreamCall> d_call;
     DevBuf<hd::SymbolParams> d_sym;
@@ -227,7 +229,9 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     e->fir_hist_cap = (e->taps_cap + 1u) & ~1u;       // even, so the chunk behind it stays 16-byte aligned
     e->fbuf_stride = (size_t)e->fir_hist_cap + hd::kFirBatch + e->n2_cap + 2;
     e->fbuf_stride = (e->fbuf_stride + 1) & ~(size_t)1;
-    e->tail_cap = ((hd::kVentLimit + 1 + m_cap + 63) / 64) * 64;
+    e->backlog_cap = hd::kVentLimit + 1 + m_cap;       // most samples the symbol extractor can hold (SymbolExtractor.h:116)
+    e->tail_cap = 1u;                                  // per-stream symbol ring: power of two >= vent limit + one batch + slack
+    while (e->tail_cap < hd::kVentLimit + 1 + m_cap + 1024) e->tail_cap <<= 1;
 
     e->st.resize(S);
     for (auto& s : e->st) {
@@ -238,7 +242,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     {   // result slot: header + packed bits.  bits per call <= 3*backlog/spb (SymbolExtractor run lengths)
         const hd::SymbolParams p = symbol_params(e.get(), e->st[0]);
         const uint32_t spb = std::max<uint32_t>(p.spb, 1);
-        uint32_t bits = 3u * e->tail_cap / spb + 64u;
+        uint32_t bits = 3u * e->backlog_cap / spb + 64u;
         bits = std::max<uint32_t>(256u, (bits + 31u) & ~31u);
         e->slot_words = (uint32_t)(sizeof(hd::BitsHeader) / 4) + bits / 32;
         e->max_R = std::max<uint32_t>(p.R, 4);
@@ -265,7 +269,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     HD_HIP(e->tail.alloc((size_t)S * e->tail_cap));
     HD_HIP(e->weight.alloc((size_t)S * e->tail_cap));
     HD_HIP(e->flipmask.alloc((size_t)S * (e->tail_cap / 64)));
-    HD_HIP(e->held.alloc(S));
+    HD_HIP(e->d_symstate.alloc(S));
     HD_HIP(e->slots.alloc((size_t)S * e->slot_words));
     if (e->flips_cap) HD_HIP(e->flips_dbg.alloc((size_t)S * e->flips_cap));
     for (auto& c : e->carry) HD_HIP(c.alloc(S));
@@ -335,12 +339,13 @@ int hd_stream_set_baud(hd_engine* e, uint32_t s, double baud)
     probe.baud = baud;
     const hd::SymbolParams p = symbol_params(e, probe);
     if (p.spb) {
-        const uint32_t need = 3u * e->tail_cap / p.spb + 64u;
+        const uint32_t need = 3u * e->backlog_cap / p.spb + 64u;
         if (need > (e->slot_words - sizeof(hd::BitsHeader) / 4) * 32)
             return fail(HD_ERR_CAPACITY, "baud too high for the result slots sized at engine creation");
         if (p.R > e->max_R) e->max_R = p.R;
     }
     e->st[s].baud = baud;
+    e->st[s].sym_reset = true;
     e->sym_dirty = true;
     return HD_OK;
 }
@@ -400,7 +405,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     const uint32_t R1 = nst > 0 ? e->stages[0].ratio : 1, R2 = nst > 1 ? e->stages[1].ratio : 1;
 
     // ---- host mirror of the reference's size bookkeeping -> one StreamCall per stream
-    uint32_t max_in = 0, max_n1 = 0, max_n2 = 0, max_m = 0, max_taps = 0, max_held = 0;
+    uint32_t max_in = 0, max_n1 = 0, max_n2 = 0, max_m = 0, max_taps = 0, max_new = 0;
     bool any_fft = false, any_dc = false;
     uint64_t total_in = 0;
     for (uint32_t s = 0; s < S; ++s) {
@@ -445,8 +450,10 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             st.last_m = m;
             max_m = std::max(max_m, m);
             max_taps = std::max(max_taps, T);
-            const uint32_t hb = (st.held > hd::kVentLimit ? 0u : st.held) + m;
-            max_held = std::max(max_held, hb);
+            // positions whose windows become computable this call (device: k_sym_avg range)
+            const bool vent = st.held > hd::kVentLimit;
+            const uint32_t pending_windows = vent ? 0u : (st.sym_reset ? st.held : st.uncached);
+            max_new = std::max(max_new, pending_windows + m + 64u);
         }
         c.pend_after = (uint32_t)st.pending;
         st.last_n2 = c.n2; st.last_pend_before = c.pend_before; st.last_buf = e->cur;
@@ -467,10 +474,16 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     }
     if (e->sym_dirty) {
         uint32_t mr = 4;
-        for (uint32_t s = 0; s < S; ++s) { e->h_sym.p[s] = symbol_params(e, e->st[s]); mr = std::max(mr, e->h_sym.p[s].R); }
+        for (uint32_t s = 0; s < S; ++s) {
+            e->h_sym.p[s] = symbol_params(e, e->st[s]);
+            e->h_sym.p[s].reset = e->st[s].sym_reset ? 1u : 0u;
+            mr = std::max(mr, e->h_sym.p[s].R);
+        }
         e->max_R = mr;
         HD_HIP(hipMemcpyAsync(e->d_sym.p, e->h_sym.p, S * sizeof(hd::SymbolParams), hipMemcpyHostToDevice, q));
         e->sym_dirty = false;
+        for (uint32_t s = 0; s < S; ++s)       // a reset flag is consumed by exactly one call: upload again without it next time
+            if (e->st[s].sym_reset) { e->st[s].sym_reset = false; e->sym_dirty = true; }
     }
     // ---- kernels
     const float2* iq = static_cast<const float2*>(d_iq);
@@ -509,10 +522,11 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     }
     const int cin = e->carry_cur, cout = e->carry_cur ^ 1;
     hd::launch_fir_demod(q, S, max_m, max_taps, fcur, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S,
-                         e->cfg.keep_filtered ? e->filtered.p : nullptr, e->carry[cin].p, e->carry[cout].p, e->d_call.p, e->fir_hist_cap);
+                         e->cfg.keep_filtered ? e->filtered.p : nullptr, e->carry[cin].p, e->carry[cout].p, e->d_call.p, e->fir_hist_cap,
+                         e->tail.p, e->tail_cap, e->d_symstate.p);
     hd::launch_fbuf_shift(q, S, fcur, fnext, e->fbuf_stride, e->d_call.p, e->fir_hist_cap);
-    hd::launch_symbols(q, S, max_m, max_held, e->max_R, e->demod.p, e->demod.n / S, e->tail.p, e->tail_cap, e->held.p, e->flipmask.p,
-                       e->weight.p, e->d_sym.p, e->d_call.p, e->slots.p, e->slot_words, e->flips_cap ? e->flips_dbg.p : nullptr, e->flips_cap);
+    hd::launch_symbols(q, S, max_m, max_new, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p,
+                       e->d_call.p, e->slots.p, e->slot_words, e->flips_cap ? e->flips_dbg.p : nullptr, e->flips_cap);
     HD_HIP(hipMemcpyAsync(e->h_slots.p, e->slots.p, (size_t)S * e->slot_words * 4, hipMemcpyDeviceToHost, q));
     if (e->timing_on) HD_HIP(hipEventRecord(e->ev[3], q));
     HD_HIP(hipGetLastError());
@@ -544,6 +558,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         const uint32_t* slot = e->h_slots.p + (size_t)s * e->slot_words;
         const hd::BitsHeader* hdr = reinterpret_cast<const hd::BitsHeader*>(slot);
         st.held = hdr->held_after;
+        st.uncached = hdr->uncached;
         st.last_nbits = hdr->nbits; st.last_nflips = hdr->nflips;
         if (hdr->overflow) return fail(HD_ERR_CAPACITY, "symbol result slot overflow on stream " + std::to_string(s));
         const uint32_t* words = slot + sizeof(hd::BitsHeader) / 4;

@@ -25,7 +25,9 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
                                                           float2* __restrict__ filtered,
                                                           const DemodCarry* __restrict__ carry_in,
                                                           DemodCarry* __restrict__ carry_out,
-                                                          const StreamCall* __restrict__ call, uint32_t fir_hist_cap)
+                                                          const StreamCall* __restrict__ call, uint32_t fir_hist_cap,
+                                                          float* __restrict__ sym_ring, uint32_t ring_cap,
+                                                          const SymState* __restrict__ sym)
 {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];   // [kFirLanes + T - 1] inputs, then reused for outputs
     const uint32_t s = blockIdx.y;
@@ -78,7 +80,12 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
         const DemodCarry k = carry_in[s];
         if (k.primed) { pr = k.re; pi = k.im; } else { pr = ar; pi = ai; }   // very first sample: arg(y0*conj(y0))
     }
-    demod[(size_t)s * demod_stride + i] = discriminate(ar, ai, pr, pi);
+    const float d = discriminate(ar, ai, pr, pi);
+    demod[(size_t)s * demod_stride + i] = d;
+    if (sym_ring) {      // append straight into the symbol extractor's ring (SymbolExtractor::pushSamples); a vent
+        const SymState st = sym[s];   // (backlog > 30000) restarts the backlog at the same position base + held
+        sym_ring[(size_t)s * ring_cap + ((st.base + st.held + (uint32_t)i) & (ring_cap - 1))] = d;
+    }
     if (filtered) filtered[(size_t)s * demod_stride + i] = make_float2(ar, ai);
     if (i == (long)m - 1) { DemodCarry k; k.re = ar; k.im = ai; k.primed = 1; k._pad = 0; carry_out[s] = k; }
 }
@@ -109,13 +116,14 @@ __global__ void k_fft_feed(const float2* __restrict__ fbuf, size_t stride, float
 
 void launch_fir_demod(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_taps, const float2* fbuf, size_t stride,
                       const float* taps, uint32_t taps_stride, float* demod, size_t demod_stride, float2* filtered,
-                      const DemodCarry* carry_in, DemodCarry* carry_out, const StreamCall* call, uint32_t fir_hist_cap)
+                      const DemodCarry* carry_in, DemodCarry* carry_out, const StreamCall* call, uint32_t fir_hist_cap,
+                      float* sym_ring, uint32_t ring_cap, const SymState* sym)
 {
     const uint32_t tiles = max_m ? (max_m + kFirLanes - 2) / (kFirLanes - 1) : 1;
     const size_t lds = (size_t)(kFirLanes + (max_taps ? max_taps : 1)) * sizeof(float2);
     dim3 grid(tiles, n_streams);
     hipLaunchKernelGGL(k_fir_demod, grid, dim3(kFirLanes), lds, st, fbuf, stride, taps, taps_stride, demod, demod_stride, filtered,
-                       carry_in, carry_out, call, fir_hist_cap);
+                       carry_in, carry_out, call, fir_hist_cap, sym_ring, ring_cap, sym);
 }
 
 void launch_fbuf_shift(hipStream_t st, uint32_t n_streams, const float2* src, float2* dst, size_t stride, const StreamCall* call,

@@ -8,13 +8,16 @@
 // size - samples_per_bit.  Each run between flips yields round(len/spb) copies of (mean > 0); consumed samples
 // are erased.
 //
-// The reference's cost is O(n*R) sequential.  Here the two window means of every candidate position are pure
-// functions of the backlog, so they are evaluated for all positions in parallel (k_sym_avg: one lane per
-// position, each lane adding its R samples left-to-right from LDS exactly like std::accumulate, so the float
-// results are bit-identical), reduced to one "signs differ" bit (ballot -> 64-bit masks) and one weight per
-// position.  The inherently sequential edge search then runs on those masks with one wave per stream
-// (k_sym_scan: 4096 positions per step through ballots and find-first-set), the per-run sums are taken by
-// separate lanes in element order, and lane 0 packs the bits for the host.
+// The reference re-evaluates O(backlog * R) window sums on every call.  Here:
+//   * the backlog lives in a per-stream power-of-two RING (the discriminator kernel appends straight into it), so
+//     "erase" is just advancing the base position -- no copies;
+//   * the two window means of a candidate position are pure functions of the samples around it, so they are
+//     computed ONCE, when the position's right window is complete (k_sym_avg: one lane per new position, each lane
+//     adding its R samples left-to-right from LDS exactly like std::accumulate, so the floats are bit-identical),
+//     and cached as one "signs differ" bit (ballot -> 64-bit mask words) plus one weight per position;
+//   * the inherently sequential edge search runs on those mask words with one wave per stream (k_sym_scan: 4096
+//     positions per step through ballots and find-first-set); per-run sums are accumulated in element order with
+//     the wave loading 256 samples at a time and v_readlane feeding a wave-uniform accumulator; lane 0 packs bits.
 #include <hip/hip_runtime.h>
 
 #include "launch.h"
@@ -24,27 +27,20 @@ namespace hd {
 constexpr int kAvgLanes = 256;
 constexpr uint32_t kMaxFlipsPerCall = 2048;   // LDS flip list of the scan kernel (overflow is flagged)
 
-__device__ __forceinline__ uint32_t backlog_after_push(uint32_t held, uint32_t m)
-{
-    return (held > kVentLimit ? 0u : held) + m;          // SymbolExtractor.h:116-124 (vent happens before the append)
-}
-
-__global__ void k_sym_append(const float* __restrict__ demod, size_t demod_stride, float* __restrict__ tail, uint32_t tail_cap,
-                             const uint32_t* __restrict__ held, const StreamCall* __restrict__ call)
-{
-    const uint32_t s = blockIdx.y;
-    const uint32_t m = call[s].fir_m;
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    const uint32_t h0 = held[s] > kVentLimit ? 0u : held[s];
-    if (h0 + j < tail_cap) tail[(size_t)s * tail_cap + h0 + j] = demod[(size_t)s * demod_stride + j];
-}
-
 __device__ __forceinline__ int sgnf(float v) { return (0.0f < v) - (v < 0.0f); }
 
-// One lane per candidate position i: left/right window means, sign-difference flag, flip weight.
-__global__ __launch_bounds__(kAvgLanes) void k_sym_avg(const float* __restrict__ tail, uint32_t tail_cap,
-                                                        const uint32_t* __restrict__ held, unsigned long long* __restrict__ flipmask,
+// State after this call's samples were appended (SymbolExtractor.h:116-124: the vent happens before the append).
+__device__ __forceinline__ SymState state_after_push(SymState st, const SymbolParams& q, uint32_t m)
+{
+    if (st.held > kVentLimit) { st.base += st.held; st.held = 0; st.cached = st.base; }
+    if (q.reset) st.cached = st.base;
+    st.held += m;
+    return st;
+}
+
+// One lane per NEW candidate position: left/right window means, sign-difference flag, flip weight.
+__global__ __launch_bounds__(kAvgLanes) void k_sym_avg(const float* __restrict__ tail, uint32_t ring_cap,
+                                                        const SymState* __restrict__ sym, unsigned long long* __restrict__ flipmask,
                                                         float* __restrict__ weight, const SymbolParams* __restrict__ sp,
                                                         const StreamCall* __restrict__ call)
 {
@@ -53,65 +49,68 @@ __global__ __launch_bounds__(kAvgLanes) void k_sym_avg(const float* __restrict__
     const uint32_t m = call[s].fir_m;
     if (!m) return;
     const SymbolParams q = sp[s];
-    const uint32_t h = backlog_after_push(held[s], m);
+    const SymState st = state_after_push(sym[s], q, m);
+    const uint32_t h = st.held;
     if (h < q.min_held || h < q.spb) return;
-    const uint32_t limit = h - q.spb;                      // candidates are i in [R, limit)
-    const uint32_t c0 = blockIdx.x * kAvgLanes;            // absolute position of lane 0 (mask words are 64-aligned)
-    if (c0 >= limit || c0 + kAvgLanes <= q.R) return;
-    const uint32_t R = q.R;
-    const float* v = tail + (size_t)s * tail_cap;
-    const long w0 = (long)c0 - (long)R;                    // absolute index of win[0]
+    const uint32_t R = q.R, rmask = ring_cap - 1;
+    const uint32_t end = st.base + h;
+    const uint32_t pend = end - R + 1;                     // first position whose right window is still incomplete
+    const uint32_t c0 = (st.cached & ~63u) + blockIdx.x * kAvgLanes;   // mask words are written whole: start 64-aligned
+    if ((int32_t)(pend - c0) <= 0) return;
+    const float* v = tail + (size_t)s * ring_cap;
+    const uint32_t w0 = c0 - R;
     const uint32_t wn = kAvgLanes + 2 * R;
-    for (uint32_t k = threadIdx.x; k < wn; k += kAvgLanes) {
-        const long a = w0 + (long)k;
-        win[k] = (a >= 0 && a < (long)h) ? v[a] : 0.0f;
-    }
+    for (uint32_t k = threadIdx.x; k < wn; k += kAvgLanes) win[k] = v[(w0 + k) & rmask];
     __syncthreads();
-    const uint32_t i = c0 + threadIdx.x;
+    const uint32_t p = c0 + threadIdx.x;
+    const bool valid = (int32_t)(pend - p) > 0;
     bool differ = false;
-    float wgt = 0.0f;
-    if (i >= R && i < limit) {
-        const float* pl = win + threadIdx.x;               // win index of absolute i-R
+    if (valid) {
+        const float* pl = win + threadIdx.x;               // window of position p starts at p - R
+        const float* pr = pl + R;
         float sl = 0.0f, sr = 0.0f;
         for (uint32_t k = 0; k < R; ++k) sl = sl + pl[k];
-        const uint32_t rn = min(i + R, h) - i;             // right window is clamped at the end of the backlog
-        const float* pr = pl + R;
-        for (uint32_t k = 0; k < rn; ++k) sr = sr + pr[k];
-        const float al = sl / (float)R;                    // left window never clamps: i >= R
-        const float ar = sr / (float)rn;
+        for (uint32_t k = 0; k < R; ++k) sr = sr + pr[k];
+        const float al = sl / (float)R, ar = sr / (float)R;    // no clamping: p >= base + R is all the search reads, p + R <= end
         differ = sgnf(al) != sgnf(ar);
         const float d = ar - al;
-        wgt = q.float_abs ? __builtin_fabsf(d) : (float)abs((int)d);
-        weight[(size_t)s * tail_cap + i] = wgt;
+        weight[(size_t)s * ring_cap + (p & rmask)] = q.float_abs ? __builtin_fabsf(d) : (float)abs((int)d);
     }
     const unsigned long long mask = __ballot(differ);
-    if ((threadIdx.x & 63) == 0) flipmask[(size_t)s * (tail_cap / 64) + (i >> 6)] = mask;
+    if ((threadIdx.x & 63) == 0) flipmask[(size_t)s * (ring_cap / 64) + ((p & rmask) >> 6)] = mask;
 }
 
-// first position in [from, to) whose flag equals `want`, or 0xFFFFFFFF.  One 64-bit mask word per lane per step.
-__device__ __forceinline__ uint32_t find_flag(const unsigned long long* __restrict__ masks, uint32_t from, uint32_t to, bool want)
+// First backlog index l in [from, to) whose flag equals `want`, or 0xFFFFFFFF.  One 64-bit mask word per lane per step.
+__device__ __forceinline__ uint32_t find_flag(const unsigned long long* __restrict__ masks, uint32_t base, uint32_t rmask,
+                                              uint32_t from, uint32_t to, bool want)
 {
     const uint32_t lane = threadIdx.x;
-    for (uint32_t base = from & ~63u; base < to; base += 64 * 64) {
-        const uint32_t wbase = base + lane * 64;           // first position covered by this lane's word
+    const uint32_t wr0 = (base + from) & ~63u;             // ring position of the first word
+    for (uint32_t it = 0;; ++it) {
+        const uint32_t wstart = wr0 + it * 4096u;
+        if ((int32_t)(wstart - base) >= (int32_t)to) break;
+        const uint32_t wr = wstart + lane * 64u;
+        const int32_t lw = (int32_t)(wr - base);           // backlog index of this word's bit 0 (may be < from)
         unsigned long long w = 0;
-        if (wbase < to) {
-            w = masks[wbase >> 6];
+        if (lw < (int32_t)to) {
+            w = masks[(wr & rmask) >> 6];
             if (!want) w = ~w;
-            if (wbase < from) w &= ~0ull << (from - wbase);             // from - wbase < 64 here
-            if (to - wbase < 64) w &= (1ull << (to - wbase)) - 1ull;
+            const int32_t lo = (int32_t)from - lw;         // keep bits >= lo
+            if (lo > 0) w = lo >= 64 ? 0ull : (w & (~0ull << lo));
+            const int32_t hi = (int32_t)to - lw;           // keep bits < hi
+            if (hi < 64) w &= (1ull << hi) - 1ull;
         }
         const unsigned long long hit = __ballot(w != 0ull);
         if (hit) {
             const int src = __ffsll((long long)hit) - 1;
             const unsigned long long ww = __shfl(w, src, 64);
-            return base + (uint32_t)src * 64 + (uint32_t)(__ffsll((long long)ww) - 1);
+            return (uint32_t)((int32_t)(wstart - base) + src * 64 + (__ffsll((long long)ww) - 1));
         }
     }
     return 0xFFFFFFFFu;
 }
 
-__global__ __launch_bounds__(64) void k_sym_scan(float* __restrict__ tail, uint32_t tail_cap, uint32_t* __restrict__ held,
+__global__ __launch_bounds__(64) void k_sym_scan(const float* __restrict__ tail, uint32_t ring_cap, SymState* __restrict__ sym,
                                                    const unsigned long long* __restrict__ flipmask, const float* __restrict__ weight,
                                                    const SymbolParams* __restrict__ sp, const StreamCall* __restrict__ call,
                                                    uint32_t* __restrict__ slots, uint32_t slot_words,
@@ -126,32 +125,33 @@ __global__ __launch_bounds__(64) void k_sym_scan(float* __restrict__ tail, uint3
     uint32_t* words = slot + sizeof(BitsHeader) / 4;
     const uint32_t cap_bits = (slot_words - sizeof(BitsHeader) / 4) * 32;
     const uint32_t m = call[s].fir_m;
-    const uint32_t h_old = held[s];
+    const SymState old = sym[s];
     if (!m) {                                               // symbol stage not reached this call
-        if (lane == 0) { hdr->nbits = 0; hdr->held_after = h_old; hdr->nflips = 0; hdr->overflow = 0; }
+        if (lane == 0) { hdr->nbits = 0; hdr->held_after = old.held; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = old.base + old.held - old.cached; }
         return;
     }
     const SymbolParams q = sp[s];
-    const uint32_t h = backlog_after_push(h_old, m);
+    SymState st = state_after_push(old, q, m);
+    const uint32_t h = st.held;
     if (h < q.min_held || h < q.spb) {
-        if (lane == 0) { held[s] = h; hdr->nbits = 0; hdr->held_after = h; hdr->nflips = 0; hdr->overflow = 0; }
+        if (lane == 0) { sym[s] = st; hdr->nbits = 0; hdr->held_after = h; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = st.base + h - st.cached; }
         return;
     }
-    float* v = tail + (size_t)s * tail_cap;
-    const unsigned long long* masks = flipmask + (size_t)s * (tail_cap / 64);
-    const float* wgt = weight + (size_t)s * tail_cap;
-    const uint32_t limit = h - q.spb;
+    const uint32_t rmask = ring_cap - 1;
+    const float* v = tail + (size_t)s * ring_cap;
+    const unsigned long long* masks = flipmask + (size_t)s * (ring_cap / 64);
+    const float* wgt = weight + (size_t)s * ring_cap;
+    const uint32_t limit = h - q.spb;                       // backlog indices searched: [R, limit)
     uint32_t pos = q.R, nfl = 0, overflow = 0;
     while (pos < limit) {
-        const uint32_t lo = find_flag(masks, pos, limit, true);
+        const uint32_t lo = find_flag(masks, st.base, rmask, pos, limit, true);
         if (lo == 0xFFFFFFFFu) break;
-        const uint32_t hi = find_flag(masks, lo + 1, limit, false);
+        const uint32_t hi = find_flag(masks, st.base, rmask, lo + 1, limit, false);
         if (hi == 0xFFFFFFFFu) break;
-        // first maximum of the weight over [lo, hi)
-        float bw = -1.0f;
+        float bw = -1.0f;                                   // first maximum of the weight over [lo, hi)
         uint32_t bi = 0xFFFFFFFFu;
         for (uint32_t i = lo + lane; i < hi; i += 64) {
-            const float w = wgt[i];
+            const float w = wgt[(st.base + i) & rmask];
             if (bi == 0xFFFFFFFFu || w > bw) { bw = w; bi = i; }
         }
         for (int off = 32; off > 0; off >>= 1) {
@@ -164,19 +164,41 @@ __global__ __launch_bounds__(64) void k_sym_scan(float* __restrict__ tail, uint3
         pos = f + q.R;
     }
     __syncthreads();
-    // per-run sums, one lane per run, elements added in index order (std::accumulate)
-    for (uint32_t r = lane; r < nfl; r += 64) {
+    // per-run sums in element order (std::accumulate): the wave fetches 256 samples per step, v_readlane feeds a
+    // wave-uniform accumulator one sample at a time
+    for (uint32_t r = 0; r < nfl; ++r) {
         const uint32_t a = r ? flips[r - 1] : 0u, b = flips[r];
         float acc = 0.0f;
-        for (uint32_t k = a; k < b; ++k) acc = acc + v[k];
-        const float mean = acc / (float)(b - a);
-        const uint32_t cnt = (uint32_t)roundf((float)(b - a) / (float)q.spb);
-        runinfo[r] = (cnt << 1) | (mean > 0.0f ? 1u : 0u);
+        for (uint32_t k0 = a; k0 < b; k0 += 256) {
+            float x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t k = k0 + 64 * j + lane;
+                x[j] = k < b ? v[(st.base + k) & rmask] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t c = k0 + 64 * j;
+                if (c >= b) break;
+                const uint32_t cnt = b - c;
+                const int xi = __builtin_bit_cast(int, x[j]);
+                if (cnt >= 64) {
+#pragma unroll
+                    for (int i = 0; i < 64; ++i) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, i));
+                } else {
+                    for (uint32_t i = 0; i < cnt; ++i) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, (int)i));
+                }
+            }
+        }
+        if (lane == 0) {
+            const float mean = acc / (float)(b - a);
+            const uint32_t cnt = (uint32_t)roundf((float)(b - a) / (float)q.spb);
+            runinfo[r] = (cnt << 1) | (mean > 0.0f ? 1u : 0u);
+        }
     }
     __syncthreads();
-    uint32_t nbits = 0;
     if (lane == 0) {
-        uint32_t cur = 0;
+        uint32_t nbits = 0, cur = 0;
         for (uint32_t r = 0; r < nfl; ++r) {
             const uint32_t bit = runinfo[r] & 1u;
             for (uint32_t k = runinfo[r] >> 1; k; --k) {
@@ -189,41 +211,27 @@ __global__ __launch_bounds__(64) void k_sym_scan(float* __restrict__ tail, uint3
         if (nbits & 31) words[nbits >> 5] = cur;
         if (flips_dbg)
             for (uint32_t r = 0; r < nfl && r < flips_cap; ++r) flips_dbg[(size_t)s * flips_cap + r] = flips[r];
-    }
-    // erase the consumed prefix (SymbolExtractor.h:156-157): move [last, h) to the front, 64 samples per step;
-    // a step's loads complete before its stores and never reach back into an earlier step's destination.
-    const uint32_t last = nfl ? flips[nfl - 1] : 0u;
-    const uint32_t keep = h - last;
-    if (last) {
-        for (uint32_t base = 0; base < keep; base += 64) {
-            const uint32_t k = base + lane;
-            float x = 0.0f;
-            if (k < keep) x = v[last + k];
-            __syncthreads();
-            if (k < keep) v[k] = x;
-            __syncthreads();
-        }
-    }
-    if (lane == 0) {
-        held[s] = keep;
-        hdr->nbits = nbits; hdr->held_after = keep; hdr->nflips = nfl; hdr->overflow = overflow;
+        // erase the consumed prefix (SymbolExtractor.h:156-157) = advance the ring base
+        const uint32_t last = nfl ? flips[nfl - 1] : 0u;
+        const uint32_t end = st.base + h;
+        st.cached = end - q.R + 1;
+        st.base += last;
+        st.held = h - last;
+        sym[s] = st;
+        hdr->nbits = nbits; hdr->held_after = st.held; hdr->nflips = nfl; hdr->overflow = overflow; hdr->uncached = end - st.cached;
     }
 }
 
-void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_held, uint32_t max_R, const float* demod,
-                    size_t demod_stride, float* tail, uint32_t tail_cap, uint32_t* held, unsigned long long* flipmask, float* weight,
-                    const SymbolParams* sp, const StreamCall* call, uint32_t* slots, uint32_t slot_words, uint32_t* flips_dbg,
-                    uint32_t flips_cap)
+void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_new, uint32_t max_R, const float* tail,
+                    uint32_t ring_cap, SymState* sym, unsigned long long* flipmask, float* weight, const SymbolParams* sp,
+                    const StreamCall* call, uint32_t* slots, uint32_t slot_words, uint32_t* flips_dbg, uint32_t flips_cap)
 {
     if (max_m) {
-        dim3 g1((max_m + 255) / 256, n_streams);
-        hipLaunchKernelGGL(k_sym_append, g1, dim3(256), 0, st, demod, demod_stride, tail, tail_cap, held, call);
-        const uint32_t span = max_held > tail_cap ? tail_cap : max_held;
-        dim3 g2((span + kAvgLanes - 1) / kAvgLanes, n_streams);
+        dim3 g2((max_new + kAvgLanes - 1) / kAvgLanes, n_streams);
         const size_t lds = (size_t)(kAvgLanes + 2 * max_R) * sizeof(float);
-        hipLaunchKernelGGL(k_sym_avg, g2, dim3(kAvgLanes), lds, st, tail, tail_cap, held, flipmask, weight, sp, call);
+        hipLaunchKernelGGL(k_sym_avg, g2, dim3(kAvgLanes), lds, st, tail, ring_cap, sym, flipmask, weight, sp, call);
     }
-    hipLaunchKernelGGL(k_sym_scan, dim3(n_streams), dim3(64), 0, st, tail, tail_cap, held, flipmask, weight, sp, call, slots,
+    hipLaunchKernelGGL(k_sym_scan, dim3(n_streams), dim3(64), 0, st, tail, ring_cap, sym, flipmask, weight, sp, call, slots,
                        slot_words, flips_dbg, flips_cap);
 }
 
