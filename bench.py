@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--workload", default="cfg4", choices=list(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync", action="store_true", help="deliver each step's text before the next step starts (no two-stream pipelining)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -157,7 +158,7 @@ def main():
     W = args.warmup
     eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"],
                             rtty_stops=w["stops"], lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"],
-                            device=local_rank)
+                            device=local_rank, pipeline=not args.sync)
     base = ring.data_ptr()
 
     def step(i):
@@ -170,8 +171,10 @@ def main():
 
     for i in range(W):
         step(i)
+    eng.flush()
     front_ms = []
     total_ms = []
+    host_us = []
     barrier()
     t0 = time.perf_counter()
     for i in range(W, W + K):
@@ -179,6 +182,8 @@ def main():
         t = eng.timing()
         front_ms.append(t["ms_front"])
         total_ms.append(t["ms_total"])
+        host_us.append((t["host_enqueue_us"], t["host_wait_us"], t["host_text_us"]))
+    eng.flush()          # the last step's text is delivered inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -220,7 +225,12 @@ def main():
         "pipeline": {"bytes_per_sample": round(bytes_per_sample(w["D"]), 3),
                      "hbm_frac_end_to_end": round(value / world * 1e6 * bytes_per_sample(w["D"]) / 1e9 / HBM_PEAK_GBS, 4),
                      "gpu_ms_per_step_all_kernels": round(float(np.mean(total_ms)), 4),
-                     "sentences_ok_rank0": int(sentences_ok)},
+                     "sentences_ok_rank0": int(sentences_ok),
+                     "host_us_enqueue_p50_p90_max": [round(float(np.percentile([h[0] for h in host_us], q)), 1) for q in (50, 90, 100)],
+                     "host_us_per_step": {"enqueue": round(float(np.mean([h[0] for h in host_us])), 1),
+                                          "wait_gpu": round(float(np.mean([h[1] for h in host_us])), 1),
+                                          "text_stage": round(float(np.mean([h[2] for h in host_us])), 1)},
+                     "mode": "sync" if args.sync else "two-stream pipelined"},
     }
     if not args.no_cpu_baseline:
         cores = os.cpu_count() or 1

@@ -18,7 +18,7 @@ class hd_engine_config(C.Structure):
     _fields_ = [("device", C.c_int32), ("n_streams", C.c_uint32), ("max_chunk", C.c_uint32), ("sampling_rate", C.c_double),
                 ("decimation", C.c_uint32), ("baud", C.c_double), ("rtty_bits", C.c_uint32), ("rtty_stops", C.c_float),
                 ("lowpass_bw_hz", C.c_float), ("lowpass_trans", C.c_float), ("dc_remove", C.c_int32), ("lookup_mode", C.c_int32),
-                ("enable_spectrum", C.c_int32), ("ungated", C.c_int32), ("keep_filtered", C.c_int32)]
+                ("enable_spectrum", C.c_int32), ("ungated", C.c_int32), ("keep_filtered", C.c_int32), ("pipeline", C.c_int32)]
 
 
 class hd_afc_info(C.Structure):
@@ -27,7 +27,8 @@ class hd_afc_info(C.Structure):
 
 
 class hd_timing(C.Structure):
-    _fields_ = [("ms_total", C.c_double), ("ms_front", C.c_double), ("front_bytes", C.c_uint64), ("samples", C.c_uint64)]
+    _fields_ = [("ms_total", C.c_double), ("ms_front", C.c_double), ("front_bytes", C.c_uint64), ("samples", C.c_uint64),
+                ("host_enqueue_us", C.c_double), ("host_wait_us", C.c_double), ("host_text_us", C.c_double)]
 
 
 SENTENCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p)
@@ -57,6 +58,7 @@ ENGINE_API = {
     "hd_set_chars_callback": (None, [_vp, CHARS_CB, _vp]),
     "hd_process_host": (_int, [_vp, _vp, _sz, _vp, _u32]),
     "hd_process_device": (_int, [_vp, _vp, _sz, _vp, _u32]),
+    "hd_flush": (_int, [_vp]),
     "hd_stream_rtty": (_sz, [_vp, _u32, C.c_char_p, _sz]),
     "hd_stream_last_sentence": (_sz, [_vp, _u32, C.c_char_p, _sz]),
     "hd_stream_take_sentences": (_sz, [_vp, _u32, C.c_char_p, _sz]),

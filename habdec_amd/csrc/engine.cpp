@@ -10,8 +10,10 @@
 #include <rocfft/rocfft.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -53,12 +55,14 @@ struct DevBuf {
 template <typename T>
 struct PinBuf {
     T* p = nullptr;
+    T* dev = nullptr;      // the same memory as the GPU addresses it (kernels write results straight into it)
     size_t n = 0;
     hipError_t alloc(size_t count)
     {
         n = count;
-        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent);
         if (e == hipSuccess) std::memset(p, 0, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), p, 0);
         return e;
     }
     ~PinBuf() { if (p) (void)hipHostFree(p); }
@@ -79,7 +83,7 @@ struct StreamHost {
     hd::LowpassDesigner lp;
     bool taps_dirty = false;
     // data-dependent state learned back from the device
-    uint32_t held = 0, uncached = 0;
+    uint32_t held = 0, win_ub = 0, inflight_m = 0;   // win_ub: upper bound of backlog samples without final window results
     bool sym_reset = true;          // symbol parameters changed since the window cache was built
     // host stages
     hd::TextStage text;
@@ -104,8 +108,7 @@ struct hd_engine {
     uint32_t tail_cap = 0, backlog_cap = 0, slot_words = 0, flips_cap = 0, max_R = 0;
     int bins_sep = 8;
     bool decode_enabled = true;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t qa = nullptr, qb = nullptr;   // front (decimation, spectrum) and back (FIR, symbols, results) HIP streams
     bool timing_on = true;
     hd_timing last_timing{};
     rocfft_plan fft_plan = nullptr;
@@ -115,17 +118,27 @@ struct hd_engine {
     DevBuf<float2> staging, dec1, hist1[2], hist2[2], fbuf[2], fft_in, fft_raw, spec, filtered;
     DevBuf<float> stage_taps[2], lp_taps, power, demod, tail, weight;
     DevBuf<unsigned long long> flipmask;
-    DevBuf<uint32_t> slots, flips_dbg;
+    DevBuf<uint32_t> flips_dbg;
     DevBuf<hd::SymState> d_symstate;
     DevBuf<hd::DemodCarry> carry[2];
-    DevBuf<hd::StreamCall> d_call;
     DevBuf<hd::SymbolParams> d_sym;
-    DevBuf<hd::SpectrumStatsDev> d_stats;
-    PinBuf<hd::StreamCall> h_call;
     PinBuf<hd::SymbolParams> h_sym;
-    PinBuf<uint32_t> h_slots;
-    PinBuf<hd::SpectrumStatsDev> h_stats;
-    PinBuf<float> h_taps;
+    // Everything a call in flight owns, double-buffered so call k+1 can be enqueued (and its front half can run)
+    // while call k's back half is still executing and its results have not been read yet.
+    struct CallSlot {
+        DevBuf<hd::StreamCall> d_call;
+        PinBuf<hd::StreamCall> h_call;
+        PinBuf<uint32_t> h_slots;                 // written by the symbol scan kernel over PCIe (zero-copy), read after ev_done
+        PinBuf<hd::SpectrumStatsDev> h_stats;    // written by the spectrum kernel
+        hipEvent_t ev_front = nullptr, ev_done = nullptr, t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr;
+        bool busy = false;
+        uint64_t total_in = 0;
+        uint32_t r1 = 1;
+        ~CallSlot() { for (hipEvent_t ev : {ev_front, ev_done, t0, t1, t2, t3}) if (ev) (void)hipEventDestroy(ev); }
+    } slot[3];
+    static constexpr int kSlots = 3;
+    uint64_t calls = 0;
+    uint64_t delivered = 0;   // calls whose results have been delivered; calls - delivered <= 2 (pipelined mode)
     int cur = 0;          // which fbuf receives this call's chunk
     int hist_cur = 0;     // which stage-history buffers are read this call (the others are written)
     int carry_cur = 0;
@@ -141,8 +154,8 @@ struct hd_engine {
     {
         if (fft_plan) rocfft_plan_destroy(fft_plan);
         if (fft_info) rocfft_execution_info_destroy(fft_info);
-        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
-        if (stream) (void)hipStreamDestroy(stream);
+        if (qa) (void)hipStreamDestroy(qa);
+        if (qb) (void)hipStreamDestroy(qb);
     }
 };
 
@@ -187,7 +200,7 @@ void hd_engine_config_default(hd_engine_config* c)
     std::memset(c, 0, sizeof(*c));
     c->device = 0; c->n_streams = 1; c->max_chunk = 65536; c->sampling_rate = 2.048e6; c->decimation = 64;
     c->baud = 300; c->rtty_bits = 8; c->rtty_stops = 2; c->lowpass_bw_hz = 1500; c->lowpass_trans = 0.025f;
-    c->dc_remove = 0; c->lookup_mode = 1; c->enable_spectrum = 1; c->ungated = 0; c->keep_filtered = 0;
+    c->dc_remove = 0; c->lookup_mode = 1; c->enable_spectrum = 1; c->ungated = 0; c->keep_filtered = 0; c->pipeline = 0;
 }
 
 int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
@@ -216,8 +229,13 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device || cfg->device < 0)
         return fail(HD_ERR_DEVICE, "no HIP device " + std::to_string(cfg->device) + " (this library has no CPU path)");
     HD_HIP(hipSetDevice(cfg->device));
-    HD_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    for (auto& ev : e->ev) HD_HIP(hipEventCreate(&ev));
+    HD_HIP(hipStreamCreateWithFlags(&e->qa, hipStreamNonBlocking));
+    HD_HIP(hipStreamCreateWithFlags(&e->qb, hipStreamNonBlocking));
+    for (auto& sl : e->slot) {
+        HD_HIP(hipEventCreateWithFlags(&sl.ev_front, hipEventDisableTiming));
+        HD_HIP(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+        for (hipEvent_t* ev : {&sl.t0, &sl.t1, &sl.t2, &sl.t3}) HD_HIP(hipEventCreate(ev));
+    }
 
     const uint32_t S = e->S;
     const uint32_t r0 = e->stages.size() > 0 ? e->stages[0].ratio : 1;
@@ -270,22 +288,21 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     HD_HIP(e->weight.alloc((size_t)S * e->tail_cap));
     HD_HIP(e->flipmask.alloc((size_t)S * (e->tail_cap / 64)));
     HD_HIP(e->d_symstate.alloc(S));
-    HD_HIP(e->slots.alloc((size_t)S * e->slot_words));
     if (e->flips_cap) HD_HIP(e->flips_dbg.alloc((size_t)S * e->flips_cap));
     for (auto& c : e->carry) HD_HIP(c.alloc(S));
-    HD_HIP(e->d_call.alloc(S));
     HD_HIP(e->d_sym.alloc(S));
-    HD_HIP(e->h_call.alloc(S));
     HD_HIP(e->h_sym.alloc(S));
-    HD_HIP(e->h_slots.alloc((size_t)S * e->slot_words));
-    HD_HIP(e->h_taps.alloc((size_t)e->taps_cap));
+    for (auto& sl : e->slot) {
+        HD_HIP(sl.d_call.alloc(S));
+        HD_HIP(sl.h_call.alloc(S));
+        HD_HIP(sl.h_slots.alloc((size_t)S * e->slot_words));
+    }
     if (cfg->enable_spectrum) {
         HD_HIP(e->fft_in.alloc((size_t)S * hd::kFftBins));
         HD_HIP(e->fft_raw.alloc((size_t)S * hd::kFftBins));
         HD_HIP(e->spec.alloc((size_t)S * hd::kFftBins));
         HD_HIP(e->power.alloc((size_t)S * hd::kFftBins));
-        HD_HIP(e->d_stats.alloc(S));
-        HD_HIP(e->h_stats.alloc(S));
+        for (auto& sl : e->slot) HD_HIP(sl.h_stats.alloc(S));
         std::call_once(g_rocfft_once, [] { rocfft_setup(); });
         const size_t len = hd::kFftBins;
         if (rocfft_plan_create(&e->fft_plan, rocfft_placement_notinplace, rocfft_transform_type_complex_forward,
@@ -299,7 +316,40 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
             HD_HIP(e->fft_work.alloc(wsz));
             rocfft_execution_info_set_work_buffer(e->fft_info, e->fft_work.p, wsz);
         }
-        rocfft_execution_info_set_stream(e->fft_info, e->stream);
+        rocfft_execution_info_set_stream(e->fft_info, e->qa);
+    }
+    // Pay first-use costs now (rocFFT's first execute alone stalls ~7 ms): run every kernel once on an all-idle call.
+    {
+        hd_engine::CallSlot& sl = e->slot[0];
+        hipStream_t q = e->qa;
+        const uint32_t T1 = e->stages.size() > 0 ? (uint32_t)e->stages[0].taps.size() : 0, T2 = e->stages.size() > 1 ? (uint32_t)e->stages[1].taps.size() : 0;
+        if (e->stages.empty()) hd::launch_passthrough(q, S, 1, e->staging.p, cfg->max_chunk, e->fbuf[0].p, e->fbuf_stride, sl.d_call.p, e->fir_hist_cap);
+        if (e->stages.size() >= 1)
+            hd::launch_decimate(q, e->stages[0].ratio, T1, S, 1, e->staging.p, cfg->max_chunk, e->hist1[0].p, e->hist1[1].p, e->stage_taps[0].p,
+                                e->stages.size() == 1 ? e->fbuf[0].p : e->dec1.p, e->stages.size() == 1 ? e->fbuf_stride : e->n1_cap, sl.d_call.p, 0,
+                                e->stages.size() == 1, e->fir_hist_cap);
+        if (e->stages.size() == 2)
+            hd::launch_decimate(q, e->stages[1].ratio, T2, S, 1, e->dec1.p, e->n1_cap, e->hist2[0].p, e->hist2[1].p, e->stage_taps[1].p, e->fbuf[0].p,
+                                e->fbuf_stride, sl.d_call.p, 1, 1, e->fir_hist_cap);
+        hd::launch_dc_remove(q, S, e->fbuf[0].p, e->fbuf_stride, sl.d_call.p, e->fir_hist_cap);
+        if (cfg->enable_spectrum) {
+            hd::launch_fft_feed(q, S, e->fbuf[0].p, e->fbuf_stride, e->fft_in.p, sl.d_call.p, e->fir_hist_cap);
+            void* in[1] = {e->fft_in.p};
+            void* outb[1] = {e->fft_raw.p};
+            if (rocfft_execute(e->fft_plan, in, outb, e->fft_info) != rocfft_status_success) return fail(HD_ERR_DEVICE, "rocfft_execute failed");
+            hd::launch_spectrum_commit(q, S, e->fft_raw.p, e->spec.p, e->power.p, sl.h_stats.dev, sl.d_call.p, e->fsd, e->bins_sep);
+        }
+        hd::launch_fir_demod(q, S, 0, 0, e->fbuf[0].p, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S, nullptr, e->carry[0].p,
+                             e->carry[1].p, sl.d_call.p, e->fir_hist_cap, e->tail.p, e->tail_cap, e->d_symstate.p);
+        hd::launch_fbuf_shift(q, S, e->fbuf[0].p, e->fbuf[1].p, e->fbuf_stride, sl.d_call.p, e->fir_hist_cap);
+        hd::launch_symbols(q, S, 1, 1, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p, sl.d_call.p,
+                           sl.h_slots.dev, e->slot_words, nullptr, 0);
+        HD_HIP(hipStreamSynchronize(q));
+        // the all-idle call moved nothing, but the history / carry ping-pong "out" buffers were written: restore zeros
+        for (auto& h : e->hist1) if (h.p) HD_HIP(hipMemset(h.p, 0, h.n * sizeof(float2)));
+        for (auto& h : e->hist2) if (h.p) HD_HIP(hipMemset(h.p, 0, h.n * sizeof(float2)));
+        for (auto& c : e->carry) HD_HIP(hipMemset(c.p, 0, c.n * sizeof(hd::DemodCarry)));
+        HD_HIP(hipMemset(e->d_symstate.p, 0, S * sizeof(hd::SymState)));
     }
     HD_HIP(hipDeviceSynchronize());
     *out = e.release();
@@ -392,17 +442,112 @@ int hd_stream_reset_frequency_correction(hd_engine* e, uint32_t s, double c)
 
 /* ---------------------------------------------------------------- data path ------------------------------------ */
 
+namespace {
+
+// Deliver the results of the call that ran in `sl`: wait for its back half, then the host stages, stream by stream
+// (AFC state machine Decoder.h:501-515; RTTY framing, sentence scan, callbacks Decoder.h:559-637).
+int collect(hd_engine* e, hd_engine::CallSlot& sl)
+{
+    if (!sl.busy) return HD_OK;
+    const auto w0 = std::chrono::steady_clock::now();
+    HD_HIP(hipEventSynchronize(sl.ev_done));
+    const auto w1 = std::chrono::steady_clock::now();
+    sl.busy = false;
+    if (e->timing_on) {
+        float a = 0, b = 0;
+        HD_HIP(hipEventElapsedTime(&a, sl.t0, sl.t3));
+        HD_HIP(hipEventElapsedTime(&b, sl.t1, sl.t2));
+        e->last_timing.ms_total = a;
+        e->last_timing.ms_front = b;
+        e->last_timing.samples = sl.total_in;
+        e->last_timing.front_bytes = sl.total_in * 8 + (sl.total_in / sl.r1) * 8;
+    }
+    int rc = HD_OK;
+    for (uint32_t s = 0; s < e->S; ++s) {
+        StreamHost& st = e->st[s];
+        const hd::StreamCall& c = sl.h_call.p[s];
+        if (c.fft_run) {
+            std::memcpy(&st.stats, &sl.h_stats.p[s], sizeof(st.stats));
+            st.have_spectrum = true;
+            ++st.spectra;
+        }
+        const bool past_batch_gate = c.fir_m || c.clear_pending;
+        if (past_batch_gate && e->cfg.enable_spectrum) st.afc.step(st.have_spectrum, st.stats, hd::kFftBins, e->fsd);
+        const uint32_t* slot = sl.h_slots.p + (size_t)s * e->slot_words;
+        const hd::BitsHeader* hdr = reinterpret_cast<const hd::BitsHeader*>(slot);
+        st.held = hdr->held_after;
+        st.inflight_m -= c.fir_m;
+        st.win_ub = hdr->uncached + st.inflight_m;
+        st.last_nbits = hdr->nbits; st.last_nflips = hdr->nflips;
+        if (hdr->overflow) rc = fail(HD_ERR_CAPACITY, "symbol result slot overflow on stream " + std::to_string(s));
+        const uint32_t* words = slot + sizeof(hd::BitsHeader) / 4;
+        st.last_words.assign(words, words + (hdr->nbits + 31) / 32);
+        if (!c.fir_m) continue;
+        if (hdr->nbits) st.text.framer.push_packed(words, hdr->nbits);
+        const std::string chars = st.text.run(hdr->nbits != 0, [&](const hd::SentenceMatch& m) {
+            ++e->sentences_ok;
+            if (e->sentence_cb) e->sentence_cb(e->sentence_user, s, m.callsign.c_str(), m.data.c_str(), m.crc.c_str());
+        });
+        if (!chars.empty() && e->chars_cb) e->chars_cb(e->chars_user, s, chars.data(), chars.size());
+    }
+    e->last_timing.host_wait_us = std::chrono::duration<double, std::micro>(w1 - w0).count();
+    e->last_timing.host_text_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w1).count();
+    return rc;
+}
+
+int flush_locked(hd_engine* e)
+{
+    int rc = HD_OK;
+    while (e->delivered < e->calls) {           // oldest first
+        const int r = collect(e, e->slot[e->delivered % hd_engine::kSlots]);
+        if (r) rc = r;
+        ++e->delivered;
+    }
+    return rc;
+}
+
+}  // namespace
+
+int hd_flush(hd_engine* e)
+{
+    if (!e) return fail(HD_ERR_INVALID, "null engine");
+    std::lock_guard<std::mutex> lock(e->mtx);
+    HD_HIP(hipSetDevice(e->cfg.device));
+    return flush_locked(e);
+}
+
 int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint32_t* n_per_stream, uint32_t n_uniform)
 {
     if (!e) return fail(HD_ERR_INVALID, "null engine");
     if (!d_iq) return fail(HD_ERR_INVALID, "null IQ pointer");
     if ((reinterpret_cast<uintptr_t>(d_iq) & 15) || (stride & 1)) return fail(HD_ERR_INVALID, "IQ base must be 16-byte aligned and stream_stride even");
     std::lock_guard<std::mutex> lock(e->mtx);
+    const auto h0 = std::chrono::steady_clock::now();
     HD_HIP(hipSetDevice(e->cfg.device));
     const uint32_t S = e->S;
     const size_t nst = e->stages.size();
     const uint32_t T1 = nst > 0 ? (uint32_t)e->stages[0].taps.size() : 0, T2 = nst > 1 ? (uint32_t)e->stages[1].taps.size() : 0;
     const uint32_t R1 = nst > 0 ? e->stages[0].ratio : 1, R2 = nst > 1 ? e->stages[1].ratio : 1;
+
+    // ---- validate first, so a rejected call leaves every stream untouched
+    for (uint32_t s = 0; s < S; ++s) {
+        const uint32_t n = n_per_stream ? n_per_stream[s] : n_uniform;
+        if (n > e->cfg.max_chunk) return fail(HD_ERR_CAPACITY, "more samples than max_chunk");
+        if (n % e->D) return fail(HD_ERR_INVALID, "sample count must be a multiple of the decimation factor (queue the remainder)");
+        if (n && nst > 0 && n + 1 < T1) return fail(HD_ERR_UNSUPPORTED, "chunk shorter than the first stage's history (undefined in the reference)");
+        if (n && nst > 1 && n / R1 + 1 < T2) return fail(HD_ERR_UNSUPPORTED, "chunk shorter than the second stage's history (undefined in the reference)");
+    }
+    // Control-plane changes (new low-pass design, new symbol parameters) rewrite device tables the previous call's
+    // back half may still be reading: drain the pipeline first.  Rare.
+    bool tables_dirty = e->sym_dirty;
+    for (uint32_t s = 0; s < S && !tables_dirty; ++s) tables_dirty = e->st[s].taps_dirty;
+    if (tables_dirty) { if (int rc = flush_locked(e)) return rc; }
+
+    hd_engine::CallSlot& sl = e->slot[e->calls % hd_engine::kSlots];
+    while (sl.busy) {                            // cannot happen with depth <= 2, but never reuse a slot in flight
+        if (int rc = collect(e, e->slot[e->delivered % hd_engine::kSlots])) return rc;
+        ++e->delivered;
+    }
 
     // ---- host mirror of the reference's size bookkeeping -> one StreamCall per stream
     uint32_t max_in = 0, max_n1 = 0, max_n2 = 0, max_m = 0, max_taps = 0, max_new = 0;
@@ -412,14 +557,10 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         StreamHost& st = e->st[s];
         hd::StreamCall c{};
         const uint32_t n = n_per_stream ? n_per_stream[s] : n_uniform;
-        if (n > e->cfg.max_chunk) return fail(HD_ERR_CAPACITY, "more samples than max_chunk");
-        if (n % e->D) return fail(HD_ERR_INVALID, "sample count must be a multiple of the decimation factor (queue the remainder)");
         c.n_in = n;
         c.n1 = n / R1;
         c.n2 = c.n1 / R2;
-        if (n) {
-            if (nst > 0 && n + 1 < T1) return fail(HD_ERR_UNSUPPORTED, "chunk shorter than the first stage's history (undefined in the reference)");
-            if (nst > 1 && c.n1 + 1 < T2) return fail(HD_ERR_UNSUPPORTED, "chunk shorter than the second stage's history (undefined in the reference)");
+        if (n) {   // Decimator::setInput growth rule (Decimator.h:74-79, Q5)
             if (nst > 0) { const size_t want = (size_t)n + T1 + R1; if (st.stage_buf[0] < want) { st.stage_buf[0] = want; c.zero_hist1 = 1; } }
             if (nst > 1) { const size_t want = (size_t)c.n1 + T2 + R2; if (st.stage_buf[1] < want) { st.stage_buf[1] = want; c.zero_hist2 = 1; } }
         }
@@ -440,7 +581,10 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         else if (past_batch_gate) {
             const uint32_t m = (uint32_t)(st.pending - st.pending % hd::kFirBatch);
             st.lp.batch = m;                                                       // FirFilter::setInput
-            if (st.lp.design(cutoff_rel(e, st), st.lp_trans)) st.taps_dirty = true; // LP_BlackmanHarris, Decoder.h:538
+            if (st.lp.design(cutoff_rel(e, st), st.lp_trans)) {                    // LP_BlackmanHarris, Decoder.h:538
+                st.taps_dirty = true;
+                if (int rc = flush_locked(e)) return rc;                           // (only when a stream's batch size changes)
+            }
             const uint32_t T = (uint32_t)st.lp.taps.size();
             if (!T) return fail(HD_ERR_UNSUPPORTED, "low-pass transition width leaves no taps (reference filters nothing then)");
             if (T > e->taps_cap) return fail(HD_ERR_CAPACITY, "low-pass tap count exceeds engine capacity");
@@ -450,26 +594,36 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             st.last_m = m;
             max_m = std::max(max_m, m);
             max_taps = std::max(max_taps, T);
-            // positions whose windows become computable this call (device: k_sym_avg range)
-            const bool vent = st.held > hd::kVentLimit;
-            const uint32_t pending_windows = vent ? 0u : (st.sym_reset ? st.held : st.uncached);
+            // positions whose windows can become computable this call (device: k_sym_avg range), as an upper bound
+            const uint32_t pending_windows = st.sym_reset ? std::max(st.held, st.win_ub) : st.win_ub;
             max_new = std::max(max_new, pending_windows + m + 64u);
+            st.inflight_m += m;
+            st.win_ub += m;
         }
         c.pend_after = (uint32_t)st.pending;
         st.last_n2 = c.n2; st.last_pend_before = c.pend_before; st.last_buf = e->cur;
-        e->h_call.p[s] = c;
+        sl.h_call.p[s] = c;
         max_in = std::max(max_in, n); max_n1 = std::max(max_n1, c.n1); max_n2 = std::max(max_n2, c.n2);
         any_dc |= c.dc_remove != 0;
         total_in += n;
     }
+    sl.total_in = total_in;
+    sl.r1 = R1;
+    const auto h1 = std::chrono::steady_clock::now();
     // ---- uploads: per-call parameters, changed low-pass designs, changed symbol parameters
-    hipStream_t q = e->stream;
-    HD_HIP(hipMemcpyAsync(e->d_call.p, e->h_call.p, S * sizeof(hd::StreamCall), hipMemcpyHostToDevice, q));
+    hipStream_t qa = e->qa, qb = e->qb;
+    double tp[12]; int ntp = 0;
+    auto mark = [&] { if (ntp < 12) tp[ntp++] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count(); };
+    mark();
+    // With two calls in flight the front half of call k could otherwise overwrite the low-pass input buffer that the
+    // back half of call k-2 is still reading (same ping-pong parity): order it behind that call's completion.
+    if (e->calls >= 2) HD_HIP(hipStreamWaitEvent(qa, e->slot[(e->calls - 2) % hd_engine::kSlots].ev_done, 0));
+    if (e->timing_on) HD_HIP(hipEventRecord(sl.t0, qa));
+    hd::launch_fetch_params(qa, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
     for (uint32_t s = 0; s < S; ++s) {
         StreamHost& st = e->st[s];
         if (!st.taps_dirty) continue;
-        // identical designs are common (all streams share defaults): upload from the first dirty stream's copy
-        HD_HIP(hipMemcpyAsync(e->lp_taps.p + (size_t)s * e->taps_cap, st.lp.taps.data(), st.lp.taps.size() * 4, hipMemcpyHostToDevice, q));
+        HD_HIP(hipMemcpyAsync(e->lp_taps.p + (size_t)s * e->taps_cap, st.lp.taps.data(), st.lp.taps.size() * 4, hipMemcpyHostToDevice, qa));
         st.taps_dirty = false;
     }
     if (e->sym_dirty) {
@@ -480,98 +634,94 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             mr = std::max(mr, e->h_sym.p[s].R);
         }
         e->max_R = mr;
-        HD_HIP(hipMemcpyAsync(e->d_sym.p, e->h_sym.p, S * sizeof(hd::SymbolParams), hipMemcpyHostToDevice, q));
+        HD_HIP(hipMemcpyAsync(e->d_sym.p, e->h_sym.p, S * sizeof(hd::SymbolParams), hipMemcpyHostToDevice, qa));
         e->sym_dirty = false;
         for (uint32_t s = 0; s < S; ++s)       // a reset flag is consumed by exactly one call: upload again without it next time
             if (e->st[s].sym_reset) { e->st[s].sym_reset = false; e->sym_dirty = true; }
     }
-    // ---- kernels
+    mark();
+    // ---- front half on qa: decimation, DC blocker, spectrum
     const float2* iq = static_cast<const float2*>(d_iq);
     float2* fcur = e->fbuf[e->cur].p;
     float2* fnext = e->fbuf[e->cur ^ 1].p;
-    if (e->timing_on) HD_HIP(hipEventRecord(e->ev[0], q));
+    const hd::StreamCall* dcall = sl.d_call.p;
     if (nst == 0) {
-        hd::launch_passthrough(q, S, max_in, iq, stride, fcur, e->fbuf_stride, e->d_call.p, e->fir_hist_cap);
-        if (e->timing_on) { HD_HIP(hipEventRecord(e->ev[1], q)); HD_HIP(hipEventRecord(e->ev[2], q)); }
+        if (e->timing_on) HD_HIP(hipEventRecord(sl.t1, qa));
+        hd::launch_passthrough(qa, S, max_in, iq, stride, fcur, e->fbuf_stride, dcall, e->fir_hist_cap);
+        if (e->timing_on) HD_HIP(hipEventRecord(sl.t2, qa));
     } else {
         const bool single = nst == 1;
         float2* out1 = single ? fcur : e->dec1.p;
         const size_t out1_stride = single ? e->fbuf_stride : e->n1_cap;
-        if (e->timing_on) HD_HIP(hipEventRecord(e->ev[1], q));
+        if (e->timing_on) HD_HIP(hipEventRecord(sl.t1, qa));
         const int hin = e->hist_cur, hout = e->hist_cur ^ 1;
-        if (!hd::launch_decimate(q, R1, T1, S, max_n1, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
-                                 e->d_call.p, 0, single ? 1 : 0, e->fir_hist_cap))
+        if (!hd::launch_decimate(qa, R1, T1, S, max_n1, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
+                                 dcall, 0, single ? 1 : 0, e->fir_hist_cap))
             return fail(HD_ERR_INVALID, "no kernel for this decimation stage");
-        if (e->timing_on) HD_HIP(hipEventRecord(e->ev[2], q));
+        if (e->timing_on) HD_HIP(hipEventRecord(sl.t2, qa));
         if (!single) {
-            if (!hd::launch_decimate(q, R2, T2, S, max_n2, e->dec1.p, e->n1_cap, e->hist2[hin].p, e->hist2[hout].p, e->stage_taps[1].p, fcur,
-                                     e->fbuf_stride, e->d_call.p, 1, 1, e->fir_hist_cap))
+            if (!hd::launch_decimate(qa, R2, T2, S, max_n2, e->dec1.p, e->n1_cap, e->hist2[hin].p, e->hist2[hout].p, e->stage_taps[1].p, fcur,
+                                     e->fbuf_stride, dcall, 1, 1, e->fir_hist_cap))
                 return fail(HD_ERR_INVALID, "no kernel for this decimation stage");
         }
     }
-    if (any_dc) hd::launch_dc_remove(q, S, fcur, e->fbuf_stride, e->d_call.p, e->fir_hist_cap);
+    mark();
+    if (any_dc) hd::launch_dc_remove(qa, S, fcur, e->fbuf_stride, dcall, e->fir_hist_cap);
     if (e->cfg.enable_spectrum && max_n2) {
-        hd::launch_fft_feed(q, S, fcur, e->fbuf_stride, e->fft_in.p, e->d_call.p, e->fir_hist_cap);
+        hd::launch_fft_feed(qa, S, fcur, e->fbuf_stride, e->fft_in.p, dcall, e->fir_hist_cap);
         if (any_fft) {
             void* in[1] = {e->fft_in.p};
             void* outb[1] = {e->fft_raw.p};
             if (rocfft_execute(e->fft_plan, in, outb, e->fft_info) != rocfft_status_success) return fail(HD_ERR_DEVICE, "rocfft_execute failed");
-            hd::launch_spectrum_commit(q, S, e->fft_raw.p, e->spec.p, e->power.p, e->d_stats.p, e->d_call.p, e->fsd, e->bins_sep);
-            HD_HIP(hipMemcpyAsync(e->h_stats.p, e->d_stats.p, S * sizeof(hd::SpectrumStatsDev), hipMemcpyDeviceToHost, q));
+            hd::launch_spectrum_commit(qa, S, e->fft_raw.p, e->spec.p, e->power.p, sl.h_stats.dev, dcall, e->fsd, e->bins_sep);
         }
     }
+    mark();
+    HD_HIP(hipEventRecord(sl.ev_front, qa));
+    const auto h2 = std::chrono::steady_clock::now();
+    // ---- back half on qb: low-pass + discriminator, buffer slide, symbol extractor, results.  It may still be running
+    // when the NEXT call's front half starts on qa: the two halves touch disjoint buffers (DESIGN.md "two-stream pipeline").
+    HD_HIP(hipStreamWaitEvent(qb, sl.ev_front, 0));
+    mark();
     const int cin = e->carry_cur, cout = e->carry_cur ^ 1;
-    hd::launch_fir_demod(q, S, max_m, max_taps, fcur, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S,
-                         e->cfg.keep_filtered ? e->filtered.p : nullptr, e->carry[cin].p, e->carry[cout].p, e->d_call.p, e->fir_hist_cap,
+    hd::launch_fir_demod(qb, S, max_m, max_taps, fcur, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S,
+                         e->cfg.keep_filtered ? e->filtered.p : nullptr, e->carry[cin].p, e->carry[cout].p, dcall, e->fir_hist_cap,
                          e->tail.p, e->tail_cap, e->d_symstate.p);
-    hd::launch_fbuf_shift(q, S, fcur, fnext, e->fbuf_stride, e->d_call.p, e->fir_hist_cap);
-    hd::launch_symbols(q, S, max_m, max_new, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p,
-                       e->d_call.p, e->slots.p, e->slot_words, e->flips_cap ? e->flips_dbg.p : nullptr, e->flips_cap);
-    HD_HIP(hipMemcpyAsync(e->h_slots.p, e->slots.p, (size_t)S * e->slot_words * 4, hipMemcpyDeviceToHost, q));
-    if (e->timing_on) HD_HIP(hipEventRecord(e->ev[3], q));
+    mark();
+    hd::launch_fbuf_shift(qb, S, fcur, fnext, e->fbuf_stride, dcall, e->fir_hist_cap);
+    mark();
+    hd::launch_symbols(qb, S, max_m, max_new, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p,
+                       dcall, sl.h_slots.dev, e->slot_words, e->flips_cap ? e->flips_dbg.p : nullptr, e->flips_cap);
+    mark();
+    if (e->timing_on) HD_HIP(hipEventRecord(sl.t3, qb));
+    HD_HIP(hipEventRecord(sl.ev_done, qb));
+    mark();
     HD_HIP(hipGetLastError());
-    HD_HIP(hipStreamSynchronize(q));
+    sl.busy = true;
     e->cur ^= 1;
     e->carry_cur ^= 1;
     if (max_in && nst) e->hist_cur ^= 1;
-    if (e->timing_on) {
-        float a = 0, b = 0;
-        HD_HIP(hipEventElapsedTime(&a, e->ev[0], e->ev[3]));
-        HD_HIP(hipEventElapsedTime(&b, e->ev[1], e->ev[2]));
-        e->last_timing.ms_total = a;
-        e->last_timing.ms_front = b;
-        e->last_timing.samples = total_in;
-        e->last_timing.front_bytes = total_in * 8 + (total_in / R1) * 8;
+    ++e->calls;
+    e->last_timing.host_enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
+    if (getenv("HD_TRACE") && e->last_timing.host_enqueue_us > 400) {
+        fprintf(stderr, "[hd] slow call %llu:", (unsigned long long)e->calls);
+        for (int i = 0; i < ntp; ++i) fprintf(stderr, " %.0f", tp[i]);
+        fprintf(stderr, "\n");
     }
-
-    // ---- host stages, stream by stream (Decoder.h:501-515, 559-637)
-    for (uint32_t s = 0; s < S; ++s) {
-        StreamHost& st = e->st[s];
-        const hd::StreamCall& c = e->h_call.p[s];
-        if (c.fft_run) {
-            std::memcpy(&st.stats, &e->h_stats.p[s], sizeof(st.stats));
-            st.have_spectrum = true;
-            ++st.spectra;
-        }
-        const bool past_batch_gate = c.fir_m || c.clear_pending;
-        if (past_batch_gate && e->cfg.enable_spectrum) st.afc.step(st.have_spectrum, st.stats, hd::kFftBins, e->fsd);
-        const uint32_t* slot = e->h_slots.p + (size_t)s * e->slot_words;
-        const hd::BitsHeader* hdr = reinterpret_cast<const hd::BitsHeader*>(slot);
-        st.held = hdr->held_after;
-        st.uncached = hdr->uncached;
-        st.last_nbits = hdr->nbits; st.last_nflips = hdr->nflips;
-        if (hdr->overflow) return fail(HD_ERR_CAPACITY, "symbol result slot overflow on stream " + std::to_string(s));
-        const uint32_t* words = slot + sizeof(hd::BitsHeader) / 4;
-        st.last_words.assign(words, words + (hdr->nbits + 31) / 32);
-        if (!c.fir_m) continue;
-        if (hdr->nbits) st.text.framer.push_packed(words, hdr->nbits);
-        const std::string chars = st.text.run(hdr->nbits != 0, [&](const hd::SentenceMatch& m) {
-            ++e->sentences_ok;
-            if (e->sentence_cb) e->sentence_cb(e->sentence_user, s, m.callsign.c_str(), m.data.c_str(), m.crc.c_str());
-        });
-        if (!chars.empty() && e->chars_cb) e->chars_cb(e->chars_user, s, chars.data(), chars.size());
+    if (getenv("HD_TRACE") && (e->calls % 64) == 0)
+        fprintf(stderr, "[hd] call %llu: mirror %.1f us, front enqueue %.1f us, back enqueue %.1f us\n", (unsigned long long)e->calls,
+                std::chrono::duration<double, std::micro>(h1 - h0).count(), std::chrono::duration<double, std::micro>(h2 - h1).count(),
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h2).count());
+    if (!e->cfg.pipeline) { ++e->delivered; return collect(e, sl); }
+    // pipelined: keep up to two calls in flight; deliver the oldest one's results now (its host stage overlaps the GPU work
+    // of the newer calls, and the GPU always has the next call queued)
+    int rc = HD_OK;
+    while (e->calls - e->delivered > 2) {
+        const int r = collect(e, e->slot[e->delivered % hd_engine::kSlots]);
+        if (r) rc = r;
+        ++e->delivered;
     }
-    return HD_OK;
+    return rc;
 }
 
 int hd_process_host(hd_engine* e, const float* iq, size_t stride, const uint32_t* n_per_stream, uint32_t n_uniform)
@@ -584,12 +734,12 @@ int hd_process_host(hd_engine* e, const float* iq, size_t stride, const uint32_t
         if (n_uniform > e->cfg.max_chunk) return fail(HD_ERR_CAPACITY, "more samples than max_chunk");
         if (n_uniform)
             HD_HIP(hipMemcpy2DAsync(e->staging.p, dstride * sizeof(float2), iq, stride * sizeof(float2), (size_t)n_uniform * sizeof(float2),
-                                    e->S, hipMemcpyHostToDevice, e->stream));
+                                    e->S, hipMemcpyHostToDevice, e->qa));
     } else {
         for (uint32_t s = 0; s < e->S; ++s) {
             const uint32_t n = n_per_stream[s];
             if (n > e->cfg.max_chunk) return fail(HD_ERR_CAPACITY, "more samples than max_chunk");
-            if (n) HD_HIP(hipMemcpyAsync(e->staging.p + (size_t)s * dstride, iq + 2 * (size_t)s * stride, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, e->stream));
+            if (n) HD_HIP(hipMemcpyAsync(e->staging.p + (size_t)s * dstride, iq + 2 * (size_t)s * stride, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, e->qa));
         }
     }
     return hd_process_device(e, e->staging.p, dstride, n_per_stream, n_uniform);
@@ -634,6 +784,7 @@ int hd_stream_afc(hd_engine* e, uint32_t s, hd_afc_info* out)
 
 static size_t fetch(hd_engine* e, const void* dev, size_t count, size_t elem, void* host, size_t cap)
 {
+    (void)flush_locked(e);                                  // pipelined mode: wait for the call in flight
     const size_t n = std::min(count, cap);
     if (!n || !host) return count;
     if (hipSetDevice(e->cfg.device) != hipSuccess) return 0;

@@ -114,6 +114,21 @@ __global__ void k_fft_feed(const float2* __restrict__ fbuf, size_t stride, float
     fft_in[(size_t)s * kFftBins + c.fft_fill + j] = fbuf[(size_t)s * stride + fir_hist_cap + c.pend_before + j];
 }
 
+// Per-call parameters come from mapped pinned host memory; one small kernel pulls them into HBM so that the
+// thousands of workgroups of the following kernels read them from L2 instead of over PCIe.  (A hipMemcpyAsync
+// here stalled the enqueueing thread for milliseconds every few calls on this ROCm release.)
+__global__ void k_fetch_params(const uint4* __restrict__ host_src, uint4* __restrict__ dst, uint32_t n16)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = host_src[i];
+}
+
+void launch_fetch_params(hipStream_t st, const void* host_mapped, void* dst, size_t bytes)
+{
+    const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
+    hipLaunchKernelGGL(k_fetch_params, dim3((n16 + 255) / 256), dim3(256), 0, st, static_cast<const uint4*>(host_mapped), static_cast<uint4*>(dst), n16);
+}
+
 void launch_fir_demod(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_taps, const float2* fbuf, size_t stride,
                       const float* taps, uint32_t taps_stride, float* demod, size_t demod_stride, float2* filtered,
                       const DemodCarry* carry_in, DemodCarry* carry_out, const StreamCall* call, uint32_t fir_hist_cap,

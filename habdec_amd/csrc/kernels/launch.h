@@ -23,6 +23,8 @@ bool launch_decimate(hipStream_t st, int ratio, int ntaps, uint32_t n_streams, u
                      const float2* in, size_t in_stride, const float2* hist_in, float2* hist_out, const float* taps,
                      float2* out, size_t out_stride, const StreamCall* call, int stage, int final_stage,
                      uint32_t fir_hist_cap);
+// copy `bytes` (multiple of 16) from mapped pinned host memory into device memory with a kernel
+void launch_fetch_params(hipStream_t st, const void* host_mapped, void* dst, size_t bytes);
 // factor 1: copy the chunk behind the FIR history.
 void launch_passthrough(hipStream_t st, uint32_t n_streams, uint32_t max_n, const float2* in, size_t in_stride,
                         float2* out, size_t out_stride, const StreamCall* call, uint32_t fir_hist_cap);

@@ -38,13 +38,59 @@ __device__ __forceinline__ SymState state_after_push(SymState st, const SymbolPa
     return st;
 }
 
-// One lane per NEW candidate position: left/right window means, sign-difference flag, flip weight.
+// Window sums for the NEW candidate positions.  One lane owns 4 consecutive positions: it walks its R+3 left-window
+// samples (then the R+3 right-window samples) once with 16-byte LDS reads and adds each sample to every one of its
+// four accumulators whose window contains it.  Each accumulator still receives exactly its own R samples in index
+// order, so the sums are bit-identical to std::accumulate, with 1/16 of the LDS instructions of the scalar form.
+constexpr int kAvgPos = 4;                                  // positions per lane
+constexpr int kAvgSpan = kAvgLanes * kAvgPos;               // positions per workgroup (1024)
+
+__device__ __forceinline__ void window_sums(const float* __restrict__ w, uint32_t R, float acc[kAvgPos])
+{
+    // accumulator j sums w[j .. j+R)
+#pragma unroll
+    for (int j = 0; j < kAvgPos; ++j) acc[j] = 0.0f;
+    const uint32_t total = R + kAvgPos - 1;                 // samples touched: w[0 .. R+3)
+    uint32_t e = 0;
+    {   // head chunk: element e feeds accumulators j <= e
+        const float4 x = *reinterpret_cast<const float4*>(w);
+        const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < kAvgPos; ++j)
+                if (j <= u && (uint32_t)u < (uint32_t)j + R) acc[j] = acc[j] + xs[u];
+        e = 4;
+    }
+    for (; e + 4 <= R; e += 4) {                            // interior: every element feeds all four
+        const float4 x = *reinterpret_cast<const float4*>(w + e);
+#pragma unroll
+        for (int j = 0; j < kAvgPos; ++j) acc[j] = acc[j] + x.x;
+#pragma unroll
+        for (int j = 0; j < kAvgPos; ++j) acc[j] = acc[j] + x.y;
+#pragma unroll
+        for (int j = 0; j < kAvgPos; ++j) acc[j] = acc[j] + x.z;
+#pragma unroll
+        for (int j = 0; j < kAvgPos; ++j) acc[j] = acc[j] + x.w;
+    }
+    for (; e < total; e += 4) {                             // tail chunks: element e feeds accumulators with e < j + R
+        const float4 x = *reinterpret_cast<const float4*>(w + e);
+        const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < kAvgPos; ++j)
+                if (e + u >= (uint32_t)j && e + u < (uint32_t)j + R) acc[j] = acc[j] + xs[u];
+    }
+}
+
 __global__ __launch_bounds__(kAvgLanes) void k_sym_avg(const float* __restrict__ tail, uint32_t ring_cap,
                                                         const SymState* __restrict__ sym, unsigned long long* __restrict__ flipmask,
                                                         float* __restrict__ weight, const SymbolParams* __restrict__ sp,
                                                         const StreamCall* __restrict__ call)
 {
-    extern __shared__ float win[];                         // tail[c0 - R, c0 + 256 + R)
+    extern __shared__ __attribute__((aligned(16))) float win[];   // tail[c0 - R, c0 + span + R + pad)
+    __shared__ unsigned long long words[kAvgSpan / 64];
     const uint32_t s = blockIdx.y;
     const uint32_t m = call[s].fir_m;
     if (!m) return;
@@ -55,29 +101,60 @@ __global__ __launch_bounds__(kAvgLanes) void k_sym_avg(const float* __restrict__
     const uint32_t R = q.R, rmask = ring_cap - 1;
     const uint32_t end = st.base + h;
     const uint32_t pend = end - R + 1;                     // first position whose right window is still incomplete
-    const uint32_t c0 = (st.cached & ~63u) + blockIdx.x * kAvgLanes;   // mask words are written whole: start 64-aligned
+    const uint32_t c0 = (st.cached & ~63u) + blockIdx.x * kAvgSpan;   // mask words are written whole: start 64-aligned
     if ((int32_t)(pend - c0) <= 0) return;
     const float* v = tail + (size_t)s * ring_cap;
     const uint32_t w0 = c0 - R;
-    const uint32_t wn = kAvgLanes + 2 * R;
+    const uint32_t wn = kAvgSpan + 2 * R + 8;
     for (uint32_t k = threadIdx.x; k < wn; k += kAvgLanes) win[k] = v[(w0 + k) & rmask];
+    if (threadIdx.x < kAvgSpan / 64) words[threadIdx.x] = 0ull;
     __syncthreads();
-    const uint32_t p = c0 + threadIdx.x;
-    const bool valid = (int32_t)(pend - p) > 0;
-    bool differ = false;
-    if (valid) {
-        const float* pl = win + threadIdx.x;               // window of position p starts at p - R
-        const float* pr = pl + R;
-        float sl = 0.0f, sr = 0.0f;
-        for (uint32_t k = 0; k < R; ++k) sl = sl + pl[k];
-        for (uint32_t k = 0; k < R; ++k) sr = sr + pr[k];
-        const float al = sl / (float)R, ar = sr / (float)R;    // no clamping: p >= base + R is all the search reads, p + R <= end
-        differ = sgnf(al) != sgnf(ar);
-        const float d = ar - al;
-        weight[(size_t)s * ring_cap + (p & rmask)] = q.float_abs ? __builtin_fabsf(d) : (float)abs((int)d);
+    const uint32_t p0 = c0 + threadIdx.x * kAvgPos;        // this lane's first position; its left window starts at win[4*lane]
+    float sl[kAvgPos], sr[kAvgPos];
+    window_sums(win + threadIdx.x * kAvgPos, R, sl);
+    // right windows start R samples later; R is not a multiple of 4 in general, so realign through a 4-float shift
+    {
+        const uint32_t off = threadIdx.x * kAvgPos + R;    // win index of position p0
+        const uint32_t al = off & ~3u, sh = off & 3u;      // aligned start, residual shift
+        // accumulator j sums win[off + j .. off + j + R) = aligned[sh + j .. sh + j + R)
+        const float* w = win + al;
+#pragma unroll
+        for (int j = 0; j < kAvgPos; ++j) sr[j] = 0.0f;
+        const uint32_t total = sh + R + kAvgPos - 1;
+        for (uint32_t e = 0; e < total; e += 4) {
+            const float4 x = *reinterpret_cast<const float4*>(w + e);
+            const float xs[4] = {x.x, x.y, x.z, x.w};
+            const bool interior = e >= sh + kAvgPos - 1 && e + 4 <= sh + R;
+            if (interior) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < kAvgPos; ++j) sr[j] = sr[j] + xs[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < kAvgPos; ++j)
+                        if (e + u >= sh + (uint32_t)j && e + u < sh + (uint32_t)j + R) sr[j] = sr[j] + xs[u];
+            }
+        }
     }
-    const unsigned long long mask = __ballot(differ);
-    if ((threadIdx.x & 63) == 0) flipmask[(size_t)s * (ring_cap / 64) + ((p & rmask) >> 6)] = mask;
+    unsigned int bits = 0;
+#pragma unroll
+    for (int j = 0; j < kAvgPos; ++j) {
+        const uint32_t p = p0 + j;
+        if ((int32_t)(pend - p) > 0) {
+            const float al = sl[j] / (float)R, ar = sr[j] / (float)R;   // no clamping: p >= base+R is all the search reads, p+R <= end
+            if (sgnf(al) != sgnf(ar)) bits |= 1u << j;
+            const float d = ar - al;
+            weight[(size_t)s * ring_cap + (p & rmask)] = q.float_abs ? __builtin_fabsf(d) : (float)abs((int)d);
+        }
+    }
+    // lane l owns bits [4l, 4l+4) of the workgroup's 1024-position span: 16 lanes per 64-bit word
+    if (bits) atomicOr(&words[threadIdx.x >> 4], (unsigned long long)bits << ((threadIdx.x & 15) * 4));
+    __syncthreads();
+    if (threadIdx.x < kAvgSpan / 64)
+        flipmask[(size_t)s * (ring_cap / 64) + (((c0 + threadIdx.x * 64) & rmask) >> 6)] = words[threadIdx.x];
 }
 
 // First backlog index l in [from, to) whose flag equals `want`, or 0xFFFFFFFF.  One 64-bit mask word per lane per step.
@@ -164,29 +241,39 @@ __global__ __launch_bounds__(64) void k_sym_scan(const float* __restrict__ tail,
         pos = f + q.R;
     }
     __syncthreads();
-    // per-run sums in element order (std::accumulate): the wave fetches 256 samples per step, v_readlane feeds a
-    // wave-uniform accumulator one sample at a time
+    // per-run sums in element order (std::accumulate): the wave fetches 256 samples per step (the next step's loads
+    // are issued before the current 256 are consumed), v_readlane feeds a wave-uniform accumulator one sample at a time
     for (uint32_t r = 0; r < nfl; ++r) {
         const uint32_t a = r ? flips[r - 1] : 0u, b = flips[r];
         float acc = 0.0f;
-        for (uint32_t k0 = a; k0 < b; k0 += 256) {
-            float x[4];
+        float nx[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t k = k0 + 64 * j + lane;
-                x[j] = k < b ? v[(st.base + k) & rmask] : 0.0f;
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t k = a + 64 * j + lane;
+            nx[j] = k < b ? v[(st.base + k) & rmask] : 0.0f;
+        }
+        for (uint32_t k0 = a; k0 < b; k0 += 256) {
+            int x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = __builtin_bit_cast(int, nx[j]);
+            if (k0 + 256 < b) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t k = k0 + 256 + 64 * j + lane;
+                    nx[j] = k < b ? v[(st.base + k) & rmask] : 0.0f;
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t c = k0 + 64 * j;
-                if (c >= b) break;
-                const uint32_t cnt = b - c;
-                const int xi = __builtin_bit_cast(int, x[j]);
-                if (cnt >= 64) {
+                if (c < b) {
+                    const uint32_t cnt = b - c;
+                    if (cnt >= 64) {
 #pragma unroll
-                    for (int i = 0; i < 64; ++i) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, i));
-                } else {
-                    for (uint32_t i = 0; i < cnt; ++i) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, (int)i));
+                        for (int i = 0; i < 64; ++i) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(x[j], i));
+                    } else {
+                        for (uint32_t i = 0; i < cnt; ++i) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(x[j], (int)i));
+                    }
                 }
             }
         }
@@ -227,8 +314,8 @@ void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t
                     const StreamCall* call, uint32_t* slots, uint32_t slot_words, uint32_t* flips_dbg, uint32_t flips_cap)
 {
     if (max_m) {
-        dim3 g2((max_new + kAvgLanes - 1) / kAvgLanes, n_streams);
-        const size_t lds = (size_t)(kAvgLanes + 2 * max_R) * sizeof(float);
+        dim3 g2((max_new + kAvgSpan - 1) / kAvgSpan, n_streams);
+        const size_t lds = (size_t)(kAvgSpan + 2 * max_R + 16) * sizeof(float);
         hipLaunchKernelGGL(k_sym_avg, g2, dim3(kAvgLanes), lds, st, tail, ring_cap, sym, flipmask, weight, sp, call);
     }
     hipLaunchKernelGGL(k_sym_scan, dim3(n_streams), dim3(64), 0, st, tail, ring_cap, sym, flipmask, weight, sp, call, slots,

@@ -26,6 +26,7 @@ class EngineConfig:
     enable_spectrum: bool = True
     ungated: bool = False
     keep_filtered: bool = False
+    pipeline: bool = False
     device: int = 0
 
 
@@ -40,6 +41,7 @@ class Engine:
                   "lowpass_bw_hz", "lowpass_trans", "lookup_mode"):
             setattr(c, k, getattr(cfg, k))
         c.dc_remove, c.enable_spectrum, c.ungated, c.keep_filtered = int(cfg.dc_remove), int(cfg.enable_spectrum), int(cfg.ungated), int(cfg.keep_filtered)
+        c.pipeline = int(cfg.pipeline)
         h = C.c_void_p()
         check(L.hd_engine_create(C.byref(c), C.byref(h)))
         self.h, self.L = h, L
@@ -69,6 +71,9 @@ class Engine:
 
     def process_device(self, dev_ptr: int, stride: int, n: int):
         check(self.L.hd_process_device(self.h, dev_ptr, stride, None, n))
+
+    def flush(self):
+        check(self.L.hd_flush(self.h))
 
     # ---- control
     def set_baud(self, s, baud): check(self.L.hd_stream_set_baud(self.h, s, baud))
@@ -135,4 +140,5 @@ class Engine:
     def timing(self) -> dict:
         t = capi.hd_timing()
         check(self.L.hd_engine_timing(self.h, C.byref(t)))
-        return {"ms_total": t.ms_total, "ms_front": t.ms_front, "front_bytes": t.front_bytes, "samples": t.samples}
+        return {"ms_total": t.ms_total, "ms_front": t.ms_front, "front_bytes": t.front_bytes, "samples": t.samples,
+                "host_enqueue_us": t.host_enqueue_us, "host_wait_us": t.host_wait_us, "host_text_us": t.host_text_us}

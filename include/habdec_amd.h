@@ -65,6 +65,10 @@ typedef struct hd_engine_config {
      * (Decoder.h:522-527).  1 = stage-level mode: FIR/demod/symbols run at any rate (BASELINE config 3). */
     int32_t  ungated;
     int32_t  keep_filtered;     /* 1 = also store the FIR output so hd_stream_filtered() works (parity tests) */
+    /* 0 = hd_process_* returns after THIS call's text has been delivered (what Decoder::operator() does).
+     * 1 = pipelined batch mode: a call enqueues its GPU work and delivers the PREVIOUS call's text, so the host
+     *     text stage and the next call's decimation overlap the current call's symbol kernels; hd_flush() drains. */
+    int32_t  pipeline;
 } hd_engine_config;
 
 /* Fill `cfg` with the reference defaults (dec 64, 300 baud 8N2, low-pass 1500 Hz / 0.025, spectrum on). */
@@ -104,6 +108,9 @@ int hd_process_host(hd_engine* e, const float* iq, size_t stream_stride, const u
 /* Same, but `d_iq` is DEVICE memory on the engine's GPU (HBM-resident batches; base 16-byte aligned,
  * stream_stride even). */
 int hd_process_device(hd_engine* e, const void* d_iq, size_t stream_stride, const uint32_t* n_per_stream, uint32_t n);
+/* Pipelined mode: wait for the call in flight and deliver its results (no-op otherwise).  Getters that read
+ * device buffers flush implicitly. */
+int hd_flush(hd_engine* e);
 
 /* ---- results: getRTTY / getLastSentence (Decoder.h:641-652) and the callback streams ---- */
 size_t hd_stream_rtty(hd_engine* e, uint32_t stream, char* buf, size_t cap);
@@ -140,6 +147,10 @@ typedef struct hd_timing {
     double ms_front;        /* of its first-stage decimation kernel (the only kernel that touches full-rate IQ) */
     uint64_t front_bytes;   /* algorithmic bytes of that launch: 8 B per input sample + 8 B per output sample */
     uint64_t samples;       /* input samples consumed by the last call over all streams */
+    /* host side of the most recent hd_process_* call, microseconds */
+    double host_enqueue_us; /* size bookkeeping + uploads + kernel launches */
+    double host_wait_us;    /* blocked on the GPU for the results being delivered */
+    double host_text_us;    /* AFC state machines, RTTY framing, sentence scan, callbacks */
 } hd_timing;
 int hd_engine_timing(hd_engine* e, hd_timing* out);
 /* 1 = bracket kernels with HIP events on every call (default 1; tiny overhead) */

@@ -307,3 +307,34 @@ def test_full_size_batch_properties(hd):
     for s in (0, 1, 255, 256, 1000, 1023):
         assert eng.take_chars(s) == want
     assert eng.sentences_ok() == S * len(o.sentences())
+
+
+def test_pipelined_mode_delivers_identical_text(hd):
+    """pipeline=1: a call returns the PREVIOUS call's text while its own symbol kernels overlap the next call's
+    decimation on a second HIP stream; after hd_flush() everything must equal the synchronous result and the oracle."""
+    torch = pytest.importorskip("torch")
+    import habdec_amd
+    from oracle import pyoracle
+    S, fs = 64, 2.048e6
+    iq, _ = make_streams(S, fs, 300, 8, 2, seed0=4000, repeat=2)
+    dev = torch.from_numpy(iq.view(np.float32)).cuda()
+    nch = iq.shape[1] // C
+    engs = {p: habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=64, pipeline=p) for p in (False, True)}
+    seen = {False: [], True: []}
+    for p, eng in engs.items():
+        eng.on_sentence(lambda s, call, data, crc, p=p: seen[p].append((s, f"{call},{data}*{crc}")))
+        for k in range(nch):
+            eng.process_device(dev.data_ptr() + k * C * 8, iq.shape[1], C)
+        eng.flush()
+    orcs = [pyoracle.Decoder("oracle", factor=64) for _ in range(4)]
+    for s, o in enumerate(orcs):
+        for k in range(nch):
+            o(iq[s, k * C:(k + 1) * C], fs)
+    assert seen[True] == seen[False] and len(seen[True]) >= 2 * S
+    for s in range(S):
+        assert engs[True].take_chars(s) == engs[False].take_chars(s)
+        assert engs[True].rtty(s) == engs[False].rtty(s)
+        assert same_bits(engs[True].demodulated(s), engs[False].demodulated(s))
+        assert engs[True].symbol_backlog(s) == engs[False].symbol_backlog(s)
+    for s, o in enumerate(orcs):
+        assert [x for (ss, x) in seen[True] if ss == s] == o.sentences()
