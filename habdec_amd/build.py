@@ -42,7 +42,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     objs = []
     build_dir = HERE / "build"
     build_dir.mkdir(exist_ok=True)
-    common = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+    extra = os.environ.get("HD_EXTRA_FLAGS", "").split()
+    common = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", *extra,
               "-Wall", "-Wno-unused-function", "-I", str(HERE.parent / "include"), "-I", str(CSRC)]
     procs = []
     for src in SOURCES:

@@ -327,10 +327,10 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         if (e->stages.size() >= 1)
             hd::launch_decimate(q, e->stages[0].ratio, T1, S, 1, e->staging.p, cfg->max_chunk, e->hist1[0].p, e->hist1[1].p, e->stage_taps[0].p,
                                 e->stages.size() == 1 ? e->fbuf[0].p : e->dec1.p, e->stages.size() == 1 ? e->fbuf_stride : e->n1_cap, sl.d_call.p, 0,
-                                e->stages.size() == 1, e->fir_hist_cap);
+                                e->stages.size() == 1, e->fir_hist_cap, nullptr);
         if (e->stages.size() == 2)
             hd::launch_decimate(q, e->stages[1].ratio, T2, S, 1, e->dec1.p, e->n1_cap, e->hist2[0].p, e->hist2[1].p, e->stage_taps[1].p, e->fbuf[0].p,
-                                e->fbuf_stride, sl.d_call.p, 1, 1, e->fir_hist_cap);
+                                e->fbuf_stride, sl.d_call.p, 1, 1, e->fir_hist_cap, nullptr);
         hd::launch_dc_remove(q, S, e->fbuf[0].p, e->fbuf_stride, sl.d_call.p, e->fir_hist_cap);
         if (cfg->enable_spectrum) {
             hd::launch_fft_feed(q, S, e->fbuf[0].p, e->fbuf_stride, e->fft_in.p, sl.d_call.p, e->fir_hist_cap);
@@ -655,21 +655,23 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         const size_t out1_stride = single ? e->fbuf_stride : e->n1_cap;
         if (e->timing_on) HD_HIP(hipEventRecord(sl.t1, qa));
         const int hin = e->hist_cur, hout = e->hist_cur ^ 1;
+        // spectrum collection rides in the final stage's epilogue unless the DC blocker must see the samples first
+        float2* feed = (e->cfg.enable_spectrum && !any_dc) ? e->fft_in.p : nullptr;
         if (!hd::launch_decimate(qa, R1, T1, S, max_n1, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
-                                 dcall, 0, single ? 1 : 0, e->fir_hist_cap))
+                                 dcall, 0, single ? 1 : 0, e->fir_hist_cap, single ? feed : nullptr))
             return fail(HD_ERR_INVALID, "no kernel for this decimation stage");
         if (e->timing_on) HD_HIP(hipEventRecord(sl.t2, qa));
         if (!single) {
             if (!hd::launch_decimate(qa, R2, T2, S, max_n2, e->dec1.p, e->n1_cap, e->hist2[hin].p, e->hist2[hout].p, e->stage_taps[1].p, fcur,
-                                     e->fbuf_stride, dcall, 1, 1, e->fir_hist_cap))
+                                     e->fbuf_stride, dcall, 1, 1, e->fir_hist_cap, feed))
                 return fail(HD_ERR_INVALID, "no kernel for this decimation stage");
         }
     }
     mark();
     if (any_dc) hd::launch_dc_remove(qa, S, fcur, e->fbuf_stride, dcall, e->fir_hist_cap);
     if (e->cfg.enable_spectrum && max_n2) {
-        hd::launch_fft_feed(qa, S, fcur, e->fbuf_stride, e->fft_in.p, dcall, e->fir_hist_cap);
-        if (any_fft) {
+        if (any_dc || nst == 0) hd::launch_fft_feed(qa, S, fcur, e->fbuf_stride, e->fft_in.p, dcall, e->fir_hist_cap);
+        if (any_fft) {   // only when some stream's 4096-sample buffer completed (every call at >= 4096 decimated samples per push)
             void* in[1] = {e->fft_in.p};
             void* outb[1] = {e->fft_raw.p};
             if (rocfft_execute(e->fft_plan, in, outb, e->fft_info) != rocfft_status_success) return fail(HD_ERR_DEVICE, "rocfft_execute failed");

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                    const float* __restrict__ taps,
                                                    float2* __restrict__ out, size_t out_stride,
                                                    const StreamCall* __restrict__ call, int stage, int final_stage,
-                                                   uint32_t fir_hist_cap, uint32_t tiles_per_wg)
+                                                   uint32_t fir_hist_cap, uint32_t tiles_per_wg, float2* __restrict__ fft_in)
 {
     constexpr int JS = (T - 1) & 1;                // LDS slot jj = j + JS for tile-local sample j
     constexpr int NJ = (TO - 1) * D + T;           // samples a tile needs
@@ -158,6 +158,8 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         const uint32_t o = tile_i * TO + threadIdx.x;
         if (o < nout) out_s[o] = make_float2(ar, ai);
+        // spectrum input collection (reference Decoder.h:467-473): the HEAD of this call's decimated chunk
+        if (fft_in && o < c.fft_take) fft_in[(size_t)s * kFftBins + c.fft_fill + o] = make_float2(ar, ai);
         ytile[threadIdx.x] = make_float2(ar, ai);
         __syncthreads();                                    // everyone is done with this tile's LDS image
     }
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(64) void k_dc_remove(float2* __restrict__ fbuf, siz
 template <int D, int T, int TO>
 static void launch_one(hipStream_t st, uint32_t n_streams, uint32_t max_out, const float2* in, size_t in_stride,
                        const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride,
-                       const StreamCall* call, int stage, int final_stage, uint32_t fir_hist_cap)
+                       const StreamCall* call, int stage, int final_stage, uint32_t fir_hist_cap, float2* fft_in)
 {
     const uint32_t ntiles = (max_out + TO - 1) / TO;
     // Walk several tiles per workgroup (prefetch pipelining) once there are enough workgroups to fill the chip:
@@ -226,18 +228,18 @@ static void launch_one(hipStream_t st, uint32_t n_streams, uint32_t max_out, con
     while (per < 16 && (uint64_t)((ntiles + 2 * per - 1) / (2 * per)) * n_streams >= 2048) per *= 2;
     dim3 grid((ntiles + per - 1) / per, n_streams);
     hipLaunchKernelGGL((k_decimate<D, T, TO>), grid, dim3(TO), 0, st, in, in_stride, hist_in, hist_out, taps, out, out_stride, call,
-                       stage, final_stage, fir_hist_cap, per);
+                       stage, final_stage, fir_hist_cap, per, fft_in);
 }
 
 bool launch_decimate(hipStream_t st, int ratio, int ntaps, uint32_t n_streams, uint32_t max_out, const float2* in, size_t in_stride,
                      const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
-                     int stage, int final_stage, uint32_t fir_hist_cap)
+                     int stage, int final_stage, uint32_t fir_hist_cap, float2* fft_in)
 {
     if (!max_out) return true;
 #define HD_CASE(D, T, TO) \
-    if (ratio == D && ntaps == T) { launch_one<D, T, TO>(st, n_streams, max_out, in, in_stride, hist_in, hist_out, taps, out, out_stride, call, stage, final_stage, fir_hist_cap); return true; }
+    if (ratio == D && ntaps == T) { launch_one<D, T, TO>(st, n_streams, max_out, in, in_stride, hist_in, hist_out, taps, out, out_stride, call, stage, final_stage, fir_hist_cap, fft_in); return true; }
     HD_CASE(2, 69, 256) HD_CASE(4, 139, 256) HD_CASE(8, 280, 256) HD_CASE(8, 54, 256)
-    HD_CASE(16, 107, 128) HD_CASE(32, 212, 128) HD_CASE(32, 174, 128) HD_CASE(64, 348, 64)
+    HD_CASE(16, 107, 128) HD_CASE(32, 212, 64) HD_CASE(32, 174, 64) HD_CASE(64, 348, 64)
 #undef HD_CASE
     return false;
 }

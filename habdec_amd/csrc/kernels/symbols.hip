@@ -25,7 +25,7 @@
 namespace hd {
 
 constexpr int kAvgLanes = 256;
-constexpr uint32_t kMaxFlipsPerCall = 2048;   // LDS flip list of the scan kernel (overflow is flagged)
+constexpr uint32_t kMaxFlipsPerCall = 1024;   // LDS flip list of the scan kernel (overflow is flagged)
 
 __device__ __forceinline__ int sgnf(float v) { return (0.0f < v) - (v < 0.0f); }
 
@@ -84,97 +84,37 @@ __device__ __forceinline__ void window_sums(const float* __restrict__ w, uint32_
     }
 }
 
-__global__ __launch_bounds__(kAvgLanes) void k_sym_avg(const float* __restrict__ tail, uint32_t ring_cap,
-                                                        const SymState* __restrict__ sym, unsigned long long* __restrict__ flipmask,
-                                                        float* __restrict__ weight, const SymbolParams* __restrict__ sp,
-                                                        const StreamCall* __restrict__ call)
-{
-    extern __shared__ __attribute__((aligned(16))) float win[];   // tail[c0 - R, c0 + span + R + pad)
-    __shared__ unsigned long long words[kAvgSpan / 64];
-    const uint32_t s = blockIdx.y;
-    const uint32_t m = call[s].fir_m;
-    if (!m) return;
-    const SymbolParams q = sp[s];
-    const SymState st = state_after_push(sym[s], q, m);
-    const uint32_t h = st.held;
-    if (h < q.min_held || h < q.spb) return;
-    const uint32_t R = q.R, rmask = ring_cap - 1;
-    const uint32_t end = st.base + h;
-    const uint32_t pend = end - R + 1;                     // first position whose right window is still incomplete
-    const uint32_t c0 = (st.cached & ~63u) + blockIdx.x * kAvgSpan;   // mask words are written whole: start 64-aligned
-    if ((int32_t)(pend - c0) <= 0) return;
-    const float* v = tail + (size_t)s * ring_cap;
-    const uint32_t w0 = c0 - R;
-    const uint32_t wn = kAvgSpan + 2 * R + 8;
-    for (uint32_t k = threadIdx.x; k < wn; k += kAvgLanes) win[k] = v[(w0 + k) & rmask];
-    if (threadIdx.x < kAvgSpan / 64) words[threadIdx.x] = 0ull;
-    __syncthreads();
-    const uint32_t p0 = c0 + threadIdx.x * kAvgPos;        // this lane's first position; its left window starts at win[4*lane]
-    float sl[kAvgPos], sr[kAvgPos];
-    window_sums(win + threadIdx.x * kAvgPos, R, sl);
-    // right windows start R samples later; R is not a multiple of 4 in general, so realign through a 4-float shift
-    {
-        const uint32_t off = threadIdx.x * kAvgPos + R;    // win index of position p0
-        const uint32_t al = off & ~3u, sh = off & 3u;      // aligned start, residual shift
-        // accumulator j sums win[off + j .. off + j + R) = aligned[sh + j .. sh + j + R)
-        const float* w = win + al;
-#pragma unroll
-        for (int j = 0; j < kAvgPos; ++j) sr[j] = 0.0f;
-        const uint32_t total = sh + R + kAvgPos - 1;
-        for (uint32_t e = 0; e < total; e += 4) {
-            const float4 x = *reinterpret_cast<const float4*>(w + e);
-            const float xs[4] = {x.x, x.y, x.z, x.w};
-            const bool interior = e >= sh + kAvgPos - 1 && e + 4 <= sh + R;
-            if (interior) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int j = 0; j < kAvgPos; ++j) sr[j] = sr[j] + xs[u];
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int j = 0; j < kAvgPos; ++j)
-                        if (e + u >= sh + (uint32_t)j && e + u < sh + (uint32_t)j + R) sr[j] = sr[j] + xs[u];
-            }
-        }
-    }
-    unsigned int bits = 0;
-#pragma unroll
-    for (int j = 0; j < kAvgPos; ++j) {
-        const uint32_t p = p0 + j;
-        if ((int32_t)(pend - p) > 0) {
-            const float al = sl[j] / (float)R, ar = sr[j] / (float)R;   // no clamping: p >= base+R is all the search reads, p+R <= end
-            if (sgnf(al) != sgnf(ar)) bits |= 1u << j;
-            const float d = ar - al;
-            weight[(size_t)s * ring_cap + (p & rmask)] = q.float_abs ? __builtin_fabsf(d) : (float)abs((int)d);
-        }
-    }
-    // lane l owns bits [4l, 4l+4) of the workgroup's 1024-position span: 16 lanes per 64-bit word
-    if (bits) atomicOr(&words[threadIdx.x >> 4], (unsigned long long)bits << ((threadIdx.x & 15) * 4));
-    __syncthreads();
-    if (threadIdx.x < kAvgSpan / 64)
-        flipmask[(size_t)s * (ring_cap / 64) + (((c0 + threadIdx.x * 64) & rmask) >> 6)] = words[threadIdx.x];
-}
+// ---------------------------------------------------------------------------------------------------------------------
+// One workgroup (4 waves) per stream does the whole symbol stage of a call:
+//   A. window sums for the positions that became computable (4 positions per lane, 1024 per sweep) -> weights (global ring,
+//      they are needed again by later calls) and sign-difference mask words (global ring + an LDS image of every mask word
+//      the edge search can touch, so the search never waits on HBM/L2);
+//   B. wave 0: edge search on the LDS mask image (4096 positions per step);
+//   C. runs are dealt round-robin to the 4 waves; each wave sums its run in element order: 256 samples at a time go
+//      global -> registers -> a private LDS strip, then wave-uniform (broadcast) 16-byte LDS reads feed one v_add per
+//      sample while the next 256 are already in flight;
+//   D. lane 0 packs the bits, advances the ring base (the reference's erase) and writes the result slot.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kSymLanes = 256;
+constexpr uint32_t kRunStrip = 256;                       // samples per run-sum step
 
-// First backlog index l in [from, to) whose flag equals `want`, or 0xFFFFFFFF.  One 64-bit mask word per lane per step.
-__device__ __forceinline__ uint32_t find_flag(const unsigned long long* __restrict__ masks, uint32_t base, uint32_t rmask,
-                                              uint32_t from, uint32_t to, bool want)
+__device__ __forceinline__ uint32_t find_flag_lds(const unsigned long long* lmask, uint32_t base, uint32_t rmask,
+                                                  uint32_t from, uint32_t to, bool want)
 {
-    const uint32_t lane = threadIdx.x;
-    const uint32_t wr0 = (base + from) & ~63u;             // ring position of the first word
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wr0 = (base + from) & ~63u;
     for (uint32_t it = 0;; ++it) {
         const uint32_t wstart = wr0 + it * 4096u;
         if ((int32_t)(wstart - base) >= (int32_t)to) break;
         const uint32_t wr = wstart + lane * 64u;
-        const int32_t lw = (int32_t)(wr - base);           // backlog index of this word's bit 0 (may be < from)
+        const int32_t lw = (int32_t)(wr - base);
         unsigned long long w = 0;
         if (lw < (int32_t)to) {
-            w = masks[(wr & rmask) >> 6];
+            w = lmask[(wr & rmask) >> 6];
             if (!want) w = ~w;
-            const int32_t lo = (int32_t)from - lw;         // keep bits >= lo
+            const int32_t lo = (int32_t)from - lw;
             if (lo > 0) w = lo >= 64 ? 0ull : (w & (~0ull << lo));
-            const int32_t hi = (int32_t)to - lw;           // keep bits < hi
+            const int32_t hi = (int32_t)to - lw;
             if (hi < 64) w &= (1ull << hi) - 1ull;
         }
         const unsigned long long hit = __ballot(w != 0ull);
@@ -187,63 +127,147 @@ __device__ __forceinline__ uint32_t find_flag(const unsigned long long* __restri
     return 0xFFFFFFFFu;
 }
 
-__global__ __launch_bounds__(64) void k_sym_scan(const float* __restrict__ tail, uint32_t ring_cap, SymState* __restrict__ sym,
-                                                   const unsigned long long* __restrict__ flipmask, const float* __restrict__ weight,
-                                                   const SymbolParams* __restrict__ sp, const StreamCall* __restrict__ call,
-                                                   uint32_t* __restrict__ slots, uint32_t slot_words,
-                                                   uint32_t* __restrict__ flips_dbg, uint32_t flips_cap)
+__global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__ tail, uint32_t ring_cap, SymState* __restrict__ sym,
+                                                        unsigned long long* __restrict__ flipmask, float* __restrict__ weight,
+                                                        const SymbolParams* __restrict__ sp, const StreamCall* __restrict__ call,
+                                                        uint32_t* __restrict__ slots, uint32_t slot_words,
+                                                        uint32_t* __restrict__ flips_dbg, uint32_t flips_cap)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // carve: [lmask: ring_cap/64 u64][win: kAvgSpan + 2*R + 16 floats][strips: 4 waves x 2 x kRunStrip floats]
+    unsigned long long* lmask = reinterpret_cast<unsigned long long*>(smem);
+    __shared__ unsigned long long words[kAvgSpan / 64];
     __shared__ uint32_t flips[kMaxFlipsPerCall];
     __shared__ uint32_t runinfo[kMaxFlipsPerCall];          // (count << 1) | bit
+    __shared__ uint32_t s_nfl, s_overflow;
     const uint32_t s = blockIdx.x;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t* slot = slots + (size_t)s * slot_words;
     BitsHeader* hdr = reinterpret_cast<BitsHeader*>(slot);
-    uint32_t* words = slot + sizeof(BitsHeader) / 4;
+    uint32_t* outw = slot + sizeof(BitsHeader) / 4;
     const uint32_t cap_bits = (slot_words - sizeof(BitsHeader) / 4) * 32;
     const uint32_t m = call[s].fir_m;
     const SymState old = sym[s];
     if (!m) {                                               // symbol stage not reached this call
-        if (lane == 0) { hdr->nbits = 0; hdr->held_after = old.held; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = old.base + old.held - old.cached; }
+        if (tid == 0) { hdr->nbits = 0; hdr->held_after = old.held; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = old.base + old.held - old.cached; }
         return;
     }
     const SymbolParams q = sp[s];
     SymState st = state_after_push(old, q, m);
     const uint32_t h = st.held;
     if (h < q.min_held || h < q.spb) {
-        if (lane == 0) { sym[s] = st; hdr->nbits = 0; hdr->held_after = h; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = st.base + h - st.cached; }
+        if (tid == 0) { sym[s] = st; hdr->nbits = 0; hdr->held_after = h; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = st.base + h - st.cached; }
         return;
     }
-    const uint32_t rmask = ring_cap - 1;
+    const uint32_t R = q.R, rmask = ring_cap - 1;
+    float* win = reinterpret_cast<float*>(lmask + ring_cap / 64);
+    float* strips = win + ((kAvgSpan + 2 * R + 16 + 3) & ~3u);
     const float* v = tail + (size_t)s * ring_cap;
-    const unsigned long long* masks = flipmask + (size_t)s * (ring_cap / 64);
-    const float* wgt = weight + (size_t)s * ring_cap;
+    unsigned long long* gmask = flipmask + (size_t)s * (ring_cap / 64);
+    float* gw = weight + (size_t)s * ring_cap;
+    const uint32_t end = st.base + h;
+    const uint32_t pend = end - R + 1;                      // first position whose right window is still incomplete
     const uint32_t limit = h - q.spb;                       // backlog indices searched: [R, limit)
-    uint32_t pos = q.R, nfl = 0, overflow = 0;
-    while (pos < limit) {
-        const uint32_t lo = find_flag(masks, st.base, rmask, pos, limit, true);
-        if (lo == 0xFFFFFFFFu) break;
-        const uint32_t hi = find_flag(masks, st.base, rmask, lo + 1, limit, false);
-        if (hi == 0xFFFFFFFFu) break;
-        float bw = -1.0f;                                   // first maximum of the weight over [lo, hi)
-        uint32_t bi = 0xFFFFFFFFu;
-        for (uint32_t i = lo + lane; i < hi; i += 64) {
-            const float w = wgt[(st.base + i) & rmask];
-            if (bi == 0xFFFFFFFFu || w > bw) { bw = w; bi = i; }
+
+    // ---- A0: LDS image of the cached mask words the search can touch
+    {
+        const uint32_t wr0 = (st.base + R) & ~63u;                     // ring position of the first word
+        const uint32_t nw = ((st.base + limit) - wr0 + 63u) >> 6;      // modular difference: safe across the 2^32 wrap
+        for (uint32_t i = tid; i < nw; i += kSymLanes) {
+            const uint32_t wi = ((wr0 + 64u * i) & rmask) >> 6;
+            lmask[wi] = gmask[wi];
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ow = __shfl_down(bw, off, 64);
-            const uint32_t oi = __shfl_down(bi, off, 64);
-            if (oi != 0xFFFFFFFFu && (bi == 0xFFFFFFFFu || ow > bw || (ow == bw && oi < bi))) { bw = ow; bi = oi; }
+    }
+    // ---- A1: window sums for the new positions, one sweep of kAvgSpan positions at a time
+    for (uint32_t c0 = st.cached & ~63u; (int32_t)(pend - c0) > 0; c0 += kAvgSpan) {
+        __syncthreads();                                    // previous sweep's `win`/`words` consumers are done; A0 stores ordered
+        const uint32_t w0 = c0 - R;
+        const uint32_t wn = kAvgSpan + 2 * R + 8;
+        for (uint32_t k = tid; k < wn; k += kSymLanes) win[k] = v[(w0 + k) & rmask];
+        if (tid < kAvgSpan / 64) words[tid] = 0ull;
+        __syncthreads();
+        const uint32_t p0 = c0 + tid * kAvgPos;
+        if ((int32_t)(pend - p0) > 0) {
+            float sl[kAvgPos], sr[kAvgPos];
+            window_sums(win + tid * kAvgPos, R, sl);
+            {   // right windows start R samples later; R is not a multiple of 4 in general: realign through a residual shift
+                const uint32_t off = tid * kAvgPos + R;
+                const uint32_t al = off & ~3u, sh = off & 3u;
+                const float* w = win + al;
+#pragma unroll
+                for (int j = 0; j < kAvgPos; ++j) sr[j] = 0.0f;
+                const uint32_t total = sh + R + kAvgPos - 1;
+                for (uint32_t e = 0; e < total; e += 4) {
+                    const float4 x = *reinterpret_cast<const float4*>(w + e);
+                    const float xs[4] = {x.x, x.y, x.z, x.w};
+                    if (e >= sh + kAvgPos - 1 && e + 4 <= sh + R) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int j = 0; j < kAvgPos; ++j) sr[j] = sr[j] + xs[u];
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int j = 0; j < kAvgPos; ++j)
+                                if (e + u >= sh + (uint32_t)j && e + u < sh + (uint32_t)j + R) sr[j] = sr[j] + xs[u];
+                    }
+                }
+            }
+            unsigned int bits = 0;
+#pragma unroll
+            for (int j = 0; j < kAvgPos; ++j) {
+                const uint32_t p = p0 + j;
+                if ((int32_t)(pend - p) > 0) {
+                    const float al = sl[j] / (float)R, ar = sr[j] / (float)R;   // no clamping: p >= base+R is all the search reads, p+R <= end
+                    if (sgnf(al) != sgnf(ar)) bits |= 1u << j;
+                    const float d = ar - al;
+                    gw[p & rmask] = q.float_abs ? __builtin_fabsf(d) : (float)abs((int)d);
+                }
+            }
+            if (bits) atomicOr(&words[tid >> 4], (unsigned long long)bits << ((tid & 15) * 4));
         }
-        const uint32_t f = __shfl(bi, 0, 64);
-        if (nfl < kMaxFlipsPerCall) { if (lane == 0) flips[nfl] = f; ++nfl; } else { overflow = 1; break; }
-        pos = f + q.R;
+        __syncthreads();
+        if (tid < kAvgSpan / 64 && (int32_t)(pend - (c0 + tid * 64)) > 0) {
+            const uint32_t wi = ((c0 + tid * 64) & rmask) >> 6;
+            gmask[wi] = words[tid];
+            lmask[wi] = words[tid];
+        }
+    }
+    __threadfence_block();                                  // this call's weights (global) are read back by wave 0 below
+    __syncthreads();
+
+    // ---- B: edge search (wave 0)
+    if (wave == 0) {
+        uint32_t pos = R, nfl = 0, overflow = 0;
+        while (pos < limit) {
+            const uint32_t lo = find_flag_lds(lmask, st.base, rmask, pos, limit, true);
+            if (lo == 0xFFFFFFFFu) break;
+            const uint32_t hi = find_flag_lds(lmask, st.base, rmask, lo + 1, limit, false);
+            if (hi == 0xFFFFFFFFu) break;
+            float bw = -1.0f;                               // first maximum of the weight over [lo, hi)
+            uint32_t bi = 0xFFFFFFFFu;
+            for (uint32_t i = lo + lane; i < hi; i += 64) {
+                const float w = gw[(st.base + i) & rmask];
+                if (bi == 0xFFFFFFFFu || w > bw) { bw = w; bi = i; }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ow = __shfl_down(bw, off, 64);
+                const uint32_t oi = __shfl_down(bi, off, 64);
+                if (oi != 0xFFFFFFFFu && (bi == 0xFFFFFFFFu || ow > bw || (ow == bw && oi < bi))) { bw = ow; bi = oi; }
+            }
+            const uint32_t f = __shfl(bi, 0, 64);
+            if (nfl < kMaxFlipsPerCall) { if (lane == 0) flips[nfl] = f; ++nfl; } else { overflow = 1; break; }
+            pos = f + R;
+        }
+        if (lane == 0) { s_nfl = nfl; s_overflow = overflow; }
     }
     __syncthreads();
-    // per-run sums in element order (std::accumulate): the wave fetches 256 samples per step (the next step's loads
-    // are issued before the current 256 are consumed), v_readlane feeds a wave-uniform accumulator one sample at a time
-    for (uint32_t r = 0; r < nfl; ++r) {
+    const uint32_t nfl = s_nfl;
+
+    // ---- C: per-run sums in element order (std::accumulate), runs dealt round-robin to the waves
+    float* strip = strips + wave * (2 * kRunStrip);
+    for (uint32_t r = wave; r < nfl; r += kSymLanes / 64) {
         const uint32_t a = r ? flips[r - 1] : 0u, b = flips[r];
         float acc = 0.0f;
         float nx[4];
@@ -252,30 +276,31 @@ __global__ __launch_bounds__(64) void k_sym_scan(const float* __restrict__ tail,
             const uint32_t k = a + 64 * j + lane;
             nx[j] = k < b ? v[(st.base + k) & rmask] : 0.0f;
         }
-        for (uint32_t k0 = a; k0 < b; k0 += 256) {
-            int x[4];
+        uint32_t par = 0;
+        for (uint32_t k0 = a; k0 < b; k0 += kRunStrip, par ^= 1u) {
+            float* sb = strip + par * kRunStrip;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = __builtin_bit_cast(int, nx[j]);
-            if (k0 + 256 < b) {
+            for (int j = 0; j < 4; ++j) sb[64 * j + lane] = nx[j];
+            if (k0 + kRunStrip < b) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const uint32_t k = k0 + 256 + 64 * j + lane;
+                    const uint32_t k = k0 + kRunStrip + 64 * j + lane;
                     nx[j] = k < b ? v[(st.base + k) & rmask] : 0.0f;
                 }
             }
+            __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): this wave's strip writes have landed (wave-private strip)
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t cnt = min(kRunStrip, b - k0);
+            const float4* s4 = reinterpret_cast<const float4*>(sb);
+            uint32_t i = 0;
+            for (; i + 16 <= cnt; i += 16) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t c = k0 + 64 * j;
-                if (c < b) {
-                    const uint32_t cnt = b - c;
-                    if (cnt >= 64) {
-#pragma unroll
-                        for (int i = 0; i < 64; ++i) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(x[j], i));
-                    } else {
-                        for (uint32_t i = 0; i < cnt; ++i) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(x[j], (int)i));
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    const float4 x = s4[(i >> 2) + u];      // wave-uniform address: one broadcast LDS read feeds four adds
+                    acc = acc + x.x; acc = acc + x.y; acc = acc + x.z; acc = acc + x.w;
                 }
             }
+            for (; i < cnt; ++i) acc = acc + sb[i];
         }
         if (lane == 0) {
             const float mean = acc / (float)(b - a);
@@ -284,24 +309,24 @@ __global__ __launch_bounds__(64) void k_sym_scan(const float* __restrict__ tail,
         }
     }
     __syncthreads();
-    if (lane == 0) {
-        uint32_t nbits = 0, cur = 0;
+
+    // ---- D: bits, ring advance, result slot
+    if (tid == 0) {
+        uint32_t nbits = 0, cur = 0, overflow = s_overflow;
         for (uint32_t r = 0; r < nfl; ++r) {
             const uint32_t bit = runinfo[r] & 1u;
             for (uint32_t k = runinfo[r] >> 1; k; --k) {
                 if (nbits >= cap_bits) { overflow = 1; break; }
                 cur |= bit << (nbits & 31);
-                if ((nbits & 31) == 31) { words[nbits >> 5] = cur; cur = 0; }
+                if ((nbits & 31) == 31) { outw[nbits >> 5] = cur; cur = 0; }
                 ++nbits;
             }
         }
-        if (nbits & 31) words[nbits >> 5] = cur;
+        if (nbits & 31) outw[nbits >> 5] = cur;
         if (flips_dbg)
             for (uint32_t r = 0; r < nfl && r < flips_cap; ++r) flips_dbg[(size_t)s * flips_cap + r] = flips[r];
-        // erase the consumed prefix (SymbolExtractor.h:156-157) = advance the ring base
-        const uint32_t last = nfl ? flips[nfl - 1] : 0u;
-        const uint32_t end = st.base + h;
-        st.cached = end - q.R + 1;
+        const uint32_t last = nfl ? flips[nfl - 1] : 0u;   // erase the consumed prefix (SymbolExtractor.h:156-157) = advance the base
+        st.cached = pend;
         st.base += last;
         st.held = h - last;
         sym[s] = st;
@@ -313,12 +338,9 @@ void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t
                     uint32_t ring_cap, SymState* sym, unsigned long long* flipmask, float* weight, const SymbolParams* sp,
                     const StreamCall* call, uint32_t* slots, uint32_t slot_words, uint32_t* flips_dbg, uint32_t flips_cap)
 {
-    if (max_m) {
-        dim3 g2((max_new + kAvgSpan - 1) / kAvgSpan, n_streams);
-        const size_t lds = (size_t)(kAvgSpan + 2 * max_R + 16) * sizeof(float);
-        hipLaunchKernelGGL(k_sym_avg, g2, dim3(kAvgLanes), lds, st, tail, ring_cap, sym, flipmask, weight, sp, call);
-    }
-    hipLaunchKernelGGL(k_sym_scan, dim3(n_streams), dim3(64), 0, st, tail, ring_cap, sym, flipmask, weight, sp, call, slots,
+    (void)max_m; (void)max_new;
+    const size_t lds = (size_t)(ring_cap / 64) * 8 + (size_t)((kAvgSpan + 2 * max_R + 16 + 3) & ~3u) * 4 + (size_t)(kSymLanes / 64) * 2 * kRunStrip * 4;
+    hipLaunchKernelGGL(k_symbols, dim3(n_streams), dim3(kSymLanes), lds, st, tail, ring_cap, sym, flipmask, weight, sp, call, slots,
                        slot_words, flips_dbg, flips_cap);
 }
 
