@@ -44,8 +44,10 @@ struct SymbolParams {
 struct SymState {
     uint32_t base;          // position of backlog sample 0
     uint32_t held;          // backlog length (SymbolExtractor::samples_.size())
-    uint32_t cached;        // window flags / weights are final for every position p with base + R <= p < cached
-    uint32_t _pad;
+    uint32_t cached;        // window sums W(p) are final for every position p < cached (flags for base + R <= p < cached)
+    uint32_t run_pos;       // the current run's sequential sample sum is carried across calls: it covers [base, run_pos)
+    float    run_sum;       //   ... = v[base] + v[base+1] + ... + v[run_pos-1], accumulated left to right
+    uint32_t _pad[3];
 };
 
 // Header of a stream's result slot written by the symbol scan kernel, followed by packed bits.

@@ -32,7 +32,7 @@ __device__ __forceinline__ int sgnf(float v) { return (0.0f < v) - (v < 0.0f); }
 // State after this call's samples were appended (SymbolExtractor.h:116-124: the vent happens before the append).
 __device__ __forceinline__ SymState state_after_push(SymState st, const SymbolParams& q, uint32_t m)
 {
-    if (st.held > kVentLimit) { st.base += st.held; st.held = 0; st.cached = st.base; }
+    if (st.held > kVentLimit) { st.base += st.held; st.held = 0; st.cached = st.base; st.run_pos = st.base; st.run_sum = 0.0f; }
     if (q.reset) st.cached = st.base;
     st.held += m;
     return st;
@@ -45,56 +45,52 @@ __device__ __forceinline__ SymState state_after_push(SymState st, const SymbolPa
 constexpr int kAvgPos = 4;                                  // positions per lane
 constexpr int kAvgSpan = kAvgLanes * kAvgPos;               // positions per workgroup (1024)
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// acc[j] = w[j] + w[j+1] + ... + w[j+R-1] for j = 0..3, each in index order.  Interior samples feed all four sums:
+// two v_pk_add_f32 per sample.
 __device__ __forceinline__ void window_sums(const float* __restrict__ w, uint32_t R, float acc[kAvgPos])
 {
-    // accumulator j sums w[j .. j+R)
-#pragma unroll
-    for (int j = 0; j < kAvgPos; ++j) acc[j] = 0.0f;
+    f32x2 a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f};
     const uint32_t total = R + kAvgPos - 1;                 // samples touched: w[0 .. R+3)
-    uint32_t e = 0;
-    {   // head chunk: element e feeds accumulators j <= e
+    {   // head chunk: element u feeds accumulators j <= u (R >= 4 always)
         const float4 x = *reinterpret_cast<const float4*>(w);
-        const float xs[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int j = 0; j < kAvgPos; ++j)
-                if (j <= u && (uint32_t)u < (uint32_t)j + R) acc[j] = acc[j] + xs[u];
-        e = 4;
+        a01.x = a01.x + x.x;
+        a01 = a01 + (f32x2){x.y, x.y};
+        a01 = a01 + (f32x2){x.z, x.z}; a23.x = a23.x + x.z;
+        a01 = a01 + (f32x2){x.w, x.w}; a23 = a23 + (f32x2){x.w, x.w};
     }
+    uint32_t e = 4;
     for (; e + 4 <= R; e += 4) {                            // interior: every element feeds all four
         const float4 x = *reinterpret_cast<const float4*>(w + e);
-#pragma unroll
-        for (int j = 0; j < kAvgPos; ++j) acc[j] = acc[j] + x.x;
-#pragma unroll
-        for (int j = 0; j < kAvgPos; ++j) acc[j] = acc[j] + x.y;
-#pragma unroll
-        for (int j = 0; j < kAvgPos; ++j) acc[j] = acc[j] + x.z;
-#pragma unroll
-        for (int j = 0; j < kAvgPos; ++j) acc[j] = acc[j] + x.w;
+        a01 = a01 + (f32x2){x.x, x.x}; a23 = a23 + (f32x2){x.x, x.x};
+        a01 = a01 + (f32x2){x.y, x.y}; a23 = a23 + (f32x2){x.y, x.y};
+        a01 = a01 + (f32x2){x.z, x.z}; a23 = a23 + (f32x2){x.z, x.z};
+        a01 = a01 + (f32x2){x.w, x.w}; a23 = a23 + (f32x2){x.w, x.w};
     }
-    for (; e < total; e += 4) {                             // tail chunks: element e feeds accumulators with e < j + R
+    float acc0 = a01.x, acc1 = a01.y, acc2 = a23.x, acc3 = a23.y;
+    for (; e < total; e += 4) {                             // tail chunks: element e+u feeds accumulators with e+u < j + R
         const float4 x = *reinterpret_cast<const float4*>(w + e);
         const float xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int j = 0; j < kAvgPos; ++j)
-                if (e + u >= (uint32_t)j && e + u < (uint32_t)j + R) acc[j] = acc[j] + xs[u];
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = e + u;
+            if (i < R) acc0 = acc0 + xs[u];
+            if (i < 1 + R) acc1 = acc1 + xs[u];
+            if (i < 2 + R) acc2 = acc2 + xs[u];
+            if (i < 3 + R) acc3 = acc3 + xs[u];
+        }
     }
+    acc[0] = acc0; acc[1] = acc1; acc[2] = acc2; acc[3] = acc3;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// One workgroup (4 waves) per stream does the whole symbol stage of a call:
-//   A. window sums for the positions that became computable (4 positions per lane, 1024 per sweep) -> weights (global ring,
-//      they are needed again by later calls) and sign-difference mask words (global ring + an LDS image of every mask word
-//      the edge search can touch, so the search never waits on HBM/L2);
-//   B. wave 0: edge search on the LDS mask image (4096 positions per step);
-//   C. runs are dealt round-robin to the 4 waves; each wave sums its run in element order: 256 samples at a time go
-//      global -> registers -> a private LDS strip, then wave-uniform (broadcast) 16-byte LDS reads feed one v_add per
-//      sample while the next 256 are already in flight;
-//   D. lane 0 packs the bits, advances the ring base (the reference's erase) and writes the result slot.
-// ---------------------------------------------------------------------------------------------------------------------
+#ifdef HD_STAMP   // diagnostic build only: s_memtime at the phase boundaries of k_symbols, per stream
+__device__ unsigned long long g_sym_stamps[8192 * 8];
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_sym_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" void hd_debug_sym_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sym_stamps), n * 8); }
+#else
+#define STAMP(i) do { } while (0)
+#endif
 constexpr int kSymLanes = 256;
 constexpr uint32_t kRunStrip = 256;                       // samples per run-sum step
 
@@ -134,12 +130,13 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
                                                         uint32_t* __restrict__ flips_dbg, uint32_t flips_cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // carve: [lmask: ring_cap/64 u64][win: kAvgSpan + 2*R + 16 floats][strips: 4 waves x 2 x kRunStrip floats]
+    // carve: [lmask: ring_cap/64 u64][win: span + R + 16 floats][wl: span + R floats][strips: 4 waves x 2 x kRunStrip floats]
     unsigned long long* lmask = reinterpret_cast<unsigned long long*>(smem);
     __shared__ unsigned long long words[kAvgSpan / 64];
     __shared__ uint32_t flips[kMaxFlipsPerCall];
     __shared__ uint32_t runinfo[kMaxFlipsPerCall];          // (count << 1) | bit
-    __shared__ uint32_t s_nfl, s_overflow;
+    __shared__ uint32_t s_nfl, s_overflow, s_frontier;
+    __shared__ float s_carry;
     const uint32_t s = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t* slot = slots + (size_t)s * slot_words;
@@ -161,7 +158,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     }
     const uint32_t R = q.R, rmask = ring_cap - 1;
     float* win = reinterpret_cast<float*>(lmask + ring_cap / 64);
-    float* strips = win + ((kAvgSpan + 2 * R + 16 + 3) & ~3u);
+    float* strips = win + ((kAvgSpan + R + 16 + 3) & ~3u) + ((kAvgSpan + R + 3) & ~3u);
     const float* v = tail + (size_t)s * ring_cap;
     unsigned long long* gmask = flipmask + (size_t)s * (ring_cap / 64);
     float* gw = weight + (size_t)s * ring_cap;
@@ -169,6 +166,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     const uint32_t pend = end - R + 1;                      // first position whose right window is still incomplete
     const uint32_t limit = h - q.spb;                       // backlog indices searched: [R, limit)
 
+    STAMP(0);
     // ---- A0: LDS image of the cached mask words the search can touch
     {
         const uint32_t wr0 = (st.base + R) & ~63u;                     // ring position of the first word
@@ -178,51 +176,40 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
             lmask[wi] = gmask[wi];
         }
     }
-    // ---- A1: window sums for the new positions, one sweep of kAvgSpan positions at a time
+    STAMP(1);
+    // ---- A1: window sums for the new positions, one sweep of kAvgSpan positions at a time.
+    // W(p) = v[p] + ... + v[p+R-1] summed left to right is BOTH the reference's right window of p and its left window
+    // of p+R (same elements, same order, same rounding), so one sum per position is computed and cached (ring `wsum`);
+    // flag(p) = sgn(W(p-R)/R) != sgn(W(p)/R).
+    float* wl = win + ((kAvgSpan + R + 16 + 3) & ~3u);      // W of [c0 - R, c0 + span)
     for (uint32_t c0 = st.cached & ~63u; (int32_t)(pend - c0) > 0; c0 += kAvgSpan) {
-        __syncthreads();                                    // previous sweep's `win`/`words` consumers are done; A0 stores ordered
-        const uint32_t w0 = c0 - R;
-        const uint32_t wn = kAvgSpan + 2 * R + 8;
-        for (uint32_t k = tid; k < wn; k += kSymLanes) win[k] = v[(w0 + k) & rmask];
+        __syncthreads();                                    // previous sweep's LDS consumers are done; A0 stores ordered
+        const uint32_t wn = kAvgSpan + R + 8;
+        for (uint32_t k = tid; k < wn; k += kSymLanes) win[k] = v[(c0 + k) & rmask];
+        for (uint32_t k = tid; k < R; k += kSymLanes) wl[k] = gw[(c0 - R + k) & rmask];   // cached sums of the R positions in front
         if (tid < kAvgSpan / 64) words[tid] = 0ull;
         __syncthreads();
         const uint32_t p0 = c0 + tid * kAvgPos;
-        if ((int32_t)(pend - p0) > 0) {
-            float sl[kAvgPos], sr[kAvgPos];
-            window_sums(win + tid * kAvgPos, R, sl);
-            {   // right windows start R samples later; R is not a multiple of 4 in general: realign through a residual shift
-                const uint32_t off = tid * kAvgPos + R;
-                const uint32_t al = off & ~3u, sh = off & 3u;
-                const float* w = win + al;
-#pragma unroll
-                for (int j = 0; j < kAvgPos; ++j) sr[j] = 0.0f;
-                const uint32_t total = sh + R + kAvgPos - 1;
-                for (uint32_t e = 0; e < total; e += 4) {
-                    const float4 x = *reinterpret_cast<const float4*>(w + e);
-                    const float xs[4] = {x.x, x.y, x.z, x.w};
-                    if (e >= sh + kAvgPos - 1 && e + 4 <= sh + R) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-#pragma unroll
-                            for (int j = 0; j < kAvgPos; ++j) sr[j] = sr[j] + xs[u];
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-#pragma unroll
-                            for (int j = 0; j < kAvgPos; ++j)
-                                if (e + u >= sh + (uint32_t)j && e + u < sh + (uint32_t)j + R) sr[j] = sr[j] + xs[u];
-                    }
-                }
-            }
-            unsigned int bits = 0;
+        const bool any = (int32_t)(pend - p0) > 0;
+        float wp[kAvgPos];
+        if (any) {
+            window_sums(win + tid * kAvgPos, R, wp);
 #pragma unroll
             for (int j = 0; j < kAvgPos; ++j) {
-                const uint32_t p = p0 + j;
-                if ((int32_t)(pend - p) > 0) {
-                    const float al = sl[j] / (float)R, ar = sr[j] / (float)R;   // no clamping: p >= base+R is all the search reads, p+R <= end
-                    if (sgnf(al) != sgnf(ar)) bits |= 1u << j;
-                    const float d = ar - al;
-                    gw[p & rmask] = q.float_abs ? __builtin_fabsf(d) : (float)abs((int)d);
+                wl[R + tid * kAvgPos + j] = wp[j];
+                if ((int32_t)(pend - (p0 + j)) > 0) gw[(p0 + j) & rmask] = wp[j];
+            }
+        }
+        __syncthreads();
+        if (any) {
+            unsigned int bits = 0;
+            // sgn(W/R) == sgn(W) unless the quotient underflows to zero: |W| / R < 2^-149 (only then pay for the division)
+            const float tiny = (float)R * 2.8e-45f;         // > R * 2^-149, far below any non-zero window sum of real data
+            auto avg_sign = [&](float wsum) { return __builtin_fabsf(wsum) > tiny ? sgnf(wsum) : sgnf(wsum / (float)R); };
+#pragma unroll
+            for (int j = 0; j < kAvgPos; ++j) {
+                if ((int32_t)(pend - (p0 + j)) > 0) {        // no clamping: p >= base+R is all the search reads, p+R <= end
+                    if (avg_sign(wl[tid * kAvgPos + j]) != avg_sign(wp[j])) bits |= 1u << j;
                 }
             }
             if (bits) atomicOr(&words[tid >> 4], (unsigned long long)bits << ((tid & 15) * 4));
@@ -236,19 +223,22 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     }
     __threadfence_block();                                  // this call's weights (global) are read back by wave 0 below
     __syncthreads();
+    STAMP(2);
 
     // ---- B: edge search (wave 0)
     if (wave == 0) {
         uint32_t pos = R, nfl = 0, overflow = 0;
+        uint32_t frontier = 0xFFFFFFFFu;                    // backlog index no future flip point can precede
         while (pos < limit) {
             const uint32_t lo = find_flag_lds(lmask, st.base, rmask, pos, limit, true);
             if (lo == 0xFFFFFFFFu) break;
             const uint32_t hi = find_flag_lds(lmask, st.base, rmask, lo + 1, limit, false);
-            if (hi == 0xFFFFFFFFu) break;
+            if (hi == 0xFFFFFFFFu) { frontier = lo; break; }      // an edge zone is open: the next flip lies at or after lo
             float bw = -1.0f;                               // first maximum of the weight over [lo, hi)
             uint32_t bi = 0xFFFFFFFFu;
             for (uint32_t i = lo + lane; i < hi; i += 64) {
-                const float w = gw[(st.base + i) & rmask];
+                const float d = gw[(st.base + i) & rmask] / (float)R - gw[(st.base + i - R) & rmask] / (float)R;   // avg_r - avg_l
+                const float w = q.float_abs ? __builtin_fabsf(d) : (float)abs((int)d);
                 if (bi == 0xFFFFFFFFu || w > bw) { bw = w; bi = i; }
             }
             for (int off = 32; off > 0; off >>= 1) {
@@ -260,16 +250,20 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
             if (nfl < kMaxFlipsPerCall) { if (lane == 0) flips[nfl] = f; ++nfl; } else { overflow = 1; break; }
             pos = f + R;
         }
-        if (lane == 0) { s_nfl = nfl; s_overflow = overflow; }
+        if (frontier == 0xFFFFFFFFu) frontier = max(pos, limit);   // nothing flagged in [pos, limit)
+        if (lane == 0) { s_nfl = nfl; s_overflow = overflow; s_frontier = frontier; }
     }
     __syncthreads();
     const uint32_t nfl = s_nfl;
+    STAMP(3);
 
-    // ---- C: per-run sums in element order (std::accumulate), runs dealt round-robin to the waves
+    // ---- C: per-run sums in element order (std::accumulate), runs dealt round-robin to the waves.  The sum of the
+    // run in progress is carried across calls (SymState::run_sum covers [base, run_pos)): every call extends it up to
+    // the search frontier -- samples that can no longer become a flip point -- so when the flip finally shows up only
+    // the few samples between the frontier and the flip remain.  The chain is the same left-to-right sequence of adds.
     float* strip = strips + wave * (2 * kRunStrip);
-    for (uint32_t r = wave; r < nfl; r += kSymLanes / 64) {
-        const uint32_t a = r ? flips[r - 1] : 0u, b = flips[r];
-        float acc = 0.0f;
+    auto chain = [&](float acc, uint32_t a, uint32_t b) -> float {       // acc + v[a] + v[a+1] + ... + v[b-1] (backlog indices)
+        if (a >= b) return acc;
         float nx[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -293,23 +287,46 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
             const uint32_t cnt = min(kRunStrip, b - k0);
             const float4* s4 = reinterpret_cast<const float4*>(sb);
             uint32_t i = 0;
-            for (; i + 16 <= cnt; i += 16) {
+            if (cnt >= 32) {
+                float4 c[8], n[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 x = s4[(i >> 2) + u];      // wave-uniform address: one broadcast LDS read feeds four adds
-                    acc = acc + x.x; acc = acc + x.y; acc = acc + x.z; acc = acc + x.w;
+                for (int u = 0; u < 8; ++u) c[u] = s4[u];                   // wave-uniform addresses: broadcast reads
+                for (; i + 64 <= cnt; i += 32) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) n[u] = s4[((i + 32) >> 2) + u];   // next 32 samples in flight ...
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { acc = acc + c[u].x; acc = acc + c[u].y; acc = acc + c[u].z; acc = acc + c[u].w; }   // ... under these 32 adds
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) c[u] = n[u];
                 }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc = acc + c[u].x; acc = acc + c[u].y; acc = acc + c[u].z; acc = acc + c[u].w; }
+                i += 32;
             }
             for (; i < cnt; ++i) acc = acc + sb[i];
         }
+        return acc;
+    };
+    const uint32_t carried_to = st.run_pos - st.base;       // run 0's sum is already known up to here
+    for (uint32_t r = wave; r < nfl; r += kSymLanes / 64) {
+        const uint32_t a = r ? flips[r - 1] : 0u, b = flips[r];
+        const float acc = r ? chain(0.0f, a, b) : chain(st.run_sum, min(carried_to, b), b);
         if (lane == 0) {
             const float mean = acc / (float)(b - a);
             const uint32_t cnt = (uint32_t)roundf((float)(b - a) / (float)q.spb);
             runinfo[r] = (cnt << 1) | (mean > 0.0f ? 1u : 0u);
         }
     }
+    // carry for the next call: the run now in progress starts at the last flip (or continues) and is summed up to the frontier
+    const uint32_t frontier = s_frontier;
+    if (wave == (nfl & 3u)) {
+        const uint32_t a = nfl ? flips[nfl - 1] : carried_to;
+        const float acc = chain(nfl ? 0.0f : st.run_sum, a, max(a, frontier));
+        if (lane == 0) s_carry = acc;
+    }
     __syncthreads();
 
+    STAMP(4);
     // ---- D: bits, ring advance, result slot
     if (tid == 0) {
         uint32_t nbits = 0, cur = 0, overflow = s_overflow;
@@ -326,12 +343,18 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
         if (flips_dbg)
             for (uint32_t r = 0; r < nfl && r < flips_cap; ++r) flips_dbg[(size_t)s * flips_cap + r] = flips[r];
         const uint32_t last = nfl ? flips[nfl - 1] : 0u;   // erase the consumed prefix (SymbolExtractor.h:156-157) = advance the base
+        st.run_pos = st.base + max(nfl ? last : carried_to, frontier);
+        st.run_sum = s_carry;
         st.cached = pend;
         st.base += last;
         st.held = h - last;
         sym[s] = st;
         hdr->nbits = nbits; hdr->held_after = st.held; hdr->nflips = nfl; hdr->overflow = overflow; hdr->uncached = end - st.cached;
+#ifdef HD_STAMP
+        g_sym_stamps[blockIdx.x * 8 + 6] = nfl; g_sym_stamps[blockIdx.x * 8 + 7] = nfl ? flips[nfl - 1] : 0;
+#endif
     }
+    STAMP(5);
 }
 
 void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_new, uint32_t max_R, const float* tail,
@@ -339,7 +362,8 @@ void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t
                     const StreamCall* call, uint32_t* slots, uint32_t slot_words, uint32_t* flips_dbg, uint32_t flips_cap)
 {
     (void)max_m; (void)max_new;
-    const size_t lds = (size_t)(ring_cap / 64) * 8 + (size_t)((kAvgSpan + 2 * max_R + 16 + 3) & ~3u) * 4 + (size_t)(kSymLanes / 64) * 2 * kRunStrip * 4;
+    const size_t lds = (size_t)(ring_cap / 64) * 8 + (size_t)(((kAvgSpan + max_R + 16 + 3) & ~3u) + ((kAvgSpan + max_R + 3) & ~3u)) * 4 +
+                       (size_t)(kSymLanes / 64) * 2 * kRunStrip * 4;
     hipLaunchKernelGGL(k_symbols, dim3(n_streams), dim3(kSymLanes), lds, st, tail, ring_cap, sym, flipmask, weight, sp, call, slots,
                        slot_words, flips_dbg, flips_cap);
 }
