@@ -59,6 +59,21 @@ def bytes_per_sample(D: int) -> float:
     return 8.0 + 12.0 / D
 
 
+def shard(rank: int, world: int, streams_per_gpu: int):
+    """Streams are independent: rank r owns global stream ids [r*S, (r+1)*S) -- weak scaling, no data-path collective."""
+    return range(rank * streams_per_gpu, (rank + 1) * streams_per_gpu)
+
+
+def job_time(dist, dt: float, device=None) -> float:
+    """Whole-job time of the timed region = the slowest rank's (MAX all-reduce); identity without a process group."""
+    if dist is None:
+        return dt
+    import torch
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def stream_text(rank: int, s: int) -> str:
     from habdec_amd import synth
     return synth.make_sentence(f"R{rank}S{s:04d}", f"{s % 10},52,21")      # 23 characters: just above the 20-char scan threshold
@@ -186,10 +201,7 @@ def main():
     eng.flush()          # the last step's text is delivered inside the timed region
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = job_time(dist, dt, dev)
     front_bytes = eng.timing()["front_bytes"]
     sentences_ok = eng.sentences_ok()
 

@@ -69,5 +69,18 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     return OUT
 
 
+def build_facade_demo() -> Path:
+    """tests/cpp/decoder_thread_demo: the reference's DECODER_THREAD loop on top of habdec::Decoder<float> (the facade)."""
+    build()
+    src = HERE.parent / "tests" / "cpp" / "decoder_thread_demo.cpp"
+    out = HERE.parent / "tests" / "cpp" / "decoder_thread_demo"
+    if out.exists() and out.stat().st_mtime > max(src.stat().st_mtime, OUT.stat().st_mtime, (HERE / "include" / "habdec" / "Decoder.h").stat().st_mtime):
+        return out
+    cmd = ["g++", "-std=c++17", "-O2", "-I", str(HERE / "include"), "-I", str(HERE.parent / "include"), str(src), "-o", str(out),
+           "-L", str(HERE), "-lhabdec_amd", f"-Wl,-rpath,{HERE}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread"]
+    subprocess.run(cmd, check=True)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

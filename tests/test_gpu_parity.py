@@ -338,3 +338,30 @@ def test_pipelined_mode_delivers_identical_text(hd):
         assert engs[True].symbol_backlog(s) == engs[False].symbol_backlog(s)
     for s, o in enumerate(orcs):
         assert [x for (ss, x) in seen[True] if ss == s] == o.sentences()
+
+
+@pytest.mark.parametrize("ctx", ["mathh", "cmath"])
+def test_golden_chain_through_the_gpu(hd, ctx):
+    """tests/golden/chain_small: input stored on disk, expectations recorded from the reference's own stage classes.  The HIP
+    path must reproduce the per-call SHA-1 of the decimated / filtered / demodulated floats, the bits and the text."""
+    import hashlib
+    import json
+    from pathlib import Path
+    gold = Path(__file__).resolve().parent / "golden"
+    meta = json.loads((gold / "chain_small.json").read_text())
+    q = np.load(gold / "chain_small_input.npz")["iq_int16"]
+    x = (q[:, 0].astype(np.float32) / np.float32(meta["scale"]) + 1j * (q[:, 1].astype(np.float32) / np.float32(meta["scale"]))).astype(np.complex64)
+    want = meta["expected"][ctx]
+    Cn = meta["chunk"]
+    eng = hd.Engine(n_streams=1, max_chunk=Cn, sampling_rate=meta["fs"], decimation=meta["factor"], baud=meta["baud"], rtty_bits=8, rtty_stops=2,
+                    lookup_mode=1 if ctx == "mathh" else 0, keep_filtered=True)
+    sha = lambda a: hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+    for k, i in enumerate(range(0, len(x), Cn)):
+        eng.process_host(x[None, i:i + Cn])
+        w = want["per_call"][k]
+        assert [sha(eng.decimated(0)), sha(eng.filtered(0)), sha(eng.demodulated(0))] == w[:3], k
+        assert eng.bits(0).tolist() == w[3], k
+        a = eng.afc(0)
+        assert (a["peak_l"], a["peak_r"]) == (w[4]["peak_l"], w[4]["peak_r"]), k
+    assert eng.take_sentences(0) == want["sentences"] and eng.take_chars(0) == want["chars"]
+    assert eng.rtty(0) == want["rtty"] and eng.last_sentence(0) == want["last"]

@@ -1,0 +1,70 @@
+"""The N>1 path of bench.py without GPUs: two processes over gloo.  Streams shard with no data-path collective; the only
+cross-rank traffic is the barrier and the MAX all-reduce of the timed region, which must yield the slowest rank's time on
+every rank.  (The per-rank decode itself is covered by the GPU parity tests; here rank r decodes its shard with the CPU
+oracle to show that shards are disjoint and complete.)"""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+    import bench
+    from habdec_amd import synth
+    from oracle import pyoracle
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S = 2
+    ids = list(bench.shard(rank, world, S))
+    fs, C = 48000.0, 4096
+    decoded = []
+    for local, gid in enumerate(ids):
+        text = bench.stream_text(rank, local)
+        iq = synth.fsk_iq_for_text(text, fs, 600, 8, 2, chunk=C, sigma=0.05, seed=gid, idle_before=6, idle_after=12)
+        d = pyoracle.Decoder("oracle", factor=2, baud=600, bits=8, stops=2)
+        for i in range(0, len(iq), C):
+            d(iq[i:i + C], fs)
+        decoded += [(gid, s) for s in d.sentences()]
+    dist.barrier()
+    dt = bench.job_time(dist, 1.0 + rank)          # rank 1 is "slower"
+    gathered = [None] * world
+    dist.all_gather_object(gathered, decoded)
+    q.put((rank, ids, dt, gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_over_gloo():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, ids0, dt0, g0), (r1, ids1, dt1, g1) = res
+    assert ids0 == [0, 1] and ids1 == [2, 3]                       # disjoint, complete
+    assert dt0 == dt1 == 2.0                                        # every rank sees the slowest rank's time
+    flat = [x for part in g0 for x in part]
+    assert g0 == g1 and sorted({gid for gid, _ in flat}) == [0, 1, 2, 3]
+    # every stream decoded its own rank-tagged sentence
+    for gid, sent in flat:
+        assert sent.startswith(f"R{gid // 2}S{gid % 2:04d},")
+
+
+def test_algorithmic_bytes_model():
+    sys.path.insert(0, str(ROOT))
+    import bench
+    assert bench.bytes_per_sample(64) == pytest.approx(8.1875) and bench.bytes_per_sample(4) == 11.0
+    assert set(bench.WORKLOADS) == {"cfg1", "cfg2", "cfg3", "cfg4", "cfg5"}
