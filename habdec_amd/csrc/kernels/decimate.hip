@@ -71,28 +71,25 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     float4 r[ITER];
     auto load_tile = [&](uint32_t tile_i) {
         const long xe = (long)tile_i * TO * D - (T - 1) - JS;      // stream sample of LDS slot 0; even
-        const bool interior = (xe >= 0) && (xe + 2L * NP <= (long)n);   // wave-uniform
-        if (interior) {
-            const float4* src = reinterpret_cast<const float4*>(in_s + xe);
+        const float4* src = reinterpret_cast<const float4*>(in_s + xe);
+        // Per sweep of TO pairs: plain aligned 16-byte loads when the whole sweep lies inside this call's input (wave-uniform
+        // test); only the sweeps that touch the history in front of the stream (first tile: the first ceil((T-1)/2/TO) sweeps)
+        // or the end of the input take the address-selecting path.
 #pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int k = threadIdx.x + it * TO;
-                if (k < NP) r[it] = src[k];
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int k = threadIdx.x + it * TO;
-                if (k < NP) {
-                    const long xi = xe + 2 * k;
-                    bool oka, okb;
-                    const float2* pa = locate(xi, oka);
-                    const float2* pb = locate(xi + 1, okb);
-                    float2 a = *pa, b = *pb;
-                    if (!oka) a = make_float2(0.f, 0.f);
-                    if (!okb) b = make_float2(0.f, 0.f);
-                    r[it] = make_float4(a.x, a.y, b.x, b.y);
-                }
+        for (int it = 0; it < ITER; ++it) {
+            const int k = threadIdx.x + it * TO;
+            const long lo = xe + 2L * it * TO, hi = lo + 2L * TO;
+            if (lo >= 0 && hi <= (long)n) {
+                r[it] = src[k];                              // (k < NP or not: the extra pairs of the last sweep are in range and unused)
+            } else if (k < NP) {
+                const long xi = xe + 2 * k;
+                bool oka, okb;
+                const float2* pa = locate(xi, oka);
+                const float2* pb = locate(xi + 1, okb);
+                float2 a = *pa, b = *pb;
+                if (!oka) a = make_float2(0.f, 0.f);
+                if (!okb) b = make_float2(0.f, 0.f);
+                r[it] = make_float4(a.x, a.y, b.x, b.y);
             }
         }
     };
