@@ -108,6 +108,7 @@ struct hd_engine {
     uint32_t tail_cap = 0, backlog_cap = 0, slot_words = 0, flips_cap = 0, max_R = 0;
     int bins_sep = 8;
     bool decode_enabled = true;
+    bool one_stream = false;
     hipStream_t qa = nullptr, qb = nullptr;   // front (decimation, spectrum) and back (FIR, symbols, results) HIP streams
     bool timing_on = true;
     hd_timing last_timing{};
@@ -155,7 +156,7 @@ struct hd_engine {
         if (fft_plan) rocfft_plan_destroy(fft_plan);
         if (fft_info) rocfft_execution_info_destroy(fft_info);
         if (qa) (void)hipStreamDestroy(qa);
-        if (qb) (void)hipStreamDestroy(qb);
+        if (qb && qb != qa) (void)hipStreamDestroy(qb);
     }
 };
 
@@ -230,6 +231,8 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         return fail(HD_ERR_DEVICE, "no HIP device " + std::to_string(cfg->device) + " (this library has no CPU path)");
     HD_HIP(hipSetDevice(cfg->device));
     HD_HIP(hipStreamCreateWithFlags(&e->qa, hipStreamNonBlocking));
+    e->one_stream = getenv("HD_ONE_STREAM") != nullptr;
+    if (e->one_stream) e->qb = e->qa; else
     HD_HIP(hipStreamCreateWithFlags(&e->qb, hipStreamNonBlocking));
     for (auto& sl : e->slot) {
         HD_HIP(hipEventCreateWithFlags(&sl.ev_front, hipEventDisableTiming));
@@ -617,7 +620,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     mark();
     // With two calls in flight the front half of call k could otherwise overwrite the low-pass input buffer that the
     // back half of call k-2 is still reading (same ping-pong parity): order it behind that call's completion.
-    if (e->calls >= 2) HD_HIP(hipStreamWaitEvent(qa, e->slot[(e->calls - 2) % hd_engine::kSlots].ev_done, 0));
+    if (e->calls >= 2 && !e->one_stream) HD_HIP(hipStreamWaitEvent(qa, e->slot[(e->calls - 2) % hd_engine::kSlots].ev_done, 0));
     if (e->timing_on) HD_HIP(hipEventRecord(sl.t0, qa));
     hd::launch_fetch_params(qa, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
     for (uint32_t s = 0; s < S; ++s) {
@@ -679,11 +682,11 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         }
     }
     mark();
-    HD_HIP(hipEventRecord(sl.ev_front, qa));
+    if (!e->one_stream) HD_HIP(hipEventRecord(sl.ev_front, qa));
     const auto h2 = std::chrono::steady_clock::now();
     // ---- back half on qb: low-pass + discriminator, buffer slide, symbol extractor, results.  It may still be running
     // when the NEXT call's front half starts on qa: the two halves touch disjoint buffers (DESIGN.md "two-stream pipeline").
-    HD_HIP(hipStreamWaitEvent(qb, sl.ev_front, 0));
+    if (!e->one_stream) HD_HIP(hipStreamWaitEvent(qb, sl.ev_front, 0));
     mark();
     const int cin = e->carry_cur, cout = e->carry_cur ^ 1;
     hd::launch_fir_demod(qb, S, max_m, max_taps, fcur, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S,
