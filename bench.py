@@ -222,7 +222,7 @@ def main():
             traffic = json.loads(tf.read_text()).get(args.workload, {}).get("front_kernel_hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    stage1 = {64: "k_decimate<32,212,128>", 16: "k_decimate<8,54,256>", 4: "k_decimate<4,139,256>", 256: "k_decimate<64,348,64>"}.get(w["D"], "k_decimate")
+    stage1 = {64: "k_decimate<32,212,64>", 16: "k_decimate<8,54,256>", 4: "k_decimate<4,139,256>", 256: "k_decimate<64,348,64>"}.get(w["D"], "k_decimate")
     line = {
         "metric": "IQ Msamples/s (batched 2.048 MS/s streams)" if w["fs"] == 2.048e6 else "IQ Msamples/s (batched streams)",
         "value": round(value, 1), "unit": "MS/s", "n_gpus": world, "steps": K, "warmup": W,
