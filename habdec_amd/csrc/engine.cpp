@@ -343,8 +343,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
             hd::launch_spectrum_commit(q, S, e->fft_raw.p, e->spec.p, e->power.p, sl.h_stats.dev, sl.d_call.p, e->fsd, e->bins_sep);
         }
         hd::launch_fir_demod(q, S, 0, 0, e->fbuf[0].p, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S, nullptr, e->carry[0].p,
-                             e->carry[1].p, sl.d_call.p, e->fir_hist_cap, e->tail.p, e->tail_cap, e->d_symstate.p);
-        hd::launch_fbuf_shift(q, S, e->fbuf[0].p, e->fbuf[1].p, e->fbuf_stride, sl.d_call.p, e->fir_hist_cap);
+                             e->carry[1].p, sl.d_call.p, e->fir_hist_cap, e->tail.p, e->tail_cap, e->d_symstate.p, e->fbuf[1].p);
         hd::launch_symbols(q, S, 1, 1, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p, sl.d_call.p,
                            sl.h_slots.dev, e->slot_words, nullptr, 0);
         HD_HIP(hipStreamSynchronize(q));
@@ -691,9 +690,8 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     const int cin = e->carry_cur, cout = e->carry_cur ^ 1;
     hd::launch_fir_demod(qb, S, max_m, max_taps, fcur, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S,
                          e->cfg.keep_filtered ? e->filtered.p : nullptr, e->carry[cin].p, e->carry[cout].p, dcall, e->fir_hist_cap,
-                         e->tail.p, e->tail_cap, e->d_symstate.p);
+                         e->tail.p, e->tail_cap, e->d_symstate.p, fnext);
     mark();
-    hd::launch_fbuf_shift(qb, S, fcur, fnext, e->fbuf_stride, dcall, e->fir_hist_cap);
     mark();
     hd::launch_symbols(qb, S, max_m, max_new, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p,
                        dcall, sl.h_slots.dev, e->slot_words, e->flips_cap ? e->flips_dbg.p : nullptr, e->flips_cap);

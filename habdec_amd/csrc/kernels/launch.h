@@ -36,9 +36,7 @@ void launch_spectrum_commit(hipStream_t st, uint32_t n_streams, const float2* ra
 void launch_fir_demod(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_taps, const float2* fbuf, size_t stride,
                       const float* taps, uint32_t taps_stride, float* demod, size_t demod_stride, float2* filtered /*or null*/,
                       const DemodCarry* carry_in, DemodCarry* carry_out, const StreamCall* call, uint32_t fir_hist_cap,
-                      float* sym_ring, uint32_t ring_cap, const SymState* sym);
-void launch_fbuf_shift(hipStream_t st, uint32_t n_streams, const float2* src, float2* dst, size_t stride,
-                       const StreamCall* call, uint32_t fir_hist_cap);
+                      float* sym_ring, uint32_t ring_cap, const SymState* sym, float2* fbuf_next);
 // Symbol extractor: window kernel over the positions that became computable (at most max_new per stream) + scan kernel.
 void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_new, uint32_t max_R, const float* tail,
                     uint32_t ring_cap, SymState* sym, unsigned long long* flipmask, float* weight, const SymbolParams* sp,

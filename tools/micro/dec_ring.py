@@ -1,0 +1,16 @@
+# stage-1 decimator time vs. size of the region the input cycles through (TLB / Infinity-Cache sensitivity)
+import sys, numpy as np
+sys.path.insert(0, '/root/repo')
+import torch, bench, habdec_amd
+w = dict(bench.WORKLOADS["cfg4"]); S = 1024; C = w["C"]
+dev = torch.device("cuda", 0)
+eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"])
+for n in (1, 2, 8, 32, 128):
+    ring = torch.randn((n, S, C, 2), device=dev) * 0.3
+    torch.cuda.synchronize()
+    ts = []
+    for i in range(40):
+        eng.process_device(ring.data_ptr() + (i % n) * S * C * 8, C, C)
+        if i >= 8: ts.append(eng.timing()["ms_front"])
+    print(f"ring {n:4d} chunks ({n * S * C * 8 / 2**30:6.1f} GiB): stage-1 {np.mean(ts) * 1e3:7.1f} us  (min {np.min(ts) * 1e3:.1f})  -> {S * C * 8.25 / np.mean(ts) / 1e9:.2f} TB/s algorithmic")
+    del ring

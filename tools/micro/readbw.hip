@@ -72,5 +72,13 @@ int main()
     run("tiles 32 KiB, 128 thr x 16 loads, 16 tiles/WG prefetch (1024)", [&](const float4* s) { hipLaunchKernelGGL((k_tiles<128, 16>), dim3(1024), dim3(128), 0, 0, s, 16, o); });
     run("tiles 16 KiB, 64 thr x 16 loads, 8 tiles/WG prefetch (4096)", [&](const float4* s) { hipLaunchKernelGGL((k_tiles<64, 16>), dim3(4096), dim3(64), 0, 0, s, 8, o); });
     run("tiles 32 KiB, 256 thr x 8 loads, 8 tiles/WG prefetch (2048)", [&](const float4* s) { hipLaunchKernelGGL((k_tiles<256, 8>), dim3(2048), dim3(256), 0, 0, s, 8, o); });
+    // occupancy-limited like the stage-1 decimator: 19 KiB (or more) of dynamic LDS per single-wave workgroup
+    for (int lds_kb : {19, 38, 9}) {
+        char nm[128];
+        snprintf(nm, sizeof nm, "tiles 16 KiB, 64 thr x 16 loads, 16 tiles/WG, %d KiB LDS/WG", lds_kb);
+        run(nm, [&](const float4* s) { hipLaunchKernelGGL((k_tiles<64, 16>), dim3(2048), dim3(64), lds_kb * 1024, 0, s, 16, o); });
+        snprintf(nm, sizeof nm, "tiles 32 KiB, 64 thr x 32 loads, 8 tiles/WG, %d KiB LDS/WG", lds_kb);
+        run(nm, [&](const float4* s) { hipLaunchKernelGGL((k_tiles<64, 32>), dim3(2048), dim3(64), lds_kb * 1024, 0, s, 8, o); });
+    }
     return 0;
 }
