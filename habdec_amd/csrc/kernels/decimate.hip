@@ -24,6 +24,22 @@
 
 namespace hd {
 
+#ifdef HD_STAMP_DEC   // diagnostic build only (tools/micro/dec_stamps.py): phase clocks of the D = 32 kernel, per workgroup
+__device__ unsigned long long g_dec_stamps[4096 * 8];
+extern "C" void hd_debug_dec_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dec_stamps), n * 8); }
+#define DSTAMP_DECL unsigned long long ds_t = __builtin_amdgcn_s_memtime(), ds_acc[4] = {0, 0, 0, 0}; const unsigned long long ds_r0 = __builtin_amdgcn_s_memrealtime(); unsigned long long ds_r1 = 0
+#define DSTAMP(i) do { if (D == 32) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ds_acc[i] += t_ - ds_t; ds_t = t_; } } while (0)
+#define DSTAMP_ARRIVED() do { if (D == 32) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DSTAMP(0); if (!ds_r1) ds_r1 = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define DSTAMP_WRITE() do { if (D == 32 && threadIdx.x == 0) { const uint32_t w_ = blockIdx.y * gridDim.x + blockIdx.x; if (w_ < 4096) { \
+        unsigned long long* g_ = g_dec_stamps + w_ * 8; g_[0] = ds_r0; g_[1] = ds_r1; g_[2] = __builtin_amdgcn_s_memrealtime(); \
+        g_[3] = ds_acc[0]; g_[4] = ds_acc[1]; g_[5] = ds_acc[2]; g_[6] = ds_acc[3]; g_[7] = last - first; } } } while (0)
+#else
+#define DSTAMP_DECL do { } while (0)
+#define DSTAMP(i) do { } while (0)
+#define DSTAMP_ARRIVED() do { } while (0)
+#define DSTAMP_WRITE() do { } while (0)
+#endif
+
 template <int D, int T, int TO>
 __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_decimate(const float2* __restrict__ in, size_t in_stride,
                                                    const float2* __restrict__ hist_in, float2* __restrict__ hist_out,
@@ -94,6 +110,7 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     };
 
+    DSTAMP_DECL;
     load_tile(first);
     const float2* p = tile + threadIdx.x * (D + 2);
     // A tile's outputs are stored one iteration late, just BEFORE the next prefetch is issued: loads and stores retire
@@ -109,6 +126,7 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     };
     for (uint32_t tile_i = first; tile_i < last; ++tile_i) {
+        DSTAMP_ARRIVED();
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int k = threadIdx.x + it * TO;
@@ -118,8 +136,10 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
         }
         __syncthreads();
+        DSTAMP(1);
         store_prev();
         if (tile_i + 1 < last) load_tile(tile_i + 1);      // in flight while this tile is computed
+        DSTAMP(2);
 
         // The T-term sum, in tap order.  Taps are consumed in blocks of B LDS slots (B/2 ds_read_b128 issued
         // together, then 2*B packed multiply/add) inside a rolled loop: that keeps ~B taps live in SGPRs instead
@@ -175,8 +195,10 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         o_prev = o;
         ytile[threadIdx.x] = y_prev;
         __syncthreads();                                    // everyone is done with this tile's LDS image
+        DSTAMP(3);
     }
     store_prev();
+    DSTAMP_WRITE();
 
     // History carry for the next call (Decimator.h:140-143).  Q4: the reference decimates in place
     // (Decoder.h:443-444), so history positions that fall inside the first n/D samples hold OUTPUTS; that can only

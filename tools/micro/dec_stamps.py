@@ -9,8 +9,12 @@ L = habdec_amd.lib(); f = L.hd_debug_dec_stamps; f.argtypes = [ctypes.c_void_p, 
 for i in range(12):
     eng.process_device(ring.data_ptr() + (i % 8) * S * C * 8, C, C)
 st = np.zeros(4096 * 8, np.uint64); f(st.ctypes.data, 4096 * 8); st = st.reshape(4096, 8).astype(np.float64)
-st = st[st[:, 4] > 0]
-per = st[:, :4] / st[:, 4:5]
-print("workgroups sampled:", len(st), "tiles per WG:", st[0, 4])
-print("cycles per tile per wave [wait prefetched tile, stage to LDS, issue next loads, compute+store]:", per.mean(axis=0).round(0).tolist(), "sum", per.sum(axis=1).mean().round(0))
-print("kernel ms_front:", eng.timing()["ms_front"])
+st = st[st[:, 7] > 0]
+t0 = st[:, 0].min()
+print("workgroups:", len(st), "tiles per WG:", st[0, 7], " kernel ms_front:", eng.timing()["ms_front"])
+print("100MHz timeline (us): start  p0/50/100 = %s ; first tile staged p0/50/100 = %s ; end p0/50/100 = %s" % tuple(
+    np.percentile((st[:, k] - t0) / 100.0, [0, 50, 100]).round(1).tolist() for k in (0, 1, 2)))
+per = st[:, 3:7] / st[:, 7:8]
+print("cycles per tile per wave [wait prefetched tile, stage to LDS+barrier, store+issue next loads, compute]:", per.mean(axis=0).round(0).tolist(), "sum", per.sum(axis=1).mean().round(0))
+first = st[0::2]; second = st[1::2]
+print("stream-first WGs: end %.1f us ; second WGs: end %.1f us" % (np.median(first[:, 2] - t0) / 100.0, np.median(second[:, 2] - t0) / 100.0))
