@@ -19,6 +19,7 @@
 // History: the workgroup that owns a stream's last tile also writes the stream's next history (last T-1 inputs)
 // into the OTHER history buffer (ping-pong, so the first tile of the same launch still reads the old one).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "launch.h"
 
@@ -263,7 +264,8 @@ static void launch_one(hipStream_t st, uint32_t n_streams, uint32_t max_out, con
     uint32_t per = 1;
     while (per < 16 && (uint64_t)((ntiles + 2 * per - 1) / (2 * per)) * n_streams >= 2048) per *= 2;
     dim3 grid((ntiles + per - 1) / per, n_streams);
-    hipLaunchKernelGGL((k_decimate<D, T, TO>), grid, dim3(TO), 0, st, in, in_stride, hist_in, hist_out, taps, out, out_stride, call,
+    static const size_t pad_lds = [] { const char* v = getenv("HD_DEC_PAD_LDS"); return v ? (size_t)atoi(v) : (size_t)0; }();   // experiment knob
+    hipLaunchKernelGGL((k_decimate<D, T, TO>), grid, dim3(TO), TO == 64 ? pad_lds : 0, st, in, in_stride, hist_in, hist_out, taps, out, out_stride, call,
                        stage, final_stage, fir_hist_cap, per, fft_in);
 }
 

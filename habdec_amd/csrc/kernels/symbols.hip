@@ -92,7 +92,7 @@ extern "C" void hd_debug_sym_stamps(unsigned long long* host, size_t n) { (void)
 #define STAMP(i) do { } while (0)
 #endif
 constexpr int kSymLanes = 256;
-constexpr uint32_t kRunStrip = 256;                       // samples per run-sum step
+constexpr uint32_t kRunStrip = 512;                       // samples per run-sum step
 
 __device__ __forceinline__ uint32_t find_flag_lds(const unsigned long long* lmask, uint32_t base, uint32_t rmask,
                                                   uint32_t from, uint32_t to, bool want)
@@ -130,9 +130,9 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
                                                         uint32_t* __restrict__ flips_dbg, uint32_t flips_cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // carve: [lmask: ring_cap/64 u64][win: span + R + 16 floats][wl: span + R floats][strips: 4 waves x 2 x kRunStrip floats]
+    // carve: [lmask: ring_cap/64 u64][win: span + R + 16 floats][wl: span + R floats][strips: 4 waves x kRunStrip floats]
     unsigned long long* lmask = reinterpret_cast<unsigned long long*>(smem);
-    __shared__ unsigned long long words[kAvgSpan / 64];
+    __shared__ unsigned long long words[kAvgSpan / 64 + 1];
     __shared__ uint32_t flips[kMaxFlipsPerCall];
     __shared__ uint32_t runinfo[kMaxFlipsPerCall];          // (count << 1) | bit
     __shared__ uint32_t s_nfl, s_overflow, s_frontier;
@@ -167,27 +167,62 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     const uint32_t limit = h - q.spb;                       // backlog indices searched: [R, limit)
 
     STAMP(0);
-    // ---- A0: LDS image of the cached mask words the search can touch
-    {
-        const uint32_t wr0 = (st.base + R) & ~63u;                     // ring position of the first word
-        const uint32_t nw = ((st.base + limit) - wr0 + 63u) >> 6;      // modular difference: safe across the 2^32 wrap
-        for (uint32_t i = tid; i < nw; i += kSymLanes) {
-            const uint32_t wi = ((wr0 + 64u * i) & rmask) >> 6;
-            lmask[wi] = gmask[wi];
-        }
-    }
-    STAMP(1);
-    // ---- A1: window sums for the new positions, one sweep of kAvgSpan positions at a time.
+    // ---- A: window sums and flags for the new positions [cached, pend), kAvgSpan positions per sweep (one sweep per call
+    // in steady state: a call appends m <= kAvgSpan samples).  Everything the first sweep and the search read from global
+    // memory -- the samples, the R cached sums in front of them, the LDS image of the mask words the search can touch, the
+    // partially filled mask word `cached` falls into -- is requested before the first value is used: one round trip.
     // W(p) = v[p] + ... + v[p+R-1] summed left to right is BOTH the reference's right window of p and its left window
     // of p+R (same elements, same order, same rounding), so one sum per position is computed and cached (ring `wsum`);
     // flag(p) = sgn(W(p-R)/R) != sgn(W(p)/R).
     float* wl = win + ((kAvgSpan + R + 16 + 3) & ~3u);      // W of [c0 - R, c0 + span)
-    for (uint32_t c0 = st.cached & ~63u; (int32_t)(pend - c0) > 0; c0 += kAvgSpan) {
-        __syncthreads();                                    // previous sweep's LDS consumers are done; A0 stores ordered
-        const uint32_t wn = kAvgSpan + R + 8;
-        for (uint32_t k = tid; k < wn; k += kSymLanes) win[k] = v[(c0 + k) & rmask];
-        for (uint32_t k = tid; k < R; k += kSymLanes) wl[k] = gw[(c0 - R + k) & rmask];   // cached sums of the R positions in front
-        if (tid < kAvgSpan / 64) words[tid] = 0ull;
+    const uint32_t wn = kAvgSpan + R + 8;
+    constexpr int WB = 6, LB = 2, MB = 2;                   // loads per lane issued back to back (covers R <= 504, 32768 searchable positions)
+    unsigned long long first_word = 0ull;                   // mask word holding position c0, as earlier calls left it
+    {
+        const uint32_t c0 = st.cached;
+        const uint32_t wr0 = (st.base + R) & ~63u;                     // ring position of the first searchable word
+        const uint32_t nw = ((st.base + limit) - wr0 + 63u) >> 6;      // modular difference: safe across the 2^32 wrap
+        const bool sweep = (int32_t)(pend - c0) > 0;
+        float tw[WB], tl[LB];
+        unsigned long long tm[MB];
+#pragma unroll
+        for (int u = 0; u < WB; ++u) { const uint32_t k = tid + u * kSymLanes; tw[u] = (sweep && k < wn) ? v[(c0 + k) & rmask] : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < LB; ++u) { const uint32_t k = tid + u * kSymLanes; tl[u] = (sweep && k < R) ? gw[(c0 - R + k) & rmask] : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < MB; ++u) { const uint32_t i = tid + u * kSymLanes; tm[u] = i < nw ? gmask[((wr0 + 64u * i) & rmask) >> 6] : 0ull; }
+        if (sweep) first_word = gmask[(c0 & rmask) >> 6];
+#pragma unroll
+        for (int u = 0; u < WB; ++u) { const uint32_t k = tid + u * kSymLanes; if (sweep && k < wn) win[k] = tw[u]; }
+#pragma unroll
+        for (int u = 0; u < LB; ++u) { const uint32_t k = tid + u * kSymLanes; if (sweep && k < R) wl[k] = tl[u]; }
+#pragma unroll
+        for (int u = 0; u < MB; ++u) { const uint32_t i = tid + u * kSymLanes; if (i < nw) lmask[((wr0 + 64u * i) & rmask) >> 6] = tm[u]; }
+        // larger R / backlog than the batches cover: plain loops
+        if (sweep) {
+            for (uint32_t k = tid + WB * kSymLanes; k < wn; k += kSymLanes) win[k] = v[(c0 + k) & rmask];
+            for (uint32_t k = tid + LB * kSymLanes; k < R; k += kSymLanes) wl[k] = gw[(c0 - R + k) & rmask];
+        }
+        for (uint32_t i = tid + MB * kSymLanes; i < nw; i += kSymLanes) { const uint32_t wi = ((wr0 + 64u * i) & rmask) >> 6; lmask[wi] = gmask[wi]; }
+    }
+    STAMP(1);
+    bool staged = true;
+    for (uint32_t c0 = st.cached; (int32_t)(pend - c0) > 0; c0 += kAvgSpan) {
+        const uint32_t wb0 = c0 & ~63u, wsh = c0 & 63u;    // sweeps start wherever the previous call stopped: words are shared
+        if (!staged) {
+            __syncthreads();                                // previous sweep's LDS consumers are done
+            for (uint32_t k0 = tid; k0 < wn; k0 += WB * kSymLanes) {
+                float tw[WB];
+#pragma unroll
+                for (int u = 0; u < WB; ++u) { const uint32_t k = k0 + u * kSymLanes; tw[u] = k < wn ? v[(c0 + k) & rmask] : 0.0f; }
+#pragma unroll
+                for (int u = 0; u < WB; ++u) { const uint32_t k = k0 + u * kSymLanes; if (k < wn) win[k] = tw[u]; }
+            }
+            for (uint32_t k = tid; k < R; k += kSymLanes) wl[k] = gw[(c0 - R + k) & rmask];   // cached sums of the R positions in front
+            first_word = lmask[(c0 & rmask) >> 6];          // as the previous sweep left it
+        }
+        staged = false;
+        if (tid < kAvgSpan / 64 + 1) words[tid] = 0ull;
         __syncthreads();
         const uint32_t p0 = c0 + tid * kAvgPos;
         const bool any = (int32_t)(pend - p0) > 0;
@@ -212,13 +247,20 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
                     if (avg_sign(wl[tid * kAvgPos + j]) != avg_sign(wp[j])) bits |= 1u << j;
                 }
             }
-            if (bits) atomicOr(&words[tid >> 4], (unsigned long long)bits << ((tid & 15) * 4));
+            if (bits) {
+                const uint32_t bp = wsh + tid * kAvgPos;    // bit position of p0 relative to the sweep's first word
+                const uint32_t sh = bp & 63u;
+                atomicOr(&words[bp >> 6], (unsigned long long)bits << sh);
+                if (sh > 60u) atomicOr(&words[(bp >> 6) + 1], (unsigned long long)bits >> (64u - sh));
+            }
         }
         __syncthreads();
-        if (tid < kAvgSpan / 64 && (int32_t)(pend - (c0 + tid * 64)) > 0) {
-            const uint32_t wi = ((c0 + tid * 64) & rmask) >> 6;
-            gmask[wi] = words[tid];
-            lmask[wi] = words[tid];
+        if (tid < kAvgSpan / 64 + 1 && (int32_t)(pend - (wb0 + tid * 64)) > 0 && (int32_t)((c0 + kAvgSpan) - (wb0 + tid * 64)) > 0) {
+            const uint32_t wi = ((wb0 + tid * 64) & rmask) >> 6;
+            unsigned long long w = words[tid];
+            if (tid == 0 && wsh) w |= first_word & ((1ull << wsh) - 1ull);     // flags of the positions in front of c0
+            gmask[wi] = w;
+            lmask[wi] = w;
         }
     }
     __threadfence_block();                                  // this call's weights (global) are read back by wave 0 below
@@ -261,23 +303,24 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     // run in progress is carried across calls (SymState::run_sum covers [base, run_pos)): every call extends it up to
     // the search frontier -- samples that can no longer become a flip point -- so when the flip finally shows up only
     // the few samples between the frontier and the flip remain.  The chain is the same left-to-right sequence of adds.
-    float* strip = strips + wave * (2 * kRunStrip);
+    float* sb = strips + wave * kRunStrip;                                // wave-private strip, single buffer
+    constexpr int NX = kRunStrip / 64;                                    // loads in flight per lane: one whole strip
     auto chain = [&](float acc, uint32_t a, uint32_t b) -> float {       // acc + v[a] + v[a+1] + ... + v[b-1] (backlog indices)
         if (a >= b) return acc;
-        float nx[4];
+        float nx[NX];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NX; ++j) {
             const uint32_t k = a + 64 * j + lane;
             nx[j] = k < b ? v[(st.base + k) & rmask] : 0.0f;
         }
-        uint32_t par = 0;
-        for (uint32_t k0 = a; k0 < b; k0 += kRunStrip, par ^= 1u) {
-            float* sb = strip + par * kRunStrip;
+        for (uint32_t k0 = a; k0 < b; k0 += kRunStrip) {
+            // the previous strip's LDS reads have all been consumed by its adds (data dependence), so the strip can be
+            // rewritten from the prefetched registers; the next strip's loads then fly under this strip's adds
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sb[64 * j + lane] = nx[j];
+            for (int j = 0; j < NX; ++j) sb[64 * j + lane] = nx[j];
             if (k0 + kRunStrip < b) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NX; ++j) {
                     const uint32_t k = k0 + kRunStrip + 64 * j + lane;
                     nx[j] = k < b ? v[(st.base + k) & rmask] : 0.0f;
                 }
@@ -304,6 +347,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
                 i += 32;
             }
             for (; i < cnt; ++i) acc = acc + sb[i];
+            __builtin_amdgcn_wave_barrier();
         }
         return acc;
     };
@@ -363,7 +407,7 @@ void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t
 {
     (void)max_m; (void)max_new;
     const size_t lds = (size_t)(ring_cap / 64) * 8 + (size_t)(((kAvgSpan + max_R + 16 + 3) & ~3u) + ((kAvgSpan + max_R + 3) & ~3u)) * 4 +
-                       (size_t)(kSymLanes / 64) * 2 * kRunStrip * 4;
+                       (size_t)(kSymLanes / 64) * kRunStrip * 4;
     hipLaunchKernelGGL(k_symbols, dim3(n_streams), dim3(kSymLanes), lds, st, tail, ring_cap, sym, flipmask, weight, sp, call, slots,
                        slot_words, flips_dbg, flips_cap);
 }
