@@ -278,10 +278,24 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
             if (hi == 0xFFFFFFFFu) { frontier = lo; break; }      // an edge zone is open: the next flip lies at or after lo
             float bw = -1.0f;                               // first maximum of the weight over [lo, hi)
             uint32_t bi = 0xFFFFFFFFu;
-            for (uint32_t i = lo + lane; i < hi; i += 64) {
-                const float d = gw[(st.base + i) & rmask] / (float)R - gw[(st.base + i - R) & rmask] / (float)R;   // avg_r - avg_l
-                const float w = q.float_abs ? __builtin_fabsf(d) : (float)abs((int)d);
-                if (bi == 0xFFFFFFFFu || w > bw) { bw = w; bi = i; }
+            constexpr int ZB = 4;                             // 256 zone positions per round trip (a zone is about R long)
+            for (uint32_t i0 = lo + lane; i0 < hi; i0 += 64 * ZB) {
+                float wr_[ZB], wl_[ZB];
+#pragma unroll
+                for (int u = 0; u < ZB; ++u) {
+                    const uint32_t i = i0 + 64 * u;
+                    wr_[u] = i < hi ? gw[(st.base + i) & rmask] : 0.0f;
+                    wl_[u] = i < hi ? gw[(st.base + i - R) & rmask] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < ZB; ++u) {
+                    const uint32_t i = i0 + 64 * u;
+                    if (i < hi) {
+                        const float d = wr_[u] / (float)R - wl_[u] / (float)R;   // avg_r - avg_l
+                        const float w = q.float_abs ? __builtin_fabsf(d) : (float)abs((int)d);
+                        if (bi == 0xFFFFFFFFu || w > bw) { bw = w; bi = i; }
+                    }
+                }
             }
             for (int off = 32; off > 0; off >>= 1) {
                 const float ow = __shfl_down(bw, off, 64);

@@ -16,6 +16,9 @@ for i in range(70):
         tot_p.append(np.percentile(tot, [50, 90, 99, 100]))
         ph_mean += d.mean(axis=0); ph_max = np.maximum(ph_max, d.max(axis=0)); n += 1
         span.append((st[:, 5].max() - st[:, 0].min()))
+        if i in (20, 40, 60):
+            for j in np.argsort(-tot)[:4]: print('call', i, 'stream', int(j), 'total', int(tot[j]), 'phases', d[j].astype(int).tolist(), 'nflips', int(st[j, 6]), 'last flip', int(st[j, 7]))
+            print('   nflips histogram over streams:', np.bincount(st[:, 6].astype(int))[:8].tolist())
 print("phases [A0 mask image, A1 windows, B search, C run sums, D]: mean cycles", (ph_mean / n).round(0).tolist(), " max", ph_max.tolist())
 print("per-stream total cycles p50/p90/p99/max (mean over calls):", np.mean(tot_p, axis=0).round(0).tolist())
 print("first-start to last-end span, cycles (mean over calls):", np.mean(span).round(0))
