@@ -86,13 +86,37 @@ __device__ __forceinline__ void window_sums(const float* __restrict__ w, uint32_
 
 #ifdef HD_STAMP   // diagnostic build only: s_memtime at the phase boundaries of k_symbols, per stream
 __device__ unsigned long long g_sym_stamps[8192 * 8];
-#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_sym_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP(i) do { if (threadIdx.x == 0 && s < 8192) g_sym_stamps[s * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" void hd_debug_sym_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sym_stamps), n * 8); }
 #else
 #define STAMP(i) do { } while (0)
 #endif
 constexpr int kSymLanes = 256;
 constexpr uint32_t kRunStrip = 512;                       // samples per run-sum step
+
+
+// Wave-wide maximum of an unsigned 64-bit key with DPP moves (a ds_bpermute-based shuffle reduction costs an LDS round trip
+// per step, ~1.5k cycles for an arg-max; this is a few dozen).  Result is uniform.
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
+{
+#define HD_DPP_MAX(ctrl, rmask_)                                                                                         \
+    {                                                                                                                   \
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, ctrl, rmask_, 0xf, false);       \
+        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), ctrl, rmask_, 0xf, false); \
+        const unsigned long long o_ = ((unsigned long long)hi_ << 32) | lo_;                                            \
+        k = o_ > k ? o_ : k;                                                                                            \
+    }
+    HD_DPP_MAX(0x111, 0xf)   // row_shr:1
+    HD_DPP_MAX(0x112, 0xf)   // row_shr:2
+    HD_DPP_MAX(0x114, 0xf)   // row_shr:4
+    HD_DPP_MAX(0x118, 0xf)   // row_shr:8   -> lane 15 of every row holds the row's maximum
+    HD_DPP_MAX(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
+    HD_DPP_MAX(0x143, 0xc)   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
+#undef HD_DPP_MAX
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
 
 __device__ __forceinline__ uint32_t find_flag_lds(const unsigned long long* lmask, uint32_t base, uint32_t rmask,
                                                   uint32_t from, uint32_t to, bool want)
@@ -116,7 +140,8 @@ __device__ __forceinline__ uint32_t find_flag_lds(const unsigned long long* lmas
         const unsigned long long hit = __ballot(w != 0ull);
         if (hit) {
             const int src = __ffsll((long long)hit) - 1;
-            const unsigned long long ww = __shfl(w, src, 64);
+            const unsigned long long ww = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), src) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, src);     // src is wave-uniform
             return (uint32_t)((int32_t)(wstart - base) + src * 64 + (__ffsll((long long)ww) - 1));
         }
     }
@@ -137,7 +162,12 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     __shared__ uint32_t runinfo[kMaxFlipsPerCall];          // (count << 1) | bit
     __shared__ uint32_t s_nfl, s_overflow, s_frontier;
     __shared__ float s_carry;
-    const uint32_t s = blockIdx.x;
+    __shared__ uint32_t s_flagged;
+    // Workgroups are dealt round-robin to the 8 XCDs.  The kernel ends with its slowest stream, and slow streams (off-tune,
+    // noisy: ten flips per call instead of one) tend to come with a period in the stream index (every 8th receiver of a
+    // bank, ...), which would pile them onto one XCD's CUs; give XCD j the contiguous block j of the streams instead.
+    const uint32_t nS = gridDim.x;
+    const uint32_t s = (nS & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (nS >> 3) + (blockIdx.x >> 3);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t* slot = slots + (size_t)s * slot_words;
     BitsHeader* hdr = reinterpret_cast<BitsHeader*>(slot);
@@ -166,6 +196,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     const uint32_t pend = end - R + 1;                      // first position whose right window is still incomplete
     const uint32_t limit = h - q.spb;                       // backlog indices searched: [R, limit)
 
+    if (tid == 0) s_flagged = 0u;
     STAMP(0);
     // ---- A: window sums and flags for the new positions [cached, pend), kAvgSpan positions per sweep (one sweep per call
     // in steady state: a call appends m <= kAvgSpan samples).  Everything the first sweep and the search read from global
@@ -263,8 +294,35 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
             lmask[wi] = w;
         }
     }
-    __threadfence_block();                                  // this call's weights (global) are read back by wave 0 below
+    __threadfence_block();                                  // this call's weights (global) are read back below
     __syncthreads();
+    // ---- A2: busy streams (off-tune or noisy: ten flips per call instead of one) would pay one global round trip per flip
+    // for the zone weights.  When the mask image shows more flagged positions than a couple of clean edges produce, the
+    // window sums of the whole searchable backlog are pulled into LDS first (over win/wl/strips, which are idle here).
+    float* wc = win;
+    uint32_t wc_n = 0;
+    {
+        const uint32_t wr0 = (st.base + R) & ~63u;
+        const uint32_t nw = ((st.base + limit) - wr0 + 63u) >> 6;
+        uint32_t cnt = 0;
+        for (uint32_t i = tid; i < nw; i += kSymLanes) cnt += (uint32_t)__popcll(lmask[((wr0 + 64u * i) & rmask) >> 6]);
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+        if (lane == 0 && cnt) atomicAdd(&s_flagged, cnt);
+        __syncthreads();
+        if (s_flagged > 4u * R) {
+            const uint32_t cap = ((kAvgSpan + R + 16 + 3) & ~3u) + ((kAvgSpan + R + 3) & ~3u) + (kSymLanes / 64) * kRunStrip;
+            wc_n = min(limit, cap);
+            constexpr int CB = 9;
+            for (uint32_t k0 = tid; k0 < wc_n; k0 += CB * kSymLanes) {
+                float t[CB];
+#pragma unroll
+                for (int u = 0; u < CB; ++u) { const uint32_t k = k0 + u * kSymLanes; t[u] = k < wc_n ? gw[(st.base + k) & rmask] : 0.0f; }
+#pragma unroll
+                for (int u = 0; u < CB; ++u) { const uint32_t k = k0 + u * kSymLanes; if (k < wc_n) wc[k] = t[u]; }
+            }
+            __syncthreads();
+        }
+    }
     STAMP(2);
 
     // ---- B: edge search (wave 0)
@@ -276,16 +334,17 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
             if (lo == 0xFFFFFFFFu) break;
             const uint32_t hi = find_flag_lds(lmask, st.base, rmask, lo + 1, limit, false);
             if (hi == 0xFFFFFFFFu) { frontier = lo; break; }      // an edge zone is open: the next flip lies at or after lo
-            float bw = -1.0f;                               // first maximum of the weight over [lo, hi)
-            uint32_t bi = 0xFFFFFFFFu;
+            // first maximum of the weight over [lo, hi): key = (weight bits, ~index) -- weights are >= 0, so their bit patterns
+            // order like the values, and among equal weights the smaller index has the larger key
+            unsigned long long key = 0ull;
             constexpr int ZB = 4;                             // 256 zone positions per round trip (a zone is about R long)
             for (uint32_t i0 = lo + lane; i0 < hi; i0 += 64 * ZB) {
                 float wr_[ZB], wl_[ZB];
 #pragma unroll
                 for (int u = 0; u < ZB; ++u) {
                     const uint32_t i = i0 + 64 * u;
-                    wr_[u] = i < hi ? gw[(st.base + i) & rmask] : 0.0f;
-                    wl_[u] = i < hi ? gw[(st.base + i - R) & rmask] : 0.0f;
+                    wr_[u] = i < hi ? (i < wc_n ? wc[i] : gw[(st.base + i) & rmask]) : 0.0f;
+                    wl_[u] = i < hi ? (i - R < wc_n ? wc[i - R] : gw[(st.base + i - R) & rmask]) : 0.0f;
                 }
 #pragma unroll
                 for (int u = 0; u < ZB; ++u) {
@@ -293,16 +352,12 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
                     if (i < hi) {
                         const float d = wr_[u] / (float)R - wl_[u] / (float)R;   // avg_r - avg_l
                         const float w = q.float_abs ? __builtin_fabsf(d) : (float)abs((int)d);
-                        if (bi == 0xFFFFFFFFu || w > bw) { bw = w; bi = i; }
+                        const unsigned long long k = ((unsigned long long)__builtin_bit_cast(uint32_t, w) << 32) | (uint32_t)~i;
+                        key = k > key ? k : key;
                     }
                 }
             }
-            for (int off = 32; off > 0; off >>= 1) {
-                const float ow = __shfl_down(bw, off, 64);
-                const uint32_t oi = __shfl_down(bi, off, 64);
-                if (oi != 0xFFFFFFFFu && (bi == 0xFFFFFFFFu || ow > bw || (ow == bw && oi < bi))) { bw = ow; bi = oi; }
-            }
-            const uint32_t f = __shfl(bi, 0, 64);
+            const uint32_t f = ~(uint32_t)wave_max_u64(key);
             if (nfl < kMaxFlipsPerCall) { if (lane == 0) flips[nfl] = f; ++nfl; } else { overflow = 1; break; }
             pos = f + R;
         }
@@ -409,7 +464,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
         sym[s] = st;
         hdr->nbits = nbits; hdr->held_after = st.held; hdr->nflips = nfl; hdr->overflow = overflow; hdr->uncached = end - st.cached;
 #ifdef HD_STAMP
-        g_sym_stamps[blockIdx.x * 8 + 6] = nfl; g_sym_stamps[blockIdx.x * 8 + 7] = nfl ? flips[nfl - 1] : 0;
+        g_sym_stamps[s * 8 + 6] = nfl; g_sym_stamps[s * 8 + 7] = nfl ? flips[nfl - 1] : 0;
 #endif
     }
     STAMP(5);
