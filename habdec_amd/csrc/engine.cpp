@@ -109,6 +109,8 @@ struct hd_engine {
     int bins_sep = 8;
     bool decode_enabled = true;
     bool one_stream = false;
+    bool no_fuse = false;      // HD_NO_FUSE: never use the fused back end (kernels/backend.hip); A/B measurements
+    int last_fuse = -1;        // path of the previous call (the two paths use the stage-2 buffers on different queues)
     hipStream_t qa = nullptr, qb = nullptr;   // front (decimation, spectrum) and back (FIR, symbols, results) HIP streams
     bool timing_on = true;
     hd_timing last_timing{};
@@ -116,7 +118,7 @@ struct hd_engine {
     rocfft_execution_info fft_info = nullptr;
     DevBuf<char> fft_work;
 
-    DevBuf<float2> staging, dec1, hist1[2], hist2[2], fbuf[2], fft_in, fft_raw, spec, filtered;
+    DevBuf<float2> staging, dec1, dec1b, hist1[2], hist2[2], fbuf[2], fft_in, fft_raw, spec, filtered;   // dec1/dec1b: stage-1 output, alternating per call
     DevBuf<float> stage_taps[2], lp_taps, power, demod, tail, weight;
     DevBuf<unsigned long long> flipmask;
     DevBuf<uint32_t> flips_dbg;
@@ -232,6 +234,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     HD_HIP(hipSetDevice(cfg->device));
     HD_HIP(hipStreamCreateWithFlags(&e->qa, hipStreamNonBlocking));
     e->one_stream = getenv("HD_ONE_STREAM") != nullptr;
+    e->no_fuse = getenv("HD_NO_FUSE") != nullptr;
     if (e->one_stream) e->qb = e->qa; else
     HD_HIP(hipStreamCreateWithFlags(&e->qb, hipStreamNonBlocking));
     for (auto& sl : e->slot) {
@@ -272,7 +275,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
 
     // device memory
     HD_HIP(e->staging.alloc((size_t)S * cfg->max_chunk));
-    if (e->stages.size() == 2) HD_HIP(e->dec1.alloc((size_t)S * e->n1_cap));
+    if (e->stages.size() == 2) { HD_HIP(e->dec1.alloc((size_t)S * e->n1_cap)); HD_HIP(e->dec1b.alloc((size_t)S * e->n1_cap)); }
     if (e->stages.size() >= 1) {
         for (auto& h : e->hist1) HD_HIP(h.alloc((size_t)S * (e->stages[0].taps.size() - 1)));
         HD_HIP(e->stage_taps[0].alloc(e->stages[0].taps.size()));
@@ -647,50 +650,73 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     float2* fcur = e->fbuf[e->cur].p;
     float2* fnext = e->fbuf[e->cur ^ 1].p;
     const hd::StreamCall* dcall = sl.d_call.p;
+    // Two-stage plans at batch-decoding sizes: stage 2, low-pass, discriminator and slide run as ONE kernel per call on qb
+    // (kernels/backend.hip) when a stream's call fits in LDS and no DC blocker sits in between.
+    const bool fuse = nst == 2 && !any_dc && !e->no_fuse && ((R2 == 2 && T2 == 69) || (R2 == 4 && T2 == 139)) &&
+                      hd::backend_lds_bytes((int)T2, max_n1, max_n2, max_taps) <= 64 * 1024;
+    if (e->last_fuse >= 0 && e->last_fuse != (int)fuse) { HD_HIP(hipStreamSynchronize(qa)); HD_HIP(hipStreamSynchronize(qb)); }   // path switch: drain
+    e->last_fuse = (int)fuse;
+    float2* d1 = (e->calls & 1) ? e->dec1b.p : e->dec1.p;   // call k+1's stage 1 (qa) may overwrite nothing call k's back half (qb) reads
+    const int hin = e->hist_cur, hout = e->hist_cur ^ 1;
+    // spectrum collection rides in the final stage's epilogue unless the DC blocker must see the samples first
+    float2* feed = (e->cfg.enable_spectrum && !any_dc) ? e->fft_in.p : nullptr;
     if (nst == 0) {
         if (e->timing_on) HD_HIP(hipEventRecord(sl.t1, qa));
         hd::launch_passthrough(qa, S, max_in, iq, stride, fcur, e->fbuf_stride, dcall, e->fir_hist_cap);
         if (e->timing_on) HD_HIP(hipEventRecord(sl.t2, qa));
     } else {
         const bool single = nst == 1;
-        float2* out1 = single ? fcur : e->dec1.p;
+        float2* out1 = single ? fcur : d1;
         const size_t out1_stride = single ? e->fbuf_stride : e->n1_cap;
         if (e->timing_on) HD_HIP(hipEventRecord(sl.t1, qa));
-        const int hin = e->hist_cur, hout = e->hist_cur ^ 1;
-        // spectrum collection rides in the final stage's epilogue unless the DC blocker must see the samples first
-        float2* feed = (e->cfg.enable_spectrum && !any_dc) ? e->fft_in.p : nullptr;
         if (!hd::launch_decimate(qa, R1, T1, S, max_n1, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
                                  dcall, 0, single ? 1 : 0, e->fir_hist_cap, single ? feed : nullptr))
             return fail(HD_ERR_INVALID, "no kernel for this decimation stage");
         if (e->timing_on) HD_HIP(hipEventRecord(sl.t2, qa));
-        if (!single) {
-            if (!hd::launch_decimate(qa, R2, T2, S, max_n2, e->dec1.p, e->n1_cap, e->hist2[hin].p, e->hist2[hout].p, e->stage_taps[1].p, fcur,
+        if (!single && !fuse) {
+            if (!hd::launch_decimate(qa, R2, T2, S, max_n2, d1, e->n1_cap, e->hist2[hin].p, e->hist2[hout].p, e->stage_taps[1].p, fcur,
                                      e->fbuf_stride, dcall, 1, 1, e->fir_hist_cap, feed))
                 return fail(HD_ERR_INVALID, "no kernel for this decimation stage");
         }
     }
     mark();
-    if (any_dc) hd::launch_dc_remove(qa, S, fcur, e->fbuf_stride, dcall, e->fir_hist_cap);
-    if (e->cfg.enable_spectrum && max_n2) {
-        if (any_dc || nst == 0) hd::launch_fft_feed(qa, S, fcur, e->fbuf_stride, e->fft_in.p, dcall, e->fir_hist_cap);
+    auto spectrum = [&](hipStream_t q) -> int {
+        if (!(e->cfg.enable_spectrum && max_n2)) return HD_OK;
+        if (!fuse && (any_dc || nst == 0)) hd::launch_fft_feed(q, S, fcur, e->fbuf_stride, e->fft_in.p, dcall, e->fir_hist_cap);
         if (any_fft) {   // only when some stream's 4096-sample buffer completed (every call at >= 4096 decimated samples per push)
             void* in[1] = {e->fft_in.p};
             void* outb[1] = {e->fft_raw.p};
+            rocfft_execution_info_set_stream(e->fft_info, q);
             if (rocfft_execute(e->fft_plan, in, outb, e->fft_info) != rocfft_status_success) return fail(HD_ERR_DEVICE, "rocfft_execute failed");
-            hd::launch_spectrum_commit(qa, S, e->fft_raw.p, e->spec.p, e->power.p, sl.h_stats.dev, dcall, e->fsd, e->bins_sep);
+            hd::launch_spectrum_commit(q, S, e->fft_raw.p, e->spec.p, e->power.p, sl.h_stats.dev, dcall, e->fsd, e->bins_sep);
         }
+        return HD_OK;
+    };
+    if (!fuse) {
+        if (any_dc) hd::launch_dc_remove(qa, S, fcur, e->fbuf_stride, dcall, e->fir_hist_cap);
+        if (const int r = spectrum(qa)) return r;
     }
     mark();
     if (!e->one_stream) HD_HIP(hipEventRecord(sl.ev_front, qa));
     const auto h2 = std::chrono::steady_clock::now();
-    // ---- back half on qb: low-pass + discriminator, buffer slide, symbol extractor, results.  It may still be running
-    // when the NEXT call's front half starts on qa: the two halves touch disjoint buffers (DESIGN.md "two-stream pipeline").
+    // ---- back half on qb: [stage 2 +] low-pass + discriminator + buffer slide, [spectrum,] symbol extractor, results.  It may
+    // still be running when the NEXT call's front half starts on qa: the two halves touch disjoint buffers (DESIGN.md
+    // "two-stream pipeline").
     if (!e->one_stream) HD_HIP(hipStreamWaitEvent(qb, sl.ev_front, 0));
     mark();
     const int cin = e->carry_cur, cout = e->carry_cur ^ 1;
-    hd::launch_fir_demod(qb, S, max_m, max_taps, fcur, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S,
-                         e->cfg.keep_filtered ? e->filtered.p : nullptr, e->carry[cin].p, e->carry[cout].p, dcall, e->fir_hist_cap,
-                         e->tail.p, e->tail_cap, e->d_symstate.p, fnext);
+    if (fuse) {
+        if (!hd::launch_backend(qb, (int)R2, (int)T2, S, max_n1, max_n2, max_taps, d1, e->n1_cap, e->hist2[hin].p, e->hist2[hout].p,
+                                e->stage_taps[1].p, fcur, fcur, fnext, e->fbuf_stride, e->fir_hist_cap, e->lp_taps.p, e->taps_cap, e->demod.p,
+                                e->demod.n / S, e->cfg.keep_filtered ? e->filtered.p : nullptr, e->carry[cin].p, e->carry[cout].p, dcall, feed,
+                                e->tail.p, e->tail_cap, e->d_symstate.p))
+            return fail(HD_ERR_INVALID, "fused back end refused a shape it was selected for");
+        if (const int r = spectrum(qb)) return r;
+    } else {
+        hd::launch_fir_demod(qb, S, max_m, max_taps, fcur, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S,
+                             e->cfg.keep_filtered ? e->filtered.p : nullptr, e->carry[cin].p, e->carry[cout].p, dcall, e->fir_hist_cap,
+                             e->tail.p, e->tail_cap, e->d_symstate.p, fnext);
+    }
     mark();
     mark();
     hd::launch_symbols(qb, S, max_m, max_new, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p,
