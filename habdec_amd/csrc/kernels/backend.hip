@@ -28,6 +28,14 @@ constexpr int kBePass = 2 * kBeLanes;            // low-pass outputs per pass: t
     a0r = a0r + (P).z * (k1); a0i = a0i + (P).w * (k1); \
     a1r = a1r + (N).x * (k1); a1i = a1i + (N).y * (k1);
 
+#ifdef HD_STAMP_BE   // diagnostic build only (tools/micro/be_stamps.py): s_memtime at the phase boundaries, per stream
+__device__ unsigned long long g_be_stamps[8192 * 8];
+#define BSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_be_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" void hd_debug_be_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_be_stamps), n * 8); }
+#else
+#define BSTAMP(i) do { } while (0)
+#endif
+
 template <int D2, int T2>
 __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__ dec1, size_t dec1_stride,
                                                        const float2* __restrict__ hist2_in, float2* __restrict__ hist2_out,
@@ -56,9 +64,28 @@ __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__
     const uint32_t H = T ? T - 1 : 0;                       // low-pass history length in use
     const uint32_t f_old = H + pb;                          // fin slots that come from global memory
 
-    // ---- every global read, issued back to back: stage-2 history, the stage-1 chunk (16-byte loads), low-pass history + pending
+    BSTAMP(0);
+    // ---- every global read, issued back to back: stage-2 history, the stage-1 chunk (16-byte loads), low-pass history +
+    // pending, the deep part of the slide (buffer -> buffer), and one word per 64-byte line of this stream's low-pass taps
+    // (each stream has its own tap vector: without the touch the tap loop's first pass waits on a scalar-cache miss per block)
+    const float* tp = lp_taps + (size_t)s * taps_stride;
+    const uint32_t sl_cnt = fir_hist_cap + c.pend_after, sl_off = c.clear_pending ? 0u : m;
+    const uint32_t lds_from = fir_hist_cap - H;             // buffer indices from here on are imaged in `fin`
+    const uint32_t sl_deep = lds_from > sl_off ? min(lds_from - sl_off, sl_cnt) : 0u;   // slide elements whose source is below the image
+    float tap_touch = 0.f;
     {
-        constexpr int XB = 6, FB = 3;                       // covers n1 <= 3072 and H + pending <= 768 in the first batch
+        constexpr int XB = 6, FB = 3, SB = 6;               // first batch covers n1 <= 3072, H + pending <= 768, 1536 deep slide elements
+        {   // unconditional, independent scalar loads (index clamped into the stream's tap vector): issued back to back
+            const uint32_t tl = T ? T - 1 : 0;
+            float tt[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) tt[u] = tp[min((uint32_t)u * 16u, tl)];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) tap_touch += tt[u];
+        }
+        float2 ts[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) { const uint32_t k = tid + u * kBeLanes; ts[u] = k < sl_deep ? cur[k + sl_off] : make_float2(0.f, 0.f); }
         float2 th = make_float2(0.f, 0.f);
         if (tid < (uint32_t)(T2 - 1) && !c.zero_hist2) th = hist2_in[(size_t)s * (T2 - 1) + tid];
         float4 tx[XB];
@@ -75,6 +102,9 @@ __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__
         }
         if (tid < (uint32_t)(T2 - 1)) xin[tid] = th;
 #pragma unroll
+        for (int u = 0; u < SB; ++u) { const uint32_t k = tid + u * kBeLanes; if (k < sl_deep) nxt[k] = ts[u]; }
+        for (uint32_t k = tid + SB * kBeLanes; k < sl_deep; k += kBeLanes) nxt[k] = cur[k + sl_off];
+#pragma unroll
         for (int u = 0; u < XB; ++u) {
             const uint32_t k = tid + u * kBeLanes;
             if (k < n1p) { xin[(T2 - 1) + 2 * k] = make_float2(tx[u].x, tx[u].y); xin[(T2 - 1) + 2 * k + 1] = make_float2(tx[u].z, tx[u].w); }
@@ -89,28 +119,51 @@ __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__
             fin[k] = (c.fir_zero_hist && k < H) ? make_float2(0.f, 0.f) : cur[fir_hist_cap - H + k];
     }
     __syncthreads();
+    BSTAMP(1);
 
-    // ---- stage-2 decimation: y2[o] = sum_t x[o*D2 + t] * h2[t], one output per lane and step
+    // ---- stage-2 decimation: y2[o] = sum_t x[o*D2 + t] * h2[t], one output per lane and step.  Lane o starts at sample
+    // o*D2 (even), so its samples come as 16-byte pairs; for D2 = 2 consecutive lanes read consecutive pairs (conflict-free).
+    // Taps are consumed eight at a time in a rolled loop: only eight of them are live in scalar registers.
     float2* y2 = fin + f_old;
-    for (uint32_t o = tid; o < n2; o += kBeLanes) {
-        const float2* p = xin + (size_t)o * D2;
-        float ar = 0.f, ai = 0.f;
+    for (uint32_t o = tid; o < n2; o += 2 * kBeLanes) {     // two outputs (o, o + 256) share each block of taps
+        const bool has_b = o + kBeLanes < n2;
+        const float4* p4 = reinterpret_cast<const float4*>(xin + (size_t)o * D2);
+        const float4* q4 = has_b ? reinterpret_cast<const float4*>(xin + (size_t)(o + kBeLanes) * D2) : p4;
+        float ar = 0.f, ai = 0.f, br = 0.f, bi = 0.f;
         int t = 0;
+#pragma unroll 1
         for (; t + 8 <= T2; t += 8) {
-            float2 x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = p[t + u];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { ar = ar + x[u].x * taps2[t + u]; ai = ai + x[u].y * taps2[t + u]; }
+            const float4 x0 = p4[(t >> 1)], x1 = p4[(t >> 1) + 1], x2 = p4[(t >> 1) + 2], x3 = p4[(t >> 1) + 3];
+            const float4 z0 = q4[(t >> 1)], z1 = q4[(t >> 1) + 1], z2 = q4[(t >> 1) + 2], z3 = q4[(t >> 1) + 3];
+            const float* tb = taps2 + t;
+            const float k0 = tb[0], k1 = tb[1], k2 = tb[2], k3 = tb[3], k4 = tb[4], k5 = tb[5], k6 = tb[6], k7 = tb[7];
+            ar = ar + x0.x * k0; ai = ai + x0.y * k0; br = br + z0.x * k0; bi = bi + z0.y * k0;
+            ar = ar + x0.z * k1; ai = ai + x0.w * k1; br = br + z0.z * k1; bi = bi + z0.w * k1;
+            ar = ar + x1.x * k2; ai = ai + x1.y * k2; br = br + z1.x * k2; bi = bi + z1.y * k2;
+            ar = ar + x1.z * k3; ai = ai + x1.w * k3; br = br + z1.z * k3; bi = bi + z1.w * k3;
+            ar = ar + x2.x * k4; ai = ai + x2.y * k4; br = br + z2.x * k4; bi = bi + z2.y * k4;
+            ar = ar + x2.z * k5; ai = ai + x2.w * k5; br = br + z2.z * k5; bi = bi + z2.w * k5;
+            ar = ar + x3.x * k6; ai = ai + x3.y * k6; br = br + z3.x * k6; bi = bi + z3.y * k6;
+            ar = ar + x3.z * k7; ai = ai + x3.w * k7; br = br + z3.z * k7; bi = bi + z3.w * k7;
         }
 #pragma unroll
-        for (int u = 0; u < T2 % 8; ++u) { const float2 x = p[t + u]; ar = ar + x.x * taps2[t + u]; ai = ai + x.y * taps2[t + u]; }
-        const float2 y = make_float2(ar, ai);
-        y2[o] = y;
-        cur_w[fir_hist_cap + pb + o] = y;                   // the decimated chunk stays readable (getters, unfused path next call)
-        if (fft_in && o < c.fft_take) fft_in[(size_t)s * kFftBins + c.fft_fill + o] = y;   // reference Decoder.h:467-473
+        for (int u = 0; u < (T2 % 8); u += 2) {            // t is even here
+            const float4 x = p4[(t + u) >> 1], z = q4[(t + u) >> 1];
+            ar = ar + x.x * taps2[t + u]; ai = ai + x.y * taps2[t + u]; br = br + z.x * taps2[t + u]; bi = bi + z.y * taps2[t + u];
+            if (u + 1 < (T2 % 8)) {
+                ar = ar + x.z * taps2[t + u + 1]; ai = ai + x.w * taps2[t + u + 1]; br = br + z.z * taps2[t + u + 1]; bi = bi + z.w * taps2[t + u + 1];
+            }
+        }
+        auto emit = [&](uint32_t oo, float2 y) {
+            y2[oo] = y;
+            cur_w[fir_hist_cap + pb + oo] = y;              // the decimated chunk stays readable (getters, unfused path next call)
+            if (fft_in && oo < c.fft_take) fft_in[(size_t)s * kFftBins + c.fft_fill + oo] = y;   // reference Decoder.h:467-473
+        };
+        emit(o, make_float2(ar, ai));
+        if (has_b) emit(o + kBeLanes, make_float2(br, bi));
     }
     __syncthreads();
+    BSTAMP(2);
 
     // ---- stage-2 history carry for the next call (Decimator.h:140-143, with the in-place quirk Q4 of Decoder.h:443-444)
     if (n1) {
@@ -122,29 +175,27 @@ __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__
         hist2_out[(size_t)s * (T2 - 1) + tid] = hist2_in[(size_t)s * (T2 - 1) + tid];      // idle stream: passes through
     }
 
-    // ---- slide [history | leftover pending] to the front of the other buffer: next[k] = buf[k + fir_m]
-    {
-        const uint32_t cnt = fir_hist_cap + c.pend_after, off = c.clear_pending ? 0u : m;
-        const uint32_t lds_from = fir_hist_cap - H;         // buffer indices from here on are in `fin`
-        for (uint32_t k = tid; k < cnt; k += kBeLanes) {
-            const uint32_t j = k + off;
-            float2 v;
-            if (j >= lds_from && j - lds_from < f_old + n2) {
-                v = fin[j - lds_from];
-                if (c.fir_zero_hist && j < fir_hist_cap) v = cur[j];     // the image holds zeros there; the slide moves the buffer as it is
-            } else v = cur[j];
-            nxt[k] = v;
-        }
+    // ---- slide [history | leftover pending] to the front of the other buffer: next[k] = buf[k + fir_m]; the deep part went
+    // buffer to buffer with the first batch, the rest comes from the LDS image (which also holds this call's new samples)
+    for (uint32_t k = sl_deep + tid; k < sl_cnt; k += kBeLanes) {
+        const uint32_t j = k + sl_off;                      // >= lds_from
+        float2 v = make_float2(0.f, 0.f);
+        if (j - lds_from < f_old + n2) {
+            v = fin[j - lds_from];
+            if (c.fir_zero_hist && j < fir_hist_cap) v = cur[j];         // the image holds zeros there; the slide moves the buffer as it is
+        } else v = cur[j];
+        nxt[k] = v;
     }
     if (!m || !T) {
         if (tid == 0) carry_out[s] = carry_in[s];           // low-pass did not run: discriminator carry passes through
         return;
     }
 
+    BSTAMP(3);
     // ---- low-pass + discriminator, kBePass outputs per pass, two adjacent outputs per lane (see fir_demod.hip)
     __syncthreads();                                        // xin is free now: reused for a pass's outputs
     float2* yout = xin;
-    const float* tp = lp_taps + (size_t)s * taps_stride;
+    if (tap_touch == 12345.678f) demod[0] = tap_touch;      // keeps the tap touch alive; never true for a low-pass design
     const DemodCarry kin = carry_in[s];
     const SymState st = sym_ring ? sym[s] : SymState{};
     for (uint32_t i0 = 0; i0 < m; i0 += kBePass) {
@@ -190,6 +241,7 @@ __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__
             reinterpret_cast<float4*>(yout)[tid] = make_float4(a0r, a0i, a1r, a1i);
         }
         __syncthreads();
+        if (i0 == 0) BSTAMP(4);
         if (active) {
             const uint32_t i = i0 + 2 * tid;
             float pr, pi;
@@ -220,9 +272,11 @@ __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__
             }
         }
         __syncthreads();                                    // yout is read above; the next pass rewrites it
+        if (i0 == 0) BSTAMP(5);
         if (tid == kBeLanes - 1 && i0 + kBePass < m) s_ylast = make_float2(a1r, a1i);   // (a full pass: lane 255 holds its last output)
         // s_ylast is read by lane 0 only behind the next pass's barrier
     }
+    BSTAMP(6);
 }
 
 size_t backend_lds_bytes(int ntaps2, uint32_t max_n1, uint32_t max_n2, uint32_t max_taps)
