@@ -263,6 +263,8 @@ static void launch_one(hipStream_t st, uint32_t n_streams, uint32_t max_out, con
     // 256 CUs x ~4 resident workgroups; keep >= ~2048 workgroups when the batch allows it.
     uint32_t per = 1;
     while (per < 16 && (uint64_t)((ntiles + 2 * per - 1) / (2 * per)) * n_streams >= 2048) per *= 2;
+    static const uint32_t per_env = [] { const char* v = getenv("HD_DEC_PER"); return v ? (uint32_t)atoi(v) : 0u; }();   // experiment knob
+    if (per_env && TO == 64) per = per_env;
     dim3 grid((ntiles + per - 1) / per, n_streams);
     static const size_t pad_lds = [] { const char* v = getenv("HD_DEC_PAD_LDS"); return v ? (size_t)atoi(v) : (size_t)0; }();   // experiment knob
     hipLaunchKernelGGL((k_decimate<D, T, TO>), grid, dim3(TO), TO == 64 ? pad_lds : 0, st, in, in_stride, hist_in, hist_out, taps, out, out_stride, call,
