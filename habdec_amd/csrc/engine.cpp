@@ -111,7 +111,7 @@ struct hd_engine {
     bool one_stream = false;
     bool no_fuse = false;      // HD_NO_FUSE: never use the fused back end (kernels/backend.hip); A/B measurements
     int last_fuse = -1;        // path of the previous call (the two paths use the stage-2 buffers on different queues)
-    hipStream_t qa = nullptr, qb = nullptr;   // front (decimation, spectrum) and back (FIR, symbols, results) HIP streams
+    hipStream_t qa = nullptr, qb = nullptr, qc = nullptr;   // front (decimation, spectrum) and back (FIR, symbols, results) HIP streams
     bool timing_on = true;
     hd_timing last_timing{};
     rocfft_plan fft_plan = nullptr;
@@ -133,11 +133,11 @@ struct hd_engine {
         PinBuf<hd::StreamCall> h_call;
         PinBuf<uint32_t> h_slots;                 // written by the symbol scan kernel over PCIe (zero-copy), read after ev_done
         PinBuf<hd::SpectrumStatsDev> h_stats;    // written by the spectrum kernel
-        hipEvent_t ev_front = nullptr, ev_done = nullptr, t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr;
+        hipEvent_t ev_front = nullptr, ev_done = nullptr, ev_params = nullptr, t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr;
         bool busy = false;
         uint64_t total_in = 0;
         uint32_t r1 = 1;
-        ~CallSlot() { for (hipEvent_t ev : {ev_front, ev_done, t0, t1, t2, t3}) if (ev) (void)hipEventDestroy(ev); }
+        ~CallSlot() { for (hipEvent_t ev : {ev_front, ev_done, ev_params, t0, t1, t2, t3}) if (ev) (void)hipEventDestroy(ev); }
     } slot[3];
     static constexpr int kSlots = 3;
     uint64_t calls = 0;
@@ -159,6 +159,7 @@ struct hd_engine {
         if (fft_info) rocfft_execution_info_destroy(fft_info);
         if (qa) (void)hipStreamDestroy(qa);
         if (qb && qb != qa) (void)hipStreamDestroy(qb);
+        if (qc && qc != qa) (void)hipStreamDestroy(qc);
     }
 };
 
@@ -235,11 +236,15 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     HD_HIP(hipStreamCreateWithFlags(&e->qa, hipStreamNonBlocking));
     e->one_stream = getenv("HD_ONE_STREAM") != nullptr;
     e->no_fuse = getenv("HD_NO_FUSE") != nullptr;
-    if (e->one_stream) e->qb = e->qa; else
-    HD_HIP(hipStreamCreateWithFlags(&e->qb, hipStreamNonBlocking));
+    if (e->one_stream) e->qb = e->qc = e->qa;
+    else {
+        HD_HIP(hipStreamCreateWithFlags(&e->qb, hipStreamNonBlocking));
+        HD_HIP(hipStreamCreateWithFlags(&e->qc, hipStreamNonBlocking));   // parameter fetches: tiny kernels that need not queue behind stage 1
+    }
     for (auto& sl : e->slot) {
         HD_HIP(hipEventCreateWithFlags(&sl.ev_front, hipEventDisableTiming));
         HD_HIP(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+        HD_HIP(hipEventCreateWithFlags(&sl.ev_params, hipEventDisableTiming));
         for (hipEvent_t* ev : {&sl.t0, &sl.t1, &sl.t2, &sl.t3}) HD_HIP(hipEventCreate(ev));
     }
 
@@ -624,7 +629,9 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     // back half of call k-2 is still reading (same ping-pong parity): order it behind that call's completion.
     if (e->calls >= 2 && !e->one_stream) HD_HIP(hipStreamWaitEvent(qa, e->slot[(e->calls - 2) % hd_engine::kSlots].ev_done, 0));
     if (e->timing_on) HD_HIP(hipEventRecord(sl.t0, qa));
-    hd::launch_fetch_params(qa, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
+    // the parameter block is pulled on its own queue, so it does not wait for the previous call's stage 1 to drain
+    hd::launch_fetch_params(e->qc, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
+    if (!e->one_stream) { HD_HIP(hipEventRecord(sl.ev_params, e->qc)); HD_HIP(hipStreamWaitEvent(qa, sl.ev_params, 0)); }
     for (uint32_t s = 0; s < S; ++s) {
         StreamHost& st = e->st[s];
         if (!st.taps_dirty) continue;

@@ -18,3 +18,10 @@ per = st[:, 3:7] / st[:, 7:8]
 print("cycles per tile per wave [wait prefetched tile, stage to LDS+barrier, store+issue next loads, compute]:", per.mean(axis=0).round(0).tolist(), "sum", per.sum(axis=1).mean().round(0))
 first = st[0::2]; second = st[1::2]
 print("stream-first WGs: end %.1f us ; second WGs: end %.1f us" % (np.median(first[:, 2] - t0) / 100.0, np.median(second[:, 2] - t0) / 100.0))
+# does the finishing time depend on where the workgroup ran?  (workgroups are dealt round-robin to the 8 XCDs)
+w_all = np.arange(4096)[:len(st)]
+end = (st[:, 2] - t0) / 100.0
+print("mean end (us) by workgroup id mod 8:", [round(float(end[w_all % 8 == j].mean()), 1) for j in range(8)])
+print("std of end within an XCD class:", [round(float(end[w_all % 8 == j].std()), 1) for j in range(8)])
+print("mean end by (id // 8) mod 4:", [round(float(end[(w_all // 8) % 4 == j].mean()), 1) for j in range(4)])
+print("mean end by id // 256 (dispatch order octiles):", [round(float(end[w_all // 256 == j].mean()), 1) for j in range(8)])
