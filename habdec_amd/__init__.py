@@ -7,6 +7,6 @@ synthetic IQ generator.  There is no Python or CPU implementation of the data pa
 `lib()` raises.
 """
 from .capi import lib, LIB_PATH, HabdecError  # noqa: F401
-from .engine import Engine, EngineConfig  # noqa: F401
+from .engine import Engine, EngineConfig, IqFiles  # noqa: F401
 
-__all__ = ["lib", "LIB_PATH", "HabdecError", "Engine", "EngineConfig"]
+__all__ = ["lib", "LIB_PATH", "HabdecError", "Engine", "EngineConfig", "IqFiles"]

@@ -59,6 +59,7 @@ ENGINE_API = {
     "hd_process_host": (_int, [_vp, _vp, _sz, _vp, _u32]),
     "hd_process_device": (_int, [_vp, _vp, _sz, _vp, _u32]),
     "hd_flush": (_int, [_vp]),
+    "hd_ingest_run": (_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "hd_stream_rtty": (_sz, [_vp, _u32, C.c_char_p, _sz]),
     "hd_stream_last_sentence": (_sz, [_vp, _u32, C.c_char_p, _sz]),
     "hd_stream_take_sentences": (_sz, [_vp, _u32, C.c_char_p, _sz]),
@@ -99,6 +100,12 @@ HOST_API = {
     "hd_host_afc_get": (None, [_vp] + [C.POINTER(_dbl)] * 4 + [C.POINTER(_int)] * 2),
     "hd_host_atan2f": (None, [_f32p, _f32p, _f32p, _sz]),
     "hd_host_discriminate": (None, [_f32p, _sz, _f, _f, _f32p]),
+    "hd_host_iqfiles_open": (_vp, [C.POINTER(C.c_char_p), C.c_uint32, _int, C.c_uint32, C.c_uint32, _dbl]),
+    "hd_host_iqfiles_close": (None, [_vp]),
+    "hd_host_iqfiles_streams": (C.c_uint32, [_vp]),
+    "hd_host_iqfiles_count": (C.c_uint64, [_vp, C.c_uint32]),
+    "hd_host_iqfiles_rewinds": (C.c_uint64, [_vp, C.c_uint32]),
+    "hd_host_iqfiles_next": (C.c_uint32, [_vp, _f32p, _sz, C.POINTER(C.c_uint32)]),
 }
 
 

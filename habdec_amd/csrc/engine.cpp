@@ -16,7 +16,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -25,6 +27,7 @@
 #include "host/afc_tracker.hpp"
 #include "host/decim_plan.hpp"
 #include "host/fir_design.hpp"
+#include "host/iq_file_batch.hpp"
 #include "host/text_stage.hpp"
 #include "kernels/launch.h"
 
@@ -779,6 +782,82 @@ int hd_process_host(hd_engine* e, const float* iq, size_t stride, const uint32_t
         }
     }
     return hd_process_device(e, e->staging.p, dstride, n_per_stream, n_uniform);
+}
+
+/* ---------------------------------------------------------------- batched file ingest -------------------------- */
+
+int hd_ingest_run(hd_engine* e, hd_host_iqfiles* src, uint64_t max_rounds, uint64_t* samples_done)
+{
+    if (samples_done) *samples_done = 0;
+    if (!e || !src) return fail(HD_ERR_INVALID, "null engine or file batch");
+    const uint32_t S = e->S;
+    if (src->batch.streams() != S) return fail(HD_ERR_INVALID, "the file batch must hold one file per stream");
+    if (src->batch.chunk() > e->cfg.max_chunk) return fail(HD_ERR_CAPACITY, "file batch chunk larger than max_chunk");
+    HD_HIP(hipSetDevice(e->cfg.device));
+    constexpr int kSlabs = 4;      // round r's slab is refilled for round r+4: by then call r is delivered even with two calls in flight
+    const size_t stride = src->batch.chunk();
+    struct Slab { float* iq = nullptr; std::vector<uint32_t> n; uint32_t alive = 0; };
+    Slab slab[kSlabs];
+    auto release = [&] { for (auto& b : slab) if (b.iq) (void)hipHostFree(b.iq); };
+    for (auto& b : slab) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&b.iq), (size_t)S * stride * sizeof(float2), hipHostMallocDefault) != hipSuccess) {
+            release();
+            return fail(HD_ERR_DEVICE, "pinned slab allocation failed");
+        }
+        b.n.assign(S, 0);
+    }
+    std::mutex m;
+    std::condition_variable cv;
+    uint64_t filled = 0, consumed = 0;       // rounds read by the reader / handed back by the pump
+    bool stop = false;
+    std::thread reader([&] {
+        for (uint64_t r = 0;; ++r) {
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv.wait(l, [&] { return stop || r < consumed + (uint64_t)kSlabs - 2; });   // two slabs may still belong to calls in flight
+                if (stop) return;
+            }
+            Slab& b = slab[r % kSlabs];
+            b.alive = src->batch.next(b.iq, stride, b.n.data());
+            {
+                std::lock_guard<std::mutex> l(m);
+                filled = r + 1;
+            }
+            cv.notify_all();
+            if (!b.alive) return;
+        }
+    });
+    int rc = HD_OK;
+    uint64_t total = 0;
+    for (uint64_t r = 0; r < max_rounds; ++r) {
+        {
+            std::unique_lock<std::mutex> l(m);
+            cv.wait(l, [&] { return filled > r; });
+        }
+        Slab& b = slab[r % kSlabs];
+        if (!b.alive) break;
+        bool uniform = true;
+        for (uint32_t s = 1; s < S; ++s) uniform = uniform && b.n[s] == b.n[0];
+        rc = hd_process_host(e, b.iq, stride, uniform ? nullptr : b.n.data(), uniform ? b.n[0] : 0);
+        if (rc) break;
+        for (uint32_t s = 0; s < S; ++s) total += b.n[s];
+        {
+            std::lock_guard<std::mutex> l(m);
+            consumed = r + 1;
+        }
+        cv.notify_all();
+    }
+    {
+        std::lock_guard<std::mutex> l(m);
+        stop = true;
+    }
+    cv.notify_all();
+    reader.join();
+    const int rf = hd_flush(e);      // nothing may still copy from the slabs when they are freed
+    HD_HIP(hipDeviceSynchronize());
+    release();
+    if (samples_done) *samples_done = total;
+    return rc ? rc : rf;
 }
 
 /* ---------------------------------------------------------------- results -------------------------------------- */

@@ -8,6 +8,7 @@
 #include "host/decim_plan.hpp"
 #include "host/fir_design.hpp"
 #include "host/text_stage.hpp"
+#include "host/iq_file_batch.hpp"
 #include "kernels/exact_math.h"
 
 struct hd_host_rtty { hd::RttyFramer f; };
@@ -107,6 +108,26 @@ void hd_host_atan2f(const float* y, const float* x, float* out, size_t n) { for 
 void hd_host_discriminate(const float* iq, size_t n, float pr, float pi, float* out)
 {
     for (size_t i = 0; i < n; ++i) { out[i] = hd::discriminate(iq[2 * i], iq[2 * i + 1], pr, pi); pr = iq[2 * i]; pi = iq[2 * i + 1]; }
+}
+
+/* ---- batched cf32 file ingest (IQSource_File.h:124-172 per file; see host/iq_file_batch.hpp) ---- */
+hd_host_iqfiles* hd_host_iqfiles_open(const char* const* paths, uint32_t n_files, int loop, uint32_t chunk, uint32_t granule, double realtime_rate)
+{
+    if (!paths || !n_files) return nullptr;
+    std::vector<std::string> v;
+    for (uint32_t i = 0; i < n_files; ++i) { if (!paths[i]) return nullptr; v.emplace_back(paths[i]); }
+    auto* h = new hd_host_iqfiles;
+    if (!h->batch.open(v, loop != 0, chunk, granule, realtime_rate)) { delete h; return nullptr; }
+    return h;
+}
+void hd_host_iqfiles_close(hd_host_iqfiles* h) { delete h; }
+uint32_t hd_host_iqfiles_streams(const hd_host_iqfiles* h) { return h ? h->batch.streams() : 0; }
+uint64_t hd_host_iqfiles_count(const hd_host_iqfiles* h, uint32_t stream) { return (h && stream < h->batch.streams()) ? h->batch.file(stream).count() : 0; }
+uint64_t hd_host_iqfiles_rewinds(const hd_host_iqfiles* h, uint32_t stream) { return (h && stream < h->batch.streams()) ? h->batch.file(stream).rewinds() : 0; }
+uint32_t hd_host_iqfiles_next(hd_host_iqfiles* h, float* slab, size_t stride, uint32_t* n_per_stream)
+{
+    if (!h || !slab || !n_per_stream || stride < h->batch.chunk()) return 0;
+    return h->batch.next(slab, stride, n_per_stream);
 }
 
 }  // extern "C"

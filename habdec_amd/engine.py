@@ -7,7 +7,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import capi
-from .capi import check, lib
+from .capi import HabdecError, check, lib
 
 
 @dataclass
@@ -71,6 +71,13 @@ class Engine:
 
     def process_device(self, dev_ptr: int, stride: int, n: int):
         check(self.L.hd_process_device(self.h, dev_ptr, stride, None, n))
+
+    def ingest(self, files: "IqFiles", max_rounds: int = 1 << 62) -> int:
+        """Pump a batch of cf32 files (one per stream) through the engine (hd_ingest_run); returns the samples consumed."""
+        import ctypes as C
+        done = C.c_uint64(0)
+        check(self.L.hd_ingest_run(self.h, files.h, max_rounds, C.byref(done)))
+        return int(done.value)
 
     def flush(self):
         check(self.L.hd_flush(self.h))
@@ -142,3 +149,39 @@ class Engine:
         check(self.L.hd_engine_timing(self.h, C.byref(t)))
         return {"ms_total": t.ms_total, "ms_front": t.ms_front, "front_bytes": t.front_bytes, "samples": t.samples,
                 "host_enqueue_us": t.host_enqueue_us, "host_wait_us": t.host_wait_us, "host_text_us": t.host_text_us}
+
+
+class IqFiles:
+    """Batched cf32 file source (hd_host_iqfiles_*): one IQSource_File-like reader per stream, read in lock step."""
+
+    def __init__(self, paths, chunk: int, granule: int, loop: bool = False, realtime_rate: float = 0.0):
+        import ctypes as C
+        self.L = lib()
+        arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
+        self.h = self.L.hd_host_iqfiles_open(arr, len(paths), int(loop), chunk, granule, realtime_rate)
+        if not self.h:
+            raise HabdecError("hd_host_iqfiles_open failed (missing file, chunk < granule, ...)")
+        self.S, self.chunk = len(paths), chunk
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.hd_host_iqfiles_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def count(self, s: int) -> int: return int(self.L.hd_host_iqfiles_count(self.h, s))
+    def rewinds(self, s: int) -> int: return int(self.L.hd_host_iqfiles_rewinds(self.h, s))
+
+    def next(self, stride: int | None = None):
+        """One round: returns (slab complex64 [S, stride], n_per_stream uint32 [S], streams that read anything)."""
+        import ctypes as C
+        stride = stride or self.chunk
+        slab = np.zeros((self.S, stride), np.complex64)
+        n = np.zeros(self.S, np.uint32)
+        alive = self.L.hd_host_iqfiles_next(self.h, slab.view(np.float32), stride, n.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return slab, n, int(alive)

@@ -112,6 +112,15 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stream_stride, cons
  * device buffers flush implicitly. */
 int hd_flush(hd_engine* e);
 
+/* Batched file ingest: pump `src` (habdec_amd_host.h, hd_host_iqfiles_*; one file per stream, opened
+ * with chunk <= max_chunk and granule = the engine's decimation factor) through the engine until the files are exhausted
+ * or `max_rounds` rounds were pushed.  A reader thread fills pinned push slabs (four, so that a slab is never refilled
+ * while a pipelined call may still copy from it) while the calling thread runs hd_process_host on the previous one --
+ * file reads, the H2D copy and the GPU work overlap.  Text is delivered as by hd_process_host; ends with hd_flush.
+ * `samples_done` (optional) receives the IQ samples consumed over all streams. */
+struct hd_host_iqfiles;
+int hd_ingest_run(hd_engine* e, struct hd_host_iqfiles* src, uint64_t max_rounds, uint64_t* samples_done);
+
 /* ---- results: getRTTY / getLastSentence (Decoder.h:641-652) and the callback streams ---- */
 size_t hd_stream_rtty(hd_engine* e, uint32_t stream, char* buf, size_t cap);
 size_t hd_stream_last_sentence(hd_engine* e, uint32_t stream, char* buf, size_t cap);

@@ -56,6 +56,24 @@ void hd_host_afc_get(hd_host_afc*, double* correction, double* shift_hz, double*
 void hd_host_atan2f(const float* y, const float* x, float* out, size_t n);
 void hd_host_discriminate(const float* iq, size_t n, float prev_re, float prev_im, float* out);
 
+/* ---- batched cf32 file ingest: S IQ files -> one push slab per round ----
+ * Each file is an IQSource_File<float> (IQSource_File.h:124-172): raw interleaved float32 I,Q, no header; a read returns
+ * what is left, the end of file is noticed by the read that runs into it, and the NEXT read rewinds when `loop` (else
+ * returns 0).  `chunk` = samples requested per stream and round (the reference asks for 65536, main.cpp:235);
+ * `granule` = the decoder's total decimation factor: every stream delivers a whole multiple of it per round and the
+ * remainder is carried in front of its next round (what Decoder::process does with its queue, Decoder.h:429-435).
+ * `realtime_rate` > 0 throttles each round like IQSource_File.h:165-169; 0 = as fast as the files can be read. */
+typedef struct hd_host_iqfiles hd_host_iqfiles;
+hd_host_iqfiles* hd_host_iqfiles_open(const char* const* paths, uint32_t n_files, int loop, uint32_t chunk, uint32_t granule,
+                                      double realtime_rate);
+void hd_host_iqfiles_close(hd_host_iqfiles*);
+uint32_t hd_host_iqfiles_streams(const hd_host_iqfiles*);
+uint64_t hd_host_iqfiles_count(const hd_host_iqfiles*, uint32_t stream);     /* IQSource_File::count(): samples in the file */
+uint64_t hd_host_iqfiles_rewinds(const hd_host_iqfiles*, uint32_t stream);
+/* One round: slab[s*stride .. ] (stride in complex samples, >= chunk) receives stream s's samples, n_per_stream[s] how many
+ * (a multiple of granule).  Returns the number of streams that read anything (0: all files exhausted and not looping). */
+uint32_t hd_host_iqfiles_next(hd_host_iqfiles*, float* slab, size_t stride, uint32_t* n_per_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,122 @@
+"""Batched cf32 file ingest: hd_host_iqfiles_* against a restatement of the reference's
+IQSource_File<float>::get (code/IQSource/IQSource_File.h:124-172) -- std::ifstream end-of-file semantics included --
+and, on the GPU, hd_ingest_run against feeding the same samples directly."""
+import numpy as np
+import pytest
+
+
+class RefFile:
+    """IQSource_File::get restated: the eof flag is set by the read that runs into the end; the NEXT call rewinds."""
+
+    def __init__(self, data: np.ndarray, loop: bool):
+        self.d, self.loop, self.pos, self.eof = data, loop, 0, False
+
+    def get(self, want: int) -> np.ndarray:
+        if self.eof:
+            if not self.loop:
+                return self.d[:0]
+            self.eof, self.pos = False, 0
+        n = min(want, len(self.d))
+        out = self.d[self.pos:self.pos + n]
+        if len(out) < n:
+            self.eof = True                    # ifstream::read came up short: eofbit (and failbit)
+        self.pos += len(out)
+        return out
+
+
+def ref_rounds(datas, loop, chunk, granule, rounds):
+    files = [RefFile(d, loop) for d in datas]
+    carry = [d[:0] for d in datas]
+    out = []
+    for _ in range(rounds):
+        row, alive = [], 0
+        for s, f in enumerate(files):
+            got = f.get(chunk - len(carry[s]))
+            alive += len(got) > 0
+            tot = np.concatenate([carry[s], got])
+            use = len(tot) - len(tot) % granule
+            row.append(tot[:use])
+            carry[s] = tot[use:]
+        out.append((row, alive))
+    return out
+
+
+def write_files(tmp_path, lengths, seed=0):
+    rng = np.random.default_rng(seed)
+    datas, paths = [], []
+    for i, n in enumerate(lengths):
+        d = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        p = tmp_path / f"s{i}.cf32"
+        d.tofile(p)
+        datas.append(d); paths.append(p)
+    return datas, paths
+
+
+@pytest.mark.parametrize("loop", [False, True])
+@pytest.mark.parametrize("chunk,granule,lengths", [
+    (256, 64, [1000, 256 * 3, 100, 5000]),      # ragged tail / exact multiple (one empty read before the rewind) / shorter than a chunk
+    (4096, 64, [10000, 4096, 12288, 64]),
+    (300, 16, [999, 1200, 300, 17]),            # chunk not a multiple of the granule: remainders are carried
+])
+def test_rounds_match_reference_semantics(tmp_path, loop, chunk, granule, lengths):
+    import habdec_amd
+    datas, paths = write_files(tmp_path, lengths)
+    src = habdec_amd.IqFiles(paths, chunk=chunk, granule=granule, loop=loop)
+    assert [src.count(s) for s in range(len(lengths))] == lengths
+    for (row, alive), _ in zip(ref_rounds(datas, loop, chunk, granule, 40), range(40)):
+        slab, n, got_alive = src.next()
+        assert got_alive == alive
+        for s, want in enumerate(row):
+            assert n[s] == len(want) and n[s] % granule == 0
+            assert np.array_equal(slab[s, :n[s]].view(np.uint32), want.view(np.uint32))
+    if loop:
+        assert all(src.rewinds(s) > 0 for s in range(len(lengths)))
+
+
+def test_open_errors(tmp_path):
+    import habdec_amd
+    _, paths = write_files(tmp_path, [100])
+    with pytest.raises(habdec_amd.HabdecError):
+        habdec_amd.IqFiles([tmp_path / "missing.cf32"], chunk=64, granule=64)
+    with pytest.raises(habdec_amd.HabdecError):
+        habdec_amd.IqFiles(paths, chunk=32, granule=64)          # a round could never deliver a whole granule
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_ingest_run_decodes_like_direct_feeding(tmp_path, pipeline):
+    import habdec_amd
+    from habdec_amd import synth
+    fs, D, C, S = 2.048e6, 64, 65536, 6
+    iq = []
+    for s in range(S):
+        text = synth.make_sentence(f"FILE{s}", f"{s},52.1,21.{s}")
+        x = synth.fsk_iq(synth.rtty_bits(text * 2, 8, 2, 4, 4), fs, 300, seed=s, sigma=0.05)
+        iq.append(x[:len(x) - len(x) % 1000 + 1000 * (s % 3)])       # ragged lengths, not multiples of D
+    paths = []
+    for s, x in enumerate(iq):
+        p = tmp_path / f"f{s}.cf32"
+        x.astype(np.complex64).tofile(p); paths.append(p)
+    ref = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=D)
+    files = [RefFile(x.astype(np.complex64), False) for x in iq]
+    carry = [np.zeros(0, np.complex64)] * S
+    total = 0
+    while True:                                                     # the same rounds, fed through hd_process_host by hand
+        slab = np.zeros((S, C), np.complex64); n = np.zeros(S, np.uint32); alive = 0
+        for s in range(S):
+            got = files[s].get(C - len(carry[s])); alive += len(got) > 0
+            tot = np.concatenate([carry[s], got]); use = len(tot) - len(tot) % D
+            slab[s, :use] = tot[:use]; n[s] = use; carry[s] = tot[use:]
+        if not alive:
+            break
+        import ctypes as Ct
+        habdec_amd.capi.check(ref.L.hd_process_host(ref.h, slab.ctypes.data, C, n.ctypes.data_as(Ct.POINTER(Ct.c_uint32)), 0))
+        total += int(n.sum())
+    want = [ref.take_sentences(s) for s in range(S)]
+    assert sum(len(w) for w in want) >= S                            # the signals do decode
+
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=D, pipeline=pipeline)
+    src = habdec_amd.IqFiles(paths, chunk=C, granule=D)
+    assert eng.ingest(src) == total
+    assert [eng.take_sentences(s) for s in range(S)] == want
+    assert eng.rtty(0) == ref.rtty(0)
