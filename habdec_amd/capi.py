@@ -100,6 +100,11 @@ HOST_API = {
     "hd_host_afc_get": (None, [_vp] + [C.POINTER(_dbl)] * 4 + [C.POINTER(_int)] * 2),
     "hd_host_atan2f": (None, [_f32p, _f32p, _f32p, _sz]),
     "hd_host_discriminate": (None, [_f32p, _sz, _f, _f, _f32p]),
+    "hd_host_parse_time": (_int, [C.c_char_p, C.POINTER(_int), C.POINTER(_int), C.POINTER(_f)]),
+    "hd_host_parse_gps_pos": (_int, [C.c_char_p, C.POINTER(_f)]),
+    "hd_host_parse_sentence": (_int, [C.c_char_p, _vp]),
+    "hd_host_timestamp_from_hms": (_sz, [C.c_int64, _int, _int, _f, C.c_char_p, _sz]),
+    "hd_host_gps_distance": (None, [_dbl] * 6 + [C.POINTER(_dbl)]),
     "hd_host_iqfiles_open": (_vp, [C.POINTER(C.c_char_p), C.c_uint32, _int, C.c_uint32, C.c_uint32, _dbl]),
     "hd_host_iqfiles_close": (None, [_vp]),
     "hd_host_iqfiles_streams": (C.c_uint32, [_vp]),

@@ -7,6 +7,7 @@
 #include "host/afc_tracker.hpp"
 #include "host/decim_plan.hpp"
 #include "host/fir_design.hpp"
+#include "host/telemetry.hpp"
 #include "host/text_stage.hpp"
 #include "host/iq_file_batch.hpp"
 #include "kernels/exact_math.h"
@@ -108,6 +109,41 @@ void hd_host_atan2f(const float* y, const float* x, float* out, size_t n) { for 
 void hd_host_discriminate(const float* iq, size_t n, float pr, float pi, float* out)
 {
     for (size_t i = 0; i < n; ++i) { out[i] = hd::discriminate(iq[2 * i], iq[2 * i + 1], pr, pi); pr = iq[2 * i]; pi = iq[2 * i + 1]; }
+}
+
+/* ---- post-decode telemetry (sentence_parse.cpp, GpsDistance.cpp; see host/telemetry.hpp) ---- */
+int hd_host_parse_time(const char* text, int* hour, int* minute, float* second)
+{
+    if (!text || !hour || !minute || !second) return -1;
+    return (int)hd::telemetry::parse_time(text, *hour, *minute, *second);
+}
+int hd_host_parse_gps_pos(const char* text, float* out)
+{
+    if (!text || !out) return -1;
+    return (int)hd::telemetry::parse_gps_pos(text, *out);
+}
+int hd_host_parse_sentence(const char* sentence_without_crc, hd_host_telemetry* out)
+{
+    if (!sentence_without_crc || !out) return -1;
+    hd::telemetry::Fields f;
+    const auto st = hd::telemetry::parse_sentence(sentence_without_crc, f);
+    if (st != hd::telemetry::Status::Ok) return (int)st;
+    std::memset(out, 0, sizeof *out);
+    std::strncpy(out->callsign, f.callsign.c_str(), sizeof out->callsign - 1);
+    out->frame = f.frame; out->hour = f.hour; out->minute = f.minute; out->second = f.second;
+    out->lat = f.lat; out->lon = f.lon; out->alt = f.alt;
+    return 1;
+}
+size_t hd_host_timestamp_from_hms(int64_t now_unix, int hour, int minute, float second, char* buf, size_t cap)
+{
+    const std::string s = hd::telemetry::timestamp_from_hms(now_unix, hour, minute, second);
+    if (buf && cap) { const size_t n = std::min(cap - 1, s.size()); std::memcpy(buf, s.data(), n); buf[n] = 0; }
+    return s.size();
+}
+void hd_host_gps_distance(double lat1, double lon1, double alt1, double lat2, double lon2, double alt2, double out[5])
+{
+    const auto d = hd::telemetry::gps_distance(lat1, lon1, alt1, lat2, lon2, alt2);
+    out[0] = d.line; out[1] = d.circle; out[2] = d.radians; out[3] = d.elevation_deg; out[4] = d.bearing_deg;
 }
 
 /* ---- batched cf32 file ingest (IQSource_File.h:124-172 per file; see host/iq_file_batch.hpp) ---- */

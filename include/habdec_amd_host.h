@@ -56,6 +56,22 @@ void hd_host_afc_get(hd_host_afc*, double* correction, double* shift_hz, double*
 void hd_host_atan2f(const float* y, const float* x, float* out, size_t n);
 void hd_host_discriminate(const float* iq, size_t n, float prev_re, float prev_im, float* out);
 
+/* ---- post-decode telemetry ----
+ * Return convention of the parsers: 1 = parsed, 0 = the reference returns "nothing" (std::nullopt / no GPS fix / fewer than
+ * six fields), -1 = an input on which the reference lets std::stoi / std::stof / std::string::at throw. */
+typedef struct hd_host_telemetry {
+    char callsign[64];            /* leading '$' run removed (sentence_parse.cpp:156-163) */
+    int32_t frame, hour, minute;
+    float second, lat, lon, alt;  /* decimal degrees; NMEA ddmm.mmmm inputs converted (sentence_parse.cpp:106-143) */
+} hd_host_telemetry;
+int hd_host_parse_time(const char* text, int* hour, int* minute, float* second);             /* parse_sentence_time, :47-68 */
+int hd_host_parse_gps_pos(const char* text, float* out);                                      /* parse_gps_pos, :106-143 */
+int hd_host_parse_sentence(const char* sentence_without_crc, hd_host_telemetry* out);         /* parse_sentence, :146-196, without the clock */
+/* timestamp_from_HMS (:73-100) with the clock passed in (seconds since the epoch, UTC): "YYYY-MM-DDTHH:MM:SSZ" */
+size_t hd_host_timestamp_from_hms(int64_t now_unix, int hour, int minute, float second, char* buf, size_t cap);
+/* CalcGpsDistance (GpsDistance.cpp:21-84): out = {line distance m, great-circle distance m, angle rad, elevation deg, bearing deg} */
+void hd_host_gps_distance(double lat1, double lon1, double alt1, double lat2, double lon2, double alt2, double out[5]);
+
 /* ---- batched cf32 file ingest: S IQ files -> one push slab per round ----
  * Each file is an IQSource_File<float> (IQSource_File.h:124-172): raw interleaved float32 I,Q, no header; a read returns
  * what is left, the end of file is noticed by the read that runs into it, and the NEXT read rewinds when `loop` (else
