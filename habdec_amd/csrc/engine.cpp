@@ -113,7 +113,8 @@ struct hd_engine {
     bool decode_enabled = true;
     bool one_stream = false;
     bool no_fuse = false;      // HD_NO_FUSE: never use the fused back end (kernels/backend.hip); A/B measurements
-    int last_fuse = -1;        // path of the previous call (the two paths use the stage-2 buffers on different queues)
+    int last_fuse = -1;
+    uint32_t n_cus = 0, dec_wgs_per_cu = 0;   // stage-1 linear split: workgroups per CU (0 = classic grid), see kernels/decimate.hip        // path of the previous call (the two paths use the stage-2 buffers on different queues)
     hipStream_t qa = nullptr, qb = nullptr, qc = nullptr;   // front (decimation, spectrum) and back (FIR, symbols, results) HIP streams
     bool timing_on = true;
     hd_timing last_timing{};
@@ -239,6 +240,16 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     HD_HIP(hipStreamCreateWithFlags(&e->qa, hipStreamNonBlocking));
     e->one_stream = getenv("HD_ONE_STREAM") != nullptr;
     e->no_fuse = getenv("HD_NO_FUSE") != nullptr;
+    {
+        hipDeviceProp_t prop;
+        HD_HIP(hipGetDeviceProperties(&prop, cfg->device));
+        e->n_cus = (uint32_t)prop.multiProcessorCount;
+        // Batch (pipelined) mode: stage 1 takes six of a CU's eight LDS slots and leaves the rest to the previous call's back
+        // half, which then runs underneath it (alone, stage 1 is 6 % slower that way; together the step is ~30 % shorter).
+        // Synchronous mode has nothing to overlap: classic grid, all eight slots.
+        e->dec_wgs_per_cu = cfg->pipeline ? 6u : 0u;
+        if (const char* v = getenv("HD_DEC_WGS_PER_CU")) e->dec_wgs_per_cu = (uint32_t)atoi(v);
+    }
     if (e->one_stream) e->qb = e->qc = e->qa;
     else {
         HD_HIP(hipStreamCreateWithFlags(&e->qb, hipStreamNonBlocking));
@@ -563,7 +574,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     }
 
     // ---- host mirror of the reference's size bookkeeping -> one StreamCall per stream
-    uint32_t max_in = 0, max_n1 = 0, max_n2 = 0, max_m = 0, max_taps = 0, max_new = 0;
+    uint32_t max_in = 0, min_in = 0xFFFFFFFFu, max_n1 = 0, max_n2 = 0, max_m = 0, max_taps = 0, max_new = 0;
     bool any_fft = false, any_dc = false;
     uint64_t total_in = 0;
     for (uint32_t s = 0; s < S; ++s) {
@@ -616,7 +627,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         c.pend_after = (uint32_t)st.pending;
         st.last_n2 = c.n2; st.last_pend_before = c.pend_before; st.last_buf = e->cur;
         sl.h_call.p[s] = c;
-        max_in = std::max(max_in, n); max_n1 = std::max(max_n1, c.n1); max_n2 = std::max(max_n2, c.n2);
+        max_in = std::max(max_in, n); min_in = std::min(min_in, n); max_n1 = std::max(max_n1, c.n1); max_n2 = std::max(max_n2, c.n2);
         any_dc |= c.dc_remove != 0;
         total_in += n;
     }
@@ -680,7 +691,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         const size_t out1_stride = single ? e->fbuf_stride : e->n1_cap;
         if (e->timing_on) HD_HIP(hipEventRecord(sl.t1, qa));
         if (!hd::launch_decimate(qa, R1, T1, S, max_n1, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
-                                 dcall, 0, single ? 1 : 0, e->fir_hist_cap, single ? feed : nullptr))
+                                 dcall, 0, single ? 1 : 0, e->fir_hist_cap, single ? feed : nullptr, (min_in == max_in && max_in) ? e->dec_wgs_per_cu * e->n_cus : 0u))
             return fail(HD_ERR_INVALID, "no kernel for this decimation stage");
         if (e->timing_on) HD_HIP(hipEventRecord(sl.t2, qa));
         if (!single && !fuse) {

@@ -6,8 +6,9 @@
 // bit-identical to the CPU path).  The first stage is the only kernel of the pipeline that touches full-rate
 // IQ: 8 bytes read per input sample, 8/D written -- HBM-bound for D >= 8 (kernel table).
 //
-// Mapping: grid = (tile groups, streams); one lane = one output sample, so the T-term sum stays inside a lane and
-// in order.  A workgroup walks `tiles_per_wg` consecutive tiles of one stream.  Each tile's (TO-1)*D + T input
+// Mapping: one lane = one output sample, so the T-term sum stays inside a lane and in order.  A workgroup walks consecutive
+// tiles: either `tiles_per_wg` tiles of one stream (grid = (tile groups, streams)), or -- linear split -- its even share of
+// ALL the slab's tiles, crossing from one stream into the next where its range does.  Each tile's (TO-1)*D + T input
 // samples go global -> registers -> LDS with 16-byte accesses, and the NEXT tile's global loads are issued before
 // the current tile is computed, so HBM latency hides under the LDS/VALU phase (register prefetch, single LDS
 // buffer, two barriers per tile).
@@ -33,7 +34,7 @@ extern "C" void hd_debug_dec_stamps(unsigned long long* host, size_t n) { (void)
 #define DSTAMP_ARRIVED() do { if (D == 32) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DSTAMP(0); if (!ds_r1) ds_r1 = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #define DSTAMP_WRITE() do { if (D == 32 && threadIdx.x == 0) { const uint32_t w_ = blockIdx.y * gridDim.x + blockIdx.x; if (w_ < 4096) { \
         unsigned long long* g_ = g_dec_stamps + w_ * 8; g_[0] = ds_r0; g_[1] = ds_r1; g_[2] = __builtin_amdgcn_s_memrealtime(); \
-        g_[3] = ds_acc[0]; g_[4] = ds_acc[1]; g_[5] = ds_acc[2]; g_[6] = ds_acc[3]; g_[7] = last - first; } } } while (0)
+        g_[3] = ds_acc[0]; g_[4] = ds_acc[1]; g_[5] = ds_acc[2]; g_[6] = ds_acc[3]; g_[7] = count; } } } while (0)
 #else
 #define DSTAMP_DECL do { } while (0)
 #define DSTAMP(i) do { } while (0)
@@ -47,7 +48,8 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                    const float* __restrict__ taps,
                                                    float2* __restrict__ out, size_t out_stride,
                                                    const StreamCall* __restrict__ call, int stage, int final_stage,
-                                                   uint32_t fir_hist_cap, uint32_t tiles_per_wg, float2* __restrict__ fft_in)
+                                                   uint32_t fir_hist_cap, uint32_t tiles_per_wg, float2* __restrict__ fft_in,
+                                                   uint32_t n_streams, uint32_t lin_ntiles)
 {
     constexpr int JS = (T - 1) & 1;                // LDS slot jj = j + JS for tile-local sample j
     constexpr int NJ = (TO - 1) * D + T;           // samples a tile needs
@@ -59,34 +61,56 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     float2* tile = reinterpret_cast<float2*>(tile4);
     float2* ytile = tile + ((NL + 1) & ~1);        // this tile's outputs (only needed for the Q4 history quirk)
 
-    const uint32_t s = blockIdx.y;
-    const StreamCall c = call[s];
-    const uint32_t n = stage == 0 ? c.n_in : c.n1;
+    // Two ways to hand out tiles.  Classic: grid = (tile groups, streams), a workgroup walks tiles_per_wg tiles of stream
+    // blockIdx.y.  Linear split (lin_ntiles != 0; every stream has exactly lin_ntiles tiles of the same n): the S * lin_ntiles
+    // tiles of the slab are dealt evenly to gridDim.x workgroups, whatever that number is -- it decides how many of a CU's LDS
+    // slots this kernel occupies -- and a workgroup simply walks on into the next stream where its range crosses a seam.
+    // Per-stream context (s, the stream's StreamCall head) therefore is a variable; the prefetch runs one tile ahead of it.
+    struct CallHead { uint32_t n_in, n1, n2, zero_hist1, zero_hist2, pend_before, fft_fill, fft_take; };   // first 32 bytes of StreamCall
+    static_assert(sizeof(CallHead) == 32, "CallHead mirrors the head of StreamCall");
+    const bool linear = lin_ntiles != 0;
+    uint32_t s, first, count;                               // current stream, first tile in it, tiles this workgroup walks in total
+    if (linear) {
+        const uint64_t total = (uint64_t)n_streams * lin_ntiles;
+        const uint64_t g0 = (uint64_t)blockIdx.x * total / gridDim.x, g1 = (uint64_t)(blockIdx.x + 1) * total / gridDim.x;
+        s = (uint32_t)(g0 / lin_ntiles);
+        first = (uint32_t)(g0 - (uint64_t)s * lin_ntiles);
+        count = (uint32_t)(g1 - g0);
+    } else {
+        s = blockIdx.y; first = blockIdx.x * tiles_per_wg; count = tiles_per_wg;
+    }
+    CallHead c = *reinterpret_cast<const CallHead*>(call + s);
+    const uint32_t n = stage == 0 ? c.n_in : c.n1;          // (linear: the same for every stream)
     const uint32_t nout = n / D;
     const uint32_t ntiles = (nout + TO - 1) / TO;
-    const uint32_t first = blockIdx.x * tiles_per_wg;
-    if (!n && blockIdx.x == 0)                             // idle stream: its history passes through unchanged
-        for (uint32_t j = threadIdx.x; j < (uint32_t)(T - 1); j += TO)
-            hist_out[(size_t)s * (T - 1) + j] = hist_in[(size_t)s * (T - 1) + j];
-    if (first >= ntiles) return;
-    const uint32_t last = min(first + tiles_per_wg, ntiles);
-    const bool zero_hist = (stage == 0 ? c.zero_hist1 : c.zero_hist2) != 0;
-    const float2* in_s = in + (size_t)s * in_stride;
-    const float2* hist_s = hist_in + (size_t)s * (T - 1);
-    float2* out_s = out + (size_t)s * out_stride + (final_stage ? (size_t)fir_hist_cap + c.pend_before : 0);
+    if (!linear) {
+        if (!n && blockIdx.x == 0)                          // idle stream: its history passes through unchanged
+            for (uint32_t j = threadIdx.x; j < (uint32_t)(T - 1); j += TO)
+                hist_out[(size_t)s * (T - 1) + j] = hist_in[(size_t)s * (T - 1) + j];
+        if (first >= ntiles) return;
+        count = min(first + tiles_per_wg, ntiles) - first;
+    }
+    if (!count) return;
+    // prefetch context: the stream the NEXT tile to load belongs to
+    uint32_t pf_s = s;
+    bool pf_zero_hist = (stage == 0 ? c.zero_hist1 : c.zero_hist2) != 0;
+    CallHead c_next = c;                                    // head of stream s + 1 once the prefetch has crossed the seam
 
     // Edge tiles (the history tile of every stream): branch-free address selection so the loads still issue
     // back to back -- out-of-range samples read a safe address and are zeroed afterwards.
-    auto locate = [&](long xi, bool& ok) -> const float2* {
-        const bool in_hist = xi < 0;
-        ok = in_hist ? (!zero_hist && xi >= -(long)(T - 1)) : (xi < (long)n);
-        const long hi = xi + (T - 1);
-        const float2* ph = hist_s + (hi < 0 ? 0 : hi);
-        const float2* pi = in_s + (xi < 0 ? 0 : (xi < (long)n ? xi : 0));
-        return in_hist ? ph : pi;
-    };
     float4 r[ITER];
-    auto load_tile = [&](uint32_t tile_i) {
+    auto load_tile = [&](uint32_t tile_i) {                 // tile tile_i of stream pf_s
+        const float2* in_s = in + (size_t)pf_s * in_stride;
+        const float2* hist_s = hist_in + (size_t)pf_s * (T - 1);
+        const bool zero_hist = pf_zero_hist;
+        auto locate = [&](long xi, bool& ok) -> const float2* {
+            const bool in_hist = xi < 0;
+            ok = in_hist ? (!zero_hist && xi >= -(long)(T - 1)) : (xi < (long)n);
+            const long hi = xi + (T - 1);
+            const float2* ph = hist_s + (hi < 0 ? 0 : hi);
+            const float2* pi = in_s + (xi < 0 ? 0 : (xi < (long)n ? xi : 0));
+            return in_hist ? ph : pi;
+        };
         const long xe = (long)tile_i * TO * D - (T - 1) - JS;      // stream sample of LDS slot 0; even
         const float4* src = reinterpret_cast<const float4*>(in_s + xe);
         // Per sweep of TO pairs: plain aligned 16-byte loads when the whole sweep lies inside this call's input (wave-uniform
@@ -118,15 +142,15 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // through one in-order counter, so a store issued after the prefetch would make the wait for the prefetched tile also
     // wait for the store's acknowledgement (measured: 8 % of the kernel).
     float2 y_prev = make_float2(0.f, 0.f);
-    uint32_t o_prev = 0xFFFFFFFFu;
+    float2* dst_prev = nullptr;
+    float2* fdst_prev = nullptr;
     auto store_prev = [&]() {
-        if (o_prev < nout) {
-            out_s[o_prev] = y_prev;
-            // spectrum input collection (reference Decoder.h:467-473): the HEAD of this call's decimated chunk
-            if (fft_in && o_prev < c.fft_take) fft_in[(size_t)s * kFftBins + c.fft_fill + o_prev] = y_prev;
-        }
+        if (dst_prev) *dst_prev = y_prev;
+        if (fdst_prev) *fdst_prev = y_prev;                 // spectrum input collection (reference Decoder.h:467-473)
+        dst_prev = nullptr; fdst_prev = nullptr;
     };
-    for (uint32_t tile_i = first; tile_i < last; ++tile_i) {
+    uint32_t tile_i = first;                                // tile of stream s being computed; pf_* run one tile ahead
+    for (uint32_t done = 0; done < count; ++done) {
         DSTAMP_ARRIVED();
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
@@ -139,7 +163,15 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         __syncthreads();
         DSTAMP(1);
         store_prev();
-        if (tile_i + 1 < last) load_tile(tile_i + 1);      // in flight while this tile is computed
+        if (done + 1 < count) {                             // the next tile's loads stay in flight while this tile is computed
+            uint32_t pf_tile = tile_i + 1;
+            if (linear && pf_tile == ntiles) {              // ... across the seam into the next stream
+                pf_tile = 0; ++pf_s;
+                c_next = *reinterpret_cast<const CallHead*>(call + pf_s);
+                pf_zero_hist = (stage == 0 ? c_next.zero_hist1 : c_next.zero_hist2) != 0;
+            }
+            load_tile(pf_tile);
+        }
         DSTAMP(2);
 
         // The T-term sum, in tap order.  Taps are consumed in blocks of B LDS slots (B/2 ds_read_b128 issued
@@ -193,24 +225,31 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         const uint32_t o = tile_i * TO + threadIdx.x;
         y_prev = make_float2(ar, ai);
-        o_prev = o;
+        dst_prev = o < nout ? out + (size_t)s * out_stride + (final_stage ? (size_t)fir_hist_cap + c.pend_before : 0) + o : nullptr;
+        fdst_prev = (fft_in && o < c.fft_take) ? fft_in + (size_t)s * kFftBins + c.fft_fill + o : nullptr;
         ytile[threadIdx.x] = y_prev;
         __syncthreads();                                    // everyone is done with this tile's LDS image
         DSTAMP(3);
+        if (++tile_i == ntiles) {
+            // History carry for the next call (Decimator.h:140-143).  Q4: the reference decimates in place
+            // (Decoder.h:443-444), so history positions that fall inside the first n/D samples hold OUTPUTS; that can only
+            // happen for inputs so short that all outputs are in this (single) tile.
+            if (n) {
+                float2* hout = hist_out + (size_t)s * (T - 1);
+                const float2* in_s = in + (size_t)s * in_stride;
+                for (uint32_t j = threadIdx.x; j < (uint32_t)(T - 1); j += TO) {
+                    const uint32_t idx = n - (T - 1) + j;   // host guarantees n >= T-1
+                    hout[j] = idx < nout ? ytile[idx] : in_s[idx];
+                }
+            }
+            if (done + 1 < count) {                         // linear split: walk on into the next stream (its first tile is in flight)
+                __syncthreads();                            // ytile is rewritten by the next tile
+                ++s; tile_i = 0; c = c_next;
+            }
+        }
     }
     store_prev();
     DSTAMP_WRITE();
-
-    // History carry for the next call (Decimator.h:140-143).  Q4: the reference decimates in place
-    // (Decoder.h:443-444), so history positions that fall inside the first n/D samples hold OUTPUTS; that can only
-    // happen for inputs so short that all outputs are in this (single) tile.
-    if (last == ntiles && n) {
-        float2* hout = hist_out + (size_t)s * (T - 1);
-        for (uint32_t j = threadIdx.x; j < (uint32_t)(T - 1); j += TO) {
-            const uint32_t idx = n - (T - 1) + j;           // host guarantees n >= T-1
-            hout[j] = idx < nout ? ytile[idx] : in_s[idx];
-        }
-    }
 }
 
 __global__ void k_passthrough(const float2* __restrict__ in, size_t in_stride, float2* __restrict__ out, size_t out_stride,
@@ -256,28 +295,33 @@ __global__ __launch_bounds__(64) void k_dc_remove(float2* __restrict__ fbuf, siz
 template <int D, int T, int TO>
 static void launch_one(hipStream_t st, uint32_t n_streams, uint32_t max_out, const float2* in, size_t in_stride,
                        const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride,
-                       const StreamCall* call, int stage, int final_stage, uint32_t fir_hist_cap, float2* fft_in)
+                       const StreamCall* call, int stage, int final_stage, uint32_t fir_hist_cap, float2* fft_in, uint32_t lin_wgs)
 {
     const uint32_t ntiles = (max_out + TO - 1) / TO;
+    // Linear split (single-wave instantiations, every stream the same size -- the caller vouches for that by passing lin_wgs):
+    // exactly lin_wgs workgroups share the slab's tiles evenly.  The caller picks lin_wgs = k * CUs to decide how many of a CU's
+    // eight 19.5 KB LDS slots this kernel takes -- the rest stays free for the back-half kernels of the previous call.
+    if (TO == 64 && lin_wgs && (uint64_t)ntiles * n_streams >= 4ull * lin_wgs) {
+        hipLaunchKernelGGL((k_decimate<D, T, TO>), dim3(lin_wgs), dim3(TO), 0, st, in, in_stride, hist_in, hist_out, taps, out, out_stride, call,
+                           stage, final_stage, fir_hist_cap, 0u, fft_in, n_streams, ntiles);
+        return;
+    }
     // Walk several tiles per workgroup (prefetch pipelining) once there are enough workgroups to fill the chip:
     // 256 CUs x ~4 resident workgroups; keep >= ~2048 workgroups when the batch allows it.
     uint32_t per = 1;
     while (per < 16 && (uint64_t)((ntiles + 2 * per - 1) / (2 * per)) * n_streams >= 2048) per *= 2;
-    static const uint32_t per_env = [] { const char* v = getenv("HD_DEC_PER"); return v ? (uint32_t)atoi(v) : 0u; }();   // experiment knob
-    if (per_env && TO == 64) per = per_env;
     dim3 grid((ntiles + per - 1) / per, n_streams);
-    static const size_t pad_lds = [] { const char* v = getenv("HD_DEC_PAD_LDS"); return v ? (size_t)atoi(v) : (size_t)0; }();   // experiment knob
-    hipLaunchKernelGGL((k_decimate<D, T, TO>), grid, dim3(TO), TO == 64 ? pad_lds : 0, st, in, in_stride, hist_in, hist_out, taps, out, out_stride, call,
-                       stage, final_stage, fir_hist_cap, per, fft_in);
+    hipLaunchKernelGGL((k_decimate<D, T, TO>), grid, dim3(TO), 0, st, in, in_stride, hist_in, hist_out, taps, out, out_stride, call,
+                       stage, final_stage, fir_hist_cap, per, fft_in, n_streams, 0u);
 }
 
 bool launch_decimate(hipStream_t st, int ratio, int ntaps, uint32_t n_streams, uint32_t max_out, const float2* in, size_t in_stride,
                      const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
-                     int stage, int final_stage, uint32_t fir_hist_cap, float2* fft_in)
+                     int stage, int final_stage, uint32_t fir_hist_cap, float2* fft_in, uint32_t lin_wgs)
 {
     if (!max_out) return true;
 #define HD_CASE(D, T, TO) \
-    if (ratio == D && ntaps == T) { launch_one<D, T, TO>(st, n_streams, max_out, in, in_stride, hist_in, hist_out, taps, out, out_stride, call, stage, final_stage, fir_hist_cap, fft_in); return true; }
+    if (ratio == D && ntaps == T) { launch_one<D, T, TO>(st, n_streams, max_out, in, in_stride, hist_in, hist_out, taps, out, out_stride, call, stage, final_stage, fir_hist_cap, fft_in, lin_wgs); return true; }
     HD_CASE(2, 69, 256) HD_CASE(4, 139, 256) HD_CASE(8, 280, 256) HD_CASE(8, 54, 256)
     HD_CASE(16, 107, 128) HD_CASE(32, 212, 64) HD_CASE(32, 174, 64) HD_CASE(64, 348, 64)
 #undef HD_CASE

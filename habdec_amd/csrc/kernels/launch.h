@@ -22,7 +22,8 @@ struct DemodCarry {        // per-stream discriminator carry (previous filtered 
 bool launch_decimate(hipStream_t st, int ratio, int ntaps, uint32_t n_streams, uint32_t max_out,
                      const float2* in, size_t in_stride, const float2* hist_in, float2* hist_out, const float* taps,
                      float2* out, size_t out_stride, const StreamCall* call, int stage, int final_stage,
-                     uint32_t fir_hist_cap, float2* fft_in /* final stage: spectrum input buffer [S][4096], or null */);
+                     uint32_t fir_hist_cap, float2* fft_in /* final stage: spectrum input buffer [S][4096], or null */,
+                     uint32_t lin_wgs = 0 /* != 0: every stream has the same size; use exactly this many workgroups (single-wave kernels) */);
 // copy `bytes` (multiple of 16) from mapped pinned host memory into device memory with a kernel
 void launch_fetch_params(hipStream_t st, const void* host_mapped, void* dst, size_t bytes);
 // factor 1: copy the chunk behind the FIR history.

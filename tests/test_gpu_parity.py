@@ -309,6 +309,43 @@ def test_full_size_batch_properties(hd):
     assert eng.sentences_ok() == S * len(o.sentences())
 
 
+@pytest.mark.parametrize("wgs_per_cu", [5, 6, 7])
+def test_full_size_linear_split_stage1(hd, monkeypatch, wgs_per_cu):
+    """Batch mode at BASELINE size runs stage 1 as a linear split: k workgroups per CU share all 32768 tiles evenly and walk
+    across stream seams (history in, history carry out, in the middle of a workgroup's range).  Every stream gets its own
+    delayed copy of one signal, so a seam handled wrongly shows; decimated/demodulated samples must equal the oracle's bit
+    for bit and the text must be complete."""
+    torch = pytest.importorskip("torch")
+    import habdec_amd
+    from oracle import pyoracle
+    monkeypatch.setenv("HD_DEC_WGS_PER_CU", str(wgs_per_cu))
+    S, fs = 1024, 2.048e6
+    iq1, _ = make_streams(1, fs, 300, 8, 2, seed0=5)
+    nch = iq1.shape[1] // C - 1
+    base = torch.from_numpy(iq1.view(np.float32)).cuda()                     # [1, L, 2]
+    shifts = (np.arange(S) * 37) % 4096                                       # stream s starts 'shifts[s]' samples into the signal
+    slab = torch.empty((nch, S, C, 2), dtype=torch.float32, device="cuda")
+    L = base.shape[1] if base.dim() == 3 else base.numel() // 2
+    flat = base.reshape(-1, 2)
+    for s in range(S):
+        seg = flat[int(shifts[s]):int(shifts[s]) + nch * C]
+        slab[:, s] = seg.view(nch, C, 2)
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=64, pipeline=True)
+    check = (0, 1, 7, 8, 511, 512, 1023)
+    orcs = {s: pyoracle.Decoder("oracle", factor=64) for s in check}
+    for k in range(nch):
+        eng.process_device(slab[k].data_ptr(), C, C)
+        eng.flush()
+        for s, o in orcs.items():
+            x = iq1[0, int(shifts[s]) + k * C: int(shifts[s]) + (k + 1) * C]
+            o(x, fs)
+            assert same_bits(eng.decimated(s).view(np.float32), o.array("last_decimated").view(np.float32)), (k, s)
+            assert same_bits(eng.demodulated(s), o.array("last_demod")), (k, s)
+    for s, o in orcs.items():
+        assert eng.take_chars(s) == o.text("chars_log")
+    assert eng.sentences_ok() >= S * (len(orcs[0].sentences()) - 1)
+
+
 def test_pipelined_mode_delivers_identical_text(hd):
     """pipeline=1: a call returns the PREVIOUS call's text while its own symbol kernels overlap the next call's
     decimation on a second HIP stream; after hd_flush() everything must equal the synchronous result and the oracle."""
