@@ -108,7 +108,7 @@ struct hd_engine {
     uint32_t n1_cap = 0, n2_cap = 0;        // per-call capacities after stage 1 / last stage
     uint32_t taps_cap = 0, fir_hist_cap = 0; // low-pass tap capacity, history slots in front of the pending samples
     size_t fbuf_stride = 0;
-    uint32_t tail_cap = 0, backlog_cap = 0, slot_words = 0, flips_cap = 0, max_R = 0;
+    uint32_t tail_cap = 0, backlog_cap = 0, slot_words = 0, flips_cap = 0, max_R = 0, min_R = 4;
     int bins_sep = 8;
     bool decode_enabled = true;
     bool one_stream = false;
@@ -289,6 +289,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         bits = std::max<uint32_t>(256u, (bits + 31u) & ~31u);
         e->slot_words = (uint32_t)(sizeof(hd::BitsHeader) / 4) + bits / 32;
         e->max_R = std::max<uint32_t>(p.R, 4);
+        e->min_R = e->max_R;
     }
     e->flips_cap = cfg->keep_filtered ? 256 : 0;
 
@@ -367,7 +368,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         hd::launch_fir_demod(q, S, 0, 0, e->fbuf[0].p, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S, nullptr, e->carry[0].p,
                              e->carry[1].p, sl.d_call.p, e->fir_hist_cap, e->tail.p, e->tail_cap, e->d_symstate.p, e->fbuf[1].p);
         hd::launch_symbols(q, S, 1, 1, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p, sl.d_call.p,
-                           sl.h_slots.dev, e->slot_words, nullptr, 0);
+                           sl.h_slots.dev, e->slot_words, nullptr, 0, e->min_R);
         HD_HIP(hipStreamSynchronize(q));
         // the all-idle call moved nothing, but the history / carry ping-pong "out" buffers were written: restore zeros
         for (auto& h : e->hist1) if (h.p) HD_HIP(hipMemset(h.p, 0, h.n * sizeof(float2)));
@@ -417,6 +418,7 @@ int hd_stream_set_baud(hd_engine* e, uint32_t s, double baud)
         if (need > (e->slot_words - sizeof(hd::BitsHeader) / 4) * 32)
             return fail(HD_ERR_CAPACITY, "baud too high for the result slots sized at engine creation");
         if (p.R > e->max_R) e->max_R = p.R;
+        if (p.R < e->min_R) e->min_R = std::max<uint32_t>(p.R, 4);
     }
     e->st[s].baud = baud;
     e->st[s].sym_reset = true;
@@ -660,6 +662,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             mr = std::max(mr, e->h_sym.p[s].R);
         }
         e->max_R = mr;
+        { uint32_t lo = mr; for (uint32_t s2 = 0; s2 < S; ++s2) lo = std::min(lo, std::max<uint32_t>(e->h_sym.p[s2].R, 4)); e->min_R = lo; }
         HD_HIP(hipMemcpyAsync(e->d_sym.p, e->h_sym.p, S * sizeof(hd::SymbolParams), hipMemcpyHostToDevice, qa));
         e->sym_dirty = false;
         for (uint32_t s = 0; s < S; ++s)       // a reset flag is consumed by exactly one call: upload again without it next time
@@ -741,7 +744,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     mark();
     mark();
     hd::launch_symbols(qb, S, max_m, max_new, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p,
-                       dcall, sl.h_slots.dev, e->slot_words, e->flips_cap ? e->flips_dbg.p : nullptr, e->flips_cap);
+                       dcall, sl.h_slots.dev, e->slot_words, e->flips_cap ? e->flips_dbg.p : nullptr, e->flips_cap, e->min_R);
     mark();
     if (e->timing_on) HD_HIP(hipEventRecord(sl.t3, qb));
     HD_HIP(hipEventRecord(sl.ev_done, qb));

@@ -12,6 +12,11 @@
 // -ffp-contract=off), then arg(y[i] * conj(y[i-1])) (FSK2_Demod.h:37-40).  Buffer conventions (history in front of the
 // pending samples, ping-pong slide, spectrum feed from the head of the chunk, history carry with the in-place quirk Q4)
 // are those of the kernels it replaces, so the engine can switch between the two paths from call to call.
+//
+// LDS: 28.5 KB per stream at the headline shape.  A variant that walks stage 2 in two half-size images (20 KB, two
+// workgroups beside six stage-1 workgroups per CU) was measured and dropped: alone it is as fast, next to a classic stage-1
+// grid it gains 7 %, but under the 6-per-CU stage-1 split that batch mode uses it LOSES 8 % (two back-end workgroups per CU
+// take more VALU/LDS time from stage 1 than their head start returns).
 #include <hip/hip_runtime.h>
 
 #include "exact_math.h"

@@ -51,6 +51,7 @@ bool launch_backend(hipStream_t st, int ratio2, int ntaps2, uint32_t n_streams, 
 // Symbol extractor: window kernel over the positions that became computable (at most max_new per stream) + scan kernel.
 void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_new, uint32_t max_R, const float* tail,
                     uint32_t ring_cap, SymState* sym, unsigned long long* flipmask, float* weight, const SymbolParams* sp,
-                    const StreamCall* call, uint32_t* slots, uint32_t slot_words, uint32_t* flips_dbg, uint32_t flips_cap);
+                    const StreamCall* call, uint32_t* slots, uint32_t slot_words, uint32_t* flips_dbg, uint32_t flips_cap,
+                    uint32_t min_R /* smallest averaging half-window over the streams: bounds the flips one call can find */);
 
 }  // namespace hd

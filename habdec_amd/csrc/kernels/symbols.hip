@@ -19,13 +19,14 @@
 //     positions per step through ballots and find-first-set); per-run sums are accumulated in element order with
 //     the wave loading 256 samples at a time and v_readlane feeding a wave-uniform accumulator; lane 0 packs bits.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "launch.h"
 
 namespace hd {
 
 constexpr int kAvgLanes = 256;
-constexpr uint32_t kMaxFlipsPerCall = 1024;   // LDS flip list of the scan kernel (overflow is flagged)
+constexpr uint32_t kMaxFlipsPerCall = 1024;   // upper bound of the LDS flip list (the launcher sizes it from backlog / R; overflow is flagged)
 
 __device__ __forceinline__ int sgnf(float v) { return (0.0f < v) - (v < 0.0f); }
 
@@ -152,14 +153,13 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
                                                         unsigned long long* __restrict__ flipmask, float* __restrict__ weight,
                                                         const SymbolParams* __restrict__ sp, const StreamCall* __restrict__ call,
                                                         uint32_t* __restrict__ slots, uint32_t slot_words,
-                                                        uint32_t* __restrict__ flips_dbg, uint32_t flips_cap)
+                                                        uint32_t* __restrict__ flips_dbg, uint32_t flips_cap, uint32_t fl_cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // carve: [lmask: ring_cap/64 u64][win: span + R + 16 floats][wl: span + R floats][strips: 4 waves x kRunStrip floats]
+    // carve: [lmask: ring_cap/64 u64][flips, runinfo: fl_cap u32 each][win: span + R + 16 floats][wl: span + R floats];
+    // the run-sum strips (4 waves x kRunStrip floats) reuse win/wl, which are dead by then
     unsigned long long* lmask = reinterpret_cast<unsigned long long*>(smem);
     __shared__ unsigned long long words[kAvgSpan / 64 + 1];
-    __shared__ uint32_t flips[kMaxFlipsPerCall];
-    __shared__ uint32_t runinfo[kMaxFlipsPerCall];          // (count << 1) | bit
     __shared__ uint32_t s_nfl, s_overflow, s_frontier;
     __shared__ float s_carry;
     __shared__ uint32_t s_flagged;
@@ -187,8 +187,10 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
         return;
     }
     const uint32_t R = q.R, rmask = ring_cap - 1;
-    float* win = reinterpret_cast<float*>(lmask + ring_cap / 64);
-    float* strips = win + ((kAvgSpan + R + 16 + 3) & ~3u) + ((kAvgSpan + R + 3) & ~3u);
+    uint32_t* flips = reinterpret_cast<uint32_t*>(lmask + ring_cap / 64);
+    uint32_t* runinfo = flips + fl_cap;                      // (count << 1) | bit
+    float* win = reinterpret_cast<float*>(runinfo + fl_cap);
+    float* strips = win;                                    // phase C only; (kAvgSpan + R) * 2 floats >= 4 * kRunStrip
     const float* v = tail + (size_t)s * ring_cap;
     unsigned long long* gmask = flipmask + (size_t)s * (ring_cap / 64);
     float* gw = weight + (size_t)s * ring_cap;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     __syncthreads();
     // ---- A2: busy streams (off-tune or noisy: ten flips per call instead of one) would pay one global round trip per flip
     // for the zone weights.  When the mask image shows more flagged positions than a couple of clean edges produce, the
-    // window sums of the whole searchable backlog are pulled into LDS first (over win/wl/strips, which are idle here).
+    // window sums of the searchable backlog (as much as fits) are pulled into LDS first, over win/wl, which are idle here.
     float* wc = win;
     uint32_t wc_n = 0;
     {
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
         if (lane == 0 && cnt) atomicAdd(&s_flagged, cnt);
         __syncthreads();
         if (s_flagged > 4u * R) {
-            const uint32_t cap = ((kAvgSpan + R + 16 + 3) & ~3u) + ((kAvgSpan + R + 3) & ~3u) + (kSymLanes / 64) * kRunStrip;
+            const uint32_t cap = ((kAvgSpan + R + 16 + 3) & ~3u) + ((kAvgSpan + R + 3) & ~3u);
             wc_n = min(limit, cap);
             constexpr int CB = 9;
             for (uint32_t k0 = tid; k0 < wc_n; k0 += CB * kSymLanes) {
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
                 }
             }
             const uint32_t f = ~(uint32_t)wave_max_u64(key);
-            if (nfl < kMaxFlipsPerCall) { if (lane == 0) flips[nfl] = f; ++nfl; } else { overflow = 1; break; }
+            if (nfl < fl_cap) { if (lane == 0) flips[nfl] = f; ++nfl; } else { overflow = 1; break; }
             pos = f + R;
         }
         if (frontier == 0xFFFFFFFFu) frontier = max(pos, limit);   // nothing flagged in [pos, limit)
@@ -472,13 +474,17 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
 
 void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_new, uint32_t max_R, const float* tail,
                     uint32_t ring_cap, SymState* sym, unsigned long long* flipmask, float* weight, const SymbolParams* sp,
-                    const StreamCall* call, uint32_t* slots, uint32_t slot_words, uint32_t* flips_dbg, uint32_t flips_cap)
+                    const StreamCall* call, uint32_t* slots, uint32_t slot_words, uint32_t* flips_dbg, uint32_t flips_cap, uint32_t min_R)
 {
     (void)max_m; (void)max_new;
-    const size_t lds = (size_t)(ring_cap / 64) * 8 + (size_t)(((kAvgSpan + max_R + 16 + 3) & ~3u) + ((kAvgSpan + max_R + 3) & ~3u)) * 4 +
-                       (size_t)(kSymLanes / 64) * kRunStrip * 4;
+    // a flip point moves the search on by R, so a call finds at most backlog / R + 1 of them (the backlog never exceeds the ring)
+    uint32_t fl_cap = ring_cap / (min_R ? min_R : 4u) + 2u;
+    fl_cap = (fl_cap + 63u) & ~63u;
+    if (fl_cap > kMaxFlipsPerCall) fl_cap = kMaxFlipsPerCall;
+    const size_t lds = (size_t)(ring_cap / 64) * 8 + (size_t)fl_cap * 8 +
+                       (size_t)(((kAvgSpan + max_R + 16 + 3) & ~3u) + ((kAvgSpan + max_R + 3) & ~3u)) * 4;
     hipLaunchKernelGGL(k_symbols, dim3(n_streams), dim3(kSymLanes), lds, st, tail, ring_cap, sym, flipmask, weight, sp, call, slots,
-                       slot_words, flips_dbg, flips_cap);
+                       slot_words, flips_dbg, flips_cap, fl_cap);
 }
 
 }  // namespace hd
