@@ -237,7 +237,15 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device || cfg->device < 0)
         return fail(HD_ERR_DEVICE, "no HIP device " + std::to_string(cfg->device) + " (this library has no CPU path)");
     HD_HIP(hipSetDevice(cfg->device));
-    HD_HIP(hipStreamCreateWithFlags(&e->qa, hipStreamNonBlocking));
+    {   // HD_QA_PRIORITY=1: the stage-1 queue gets the device's highest priority, so that when stage 1 of call k+1 and the back half
+        // of call k become runnable together, stage 1's workgroups are placed first (evenly, k per CU) and the back half fills in
+        int lo = 0, hi = 0;
+        const char* pv = getenv("HD_QA_PRIORITY");
+        if (pv && atoi(pv) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+            HD_HIP(hipStreamCreateWithPriority(&e->qa, hipStreamNonBlocking, atoi(pv) > 0 ? hi : lo));
+        else
+            HD_HIP(hipStreamCreateWithFlags(&e->qa, hipStreamNonBlocking));
+    }
     e->one_stream = getenv("HD_ONE_STREAM") != nullptr;
     e->no_fuse = getenv("HD_NO_FUSE") != nullptr;
     {
