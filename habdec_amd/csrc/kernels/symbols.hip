@@ -240,6 +240,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     }
     STAMP(1);
     bool staged = true;
+    uint32_t sweeps = 0, wl_c0 = st.cached;                 // wl holds W of [wl_c0 - R, wl_c0 + kAvgSpan) after the last sweep
     for (uint32_t c0 = st.cached; (int32_t)(pend - c0) > 0; c0 += kAvgSpan) {
         const uint32_t wb0 = c0 & ~63u, wsh = c0 & 63u;    // sweeps start wherever the previous call stopped: words are shared
         if (!staged) {
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
             first_word = lmask[(c0 & rmask) >> 6];          // as the previous sweep left it
         }
         staged = false;
+        ++sweeps; wl_c0 = c0;
         if (tid < kAvgSpan / 64 + 1) words[tid] = 0ull;
         __syncthreads();
         const uint32_t p0 = c0 + tid * kAvgPos;
@@ -296,7 +298,11 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
             lmask[wi] = w;
         }
     }
-    __threadfence_block();                                  // this call's weights (global) are read back below
+    // The edge search reads window sums this call has just written.  After a single sweep (the steady state) they are all
+    // still in `wl`; only after several sweeps, or when the busy-stream cache below takes over win/wl, must the global copies
+    // be visible first (a store round trip).
+    bool lds_w = sweeps == 1;
+    if (sweeps > 1) __threadfence_block();
     __syncthreads();
     // ---- A2: busy streams (off-tune or noisy: ten flips per call instead of one) would pay one global round trip per flip
     // for the zone weights.  When the mask image shows more flagged positions than a couple of clean edges produce, the
@@ -312,6 +318,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
         if (lane == 0 && cnt) atomicAdd(&s_flagged, cnt);
         __syncthreads();
         if (s_flagged > 4u * R) {
+            if (lds_w) { __threadfence_block(); __syncthreads(); lds_w = false; }   // the fill reads this call's sums from global, and overwrites wl
             const uint32_t cap = ((kAvgSpan + R + 16 + 3) & ~3u) + ((kAvgSpan + R + 3) & ~3u);
             wc_n = min(limit, cap);
             constexpr int CB = 9;
@@ -327,6 +334,13 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     }
     STAMP(2);
 
+    // window sum of backlog index i: busy-stream cache, this call's sums still in LDS, or the global ring
+    auto wsum = [&](uint32_t i) -> float {
+        if (i < wc_n) return wc[i];
+        const uint32_t pos = st.base + i, rel = pos - (wl_c0 - R);
+        if (lds_w && rel < R + kAvgSpan && (int32_t)(pend - pos) > 0) return wl[rel];
+        return gw[pos & rmask];
+    };
     // ---- B: edge search (wave 0)
     if (wave == 0) {
         uint32_t pos = R, nfl = 0, overflow = 0;
@@ -345,8 +359,8 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
 #pragma unroll
                 for (int u = 0; u < ZB; ++u) {
                     const uint32_t i = i0 + 64 * u;
-                    wr_[u] = i < hi ? (i < wc_n ? wc[i] : gw[(st.base + i) & rmask]) : 0.0f;
-                    wl_[u] = i < hi ? (i - R < wc_n ? wc[i - R] : gw[(st.base + i - R) & rmask]) : 0.0f;
+                    wr_[u] = i < hi ? wsum(i) : 0.0f;
+                    wl_[u] = i < hi ? wsum(i - R) : 0.0f;
                 }
 #pragma unroll
                 for (int u = 0; u < ZB; ++u) {
