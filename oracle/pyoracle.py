@@ -365,7 +365,8 @@ class Decoder:
         assert fn("setup_factor", _int, _vp, _sz if kind == "oracle" else _int)(self.h, factor) == factor or factor == 1
         fn("baud", None, _vp, _dbl)(self.h, baud)
         fn("rtty", None, _vp, _sz, C.c_float)(self.h, bits, stops)
-        fn("dc_remove", None, _vp, _int)(self.h, int(dc_remove))
+        self._dc_remove = fn("dc_remove", None, _vp, _int)
+        self._dc_remove(self.h, int(dc_remove))
         self._lp_bw = fn("lowpass_bw", None, _vp, C.c_float)
         self._lp_trans = fn("lowpass_trans", None, _vp, C.c_float)
         # like websocketServer/main.cpp:550-551 these run before any input and only store the values
@@ -398,6 +399,9 @@ class Decoder:
 
     def sentences(self):
         return [s for s in self.text("sentence_log").split("\n") if s]
+
+    def set_dc_remove(self, on: bool):
+        self._dc_remove(self.h, int(on))
 
     def array(self, which: str) -> np.ndarray:
         p = C.POINTER(C.c_float)()

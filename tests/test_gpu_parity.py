@@ -346,6 +346,33 @@ def test_full_size_linear_split_stage1(hd, monkeypatch, wgs_per_cu):
     assert eng.sentences_ok() >= S * (len(orcs[0].sentences()) - 1)
 
 
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_switching_between_fused_and_unfused_back_end(hd, pipeline):
+    """The DC blocker forces the unfused kernels (stage 2, DC, FIR separately, front half on the other queue); switching it
+    on and off mid-stream makes the engine change paths from call to call -- histories, pending samples, carries and the symbol
+    ring must flow across the switch exactly as in the reference."""
+    import habdec_amd
+    from oracle import pyoracle
+    S, fs = 3, 2.048e6
+    iq, _ = make_streams(S, fs, 300, 8, 2, seed0=900)
+    nch = iq.shape[1] // C
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=64, pipeline=pipeline)
+    orcs = [pyoracle.Decoder("oracle", factor=64) for _ in range(S)]
+    for k in range(nch):
+        on = k % 3 == 1                                  # off, ON, off, off, ON, ...
+        for s in range(S):
+            eng.set_dc_remove(s, on)
+            orcs[s].set_dc_remove(on)
+        eng.process_host(np.ascontiguousarray(iq[:, k * C:(k + 1) * C]))
+        eng.flush()
+        for s in range(S):
+            orcs[s](iq[s, k * C:(k + 1) * C], fs)
+            assert same_bits(eng.decimated(s).view(np.float32), orcs[s].array("last_decimated").view(np.float32)), (k, s)
+            assert same_bits(eng.demodulated(s), orcs[s].array("last_demod")), (k, s)
+    for s in range(S):
+        assert eng.take_chars(s) == orcs[s].text("chars_log")
+
+
 def test_pipelined_mode_delivers_identical_text(hd):
     """pipeline=1: a call returns the PREVIOUS call's text while its own symbol kernels overlap the next call's
     decimation on a second HIP stream; after hd_flush() everything must equal the synchronous result and the oracle."""
