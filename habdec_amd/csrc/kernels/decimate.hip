@@ -20,6 +20,7 @@
 // History: the workgroup that owns a stream's last tile also writes the stream's next history (last T-1 inputs)
 // into the OTHER history buffer (ping-pong, so the first tile of the same launch still reads the old one).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <cstdlib>
 
 #include "launch.h"
@@ -42,6 +43,12 @@ extern "C" void hd_debug_dec_stamps(unsigned long long* host, size_t n) { (void)
 #define DSTAMP_WRITE() do { } while (0)
 #endif
 
+// Outputs per lane.  With a small ratio D neighbouring outputs share almost all of their T input samples, and one output per
+// lane makes the kernel LDS-bound (8 bytes read per complex multiply-add).  A lane that owns OPL consecutive outputs reads its
+// (OPL-1)*D + T samples once and feeds each to up to OPL accumulators; every accumulator still gets its own T products in
+// ascending tap order.  OPL*D is 8 or 16 samples, so the padded pitch OPL*D + 2 keeps the 16-byte reads conflict-free.
+template <int D> constexpr int dec_opl() { return D == 2 ? 4 : D == 4 ? 4 : D == 8 ? 2 : 1; }
+
 template <int D, int T, int TO>
 __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_decimate(const float2* __restrict__ in, size_t in_stride,
                                                    const float2* __restrict__ hist_in, float2* __restrict__ hist_out,
@@ -51,13 +58,16 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                    uint32_t fir_hist_cap, uint32_t tiles_per_wg, float2* __restrict__ fft_in,
                                                    uint32_t n_streams, uint32_t lin_ntiles)
 {
+    constexpr int OPL = dec_opl<D>();              // outputs per lane
+    constexpr int TOUT = TO * OPL;                 // outputs per tile
+    constexpr int RD = OPL * D;                    // samples per lane row (a 16-byte pad follows every row)
     constexpr int JS = (T - 1) & 1;                // LDS slot jj = j + JS for tile-local sample j
-    constexpr int NJ = (TO - 1) * D + T;           // samples a tile needs
+    constexpr int NJ = (TOUT - 1) * D + T;         // samples a tile needs
     constexpr int NJJ = NJ + JS;
-    constexpr int NL = NJJ + 2 * (NJJ / D) + 4;    // + two pad slots per D samples
+    constexpr int NL = NJJ + 2 * (NJJ / RD) + 4;   // + two pad slots per row
     constexpr int NP = (NJJ + 1) / 2;              // 16-byte pairs per tile
     constexpr int ITER = (NP + TO - 1) / TO;
-    __shared__ float4 tile4[(NL + 1) / 2 + TO / 2 + 1];
+    __shared__ float4 tile4[(NL + 1) / 2 + TOUT / 2 + 1];
     float2* tile = reinterpret_cast<float2*>(tile4);
     float2* ytile = tile + ((NL + 1) & ~1);        // this tile's outputs (only needed for the Q4 history quirk)
 
@@ -82,7 +92,7 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     CallHead c = *reinterpret_cast<const CallHead*>(call + s);
     const uint32_t n = stage == 0 ? c.n_in : c.n1;          // (linear: the same for every stream)
     const uint32_t nout = n / D;
-    const uint32_t ntiles = (nout + TO - 1) / TO;
+    const uint32_t ntiles = (nout + TOUT - 1) / TOUT;
     if (!linear) {
         if (!n && blockIdx.x == 0)                          // idle stream: its history passes through unchanged
             for (uint32_t j = threadIdx.x; j < (uint32_t)(T - 1); j += TO)
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const float2* pi = in_s + (xi < 0 ? 0 : (xi < (long)n ? xi : 0));
             return in_hist ? ph : pi;
         };
-        const long xe = (long)tile_i * TO * D - (T - 1) - JS;      // stream sample of LDS slot 0; even
+        const long xe = (long)tile_i * TOUT * D - (T - 1) - JS;    // stream sample of LDS slot 0; even
         const float4* src = reinterpret_cast<const float4*>(in_s + xe);
         // Per sweep of TO pairs: plain aligned 16-byte loads when the whole sweep lies inside this call's input (wave-uniform
         // test); only the sweeps that touch the history in front of the stream (first tile: the first ceil((T-1)/2/TO) sweeps)
@@ -137,17 +147,21 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
     DSTAMP_DECL;
     load_tile(first);
-    const float2* p = tile + threadIdx.x * (D + 2);
+    const float2* p = tile + threadIdx.x * (RD + 2);
     // A tile's outputs are stored one iteration late, just BEFORE the next prefetch is issued: loads and stores retire
     // through one in-order counter, so a store issued after the prefetch would make the wait for the prefetched tile also
     // wait for the store's acknowledgement (measured: 8 % of the kernel).
-    float2 y_prev = make_float2(0.f, 0.f);
-    float2* dst_prev = nullptr;
+    float2 y_prev[OPL];
+    float2* dst_prev = nullptr;                             // where y_prev[0] goes; the lane's other outputs follow it
     float2* fdst_prev = nullptr;
+    uint32_t nv_prev = 0, nf_prev = 0;                      // how many of the lane's outputs exist / belong to the spectrum feed
     auto store_prev = [&]() {
-        if (dst_prev) *dst_prev = y_prev;
-        if (fdst_prev) *fdst_prev = y_prev;                 // spectrum input collection (reference Decoder.h:467-473)
-        dst_prev = nullptr; fdst_prev = nullptr;
+#pragma unroll
+        for (int q = 0; q < OPL; ++q) {
+            if ((uint32_t)q < nv_prev) dst_prev[q] = y_prev[q];
+            if ((uint32_t)q < nf_prev) fdst_prev[q] = y_prev[q];   // spectrum input collection (reference Decoder.h:467-473)
+        }
+        nv_prev = nf_prev = 0;
     };
     uint32_t tile_i = first;                                // tile of stream s being computed; pf_* run one tile ahead
     for (uint32_t done = 0; done < count; ++done) {
@@ -157,7 +171,7 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const int k = threadIdx.x + it * TO;
             if (k < NP) {
                 const int jj = 2 * k;
-                *reinterpret_cast<float4*>(tile + jj + 2 * (jj / D)) = r[it];
+                *reinterpret_cast<float4*>(tile + jj + 2 * (jj / RD)) = r[it];
             }
         }
         __syncthreads();
@@ -177,61 +191,123 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // The T-term sum, in tap order.  Taps are consumed in blocks of B LDS slots (B/2 ds_read_b128 issued
         // together, then 2*B packed multiply/add) inside a rolled loop: that keeps ~B taps live in SGPRs instead
         // of all T (which spilled SGPRs through v_writelane) and puts B/2 LDS reads in flight per wave.
-        float ar = 0.f, ai = 0.f;
-        auto mac = [&](float xr, float xi, float k) { ar = ar + xr * k; ai = ai + xi * k; };
-#ifdef HD_DEC_B16   // 181 instead of 207 VGPRs for D = 32; +1 % in batch mode, -3 % alone (measured) -- not the default
-        constexpr int B = 16;
-#else
-        constexpr int B = D >= 32 ? 32 : 16;               // slots per block; pad inside a block is compile-time
-#endif
-        constexpr int NS = T + JS;                          // slots [JS, NS) carry taps [0, T)
-        constexpr int NFULL = NS / B;                       // full blocks; block 0 is peeled when JS (slot 0 unused)
-        // block 0 (peeled): slots [0, B) or the whole filter when it is shorter than a block
-        {
-            constexpr int END = NS < B ? NS : B;
-#pragma unroll
-            for (int jj = 0; jj + 1 < END + 1; jj += 2) {
-                if (jj + 1 < END || jj < END) {
+        float2 yq[OPL];
+        if constexpr (OPL == 1) {
+            float ar = 0.f, ai = 0.f;
+            auto mac = [&](float xr, float xi, float k) { ar = ar + xr * k; ai = ai + xi * k; };
+    #ifdef HD_DEC_B16   // 181 instead of 207 VGPRs for D = 32; +1 % in batch mode, -3 % alone (measured) -- not the default
+            constexpr int B = 16;
+    #else
+            constexpr int B = D >= 32 ? 32 : 16;               // slots per block; pad inside a block is compile-time
+    #endif
+            constexpr int NS = T + JS;                          // slots [JS, NS) carry taps [0, T)
+            constexpr int NFULL = NS / B;                       // full blocks; block 0 is peeled when JS (slot 0 unused)
+            // block 0 (peeled): slots [0, B) or the whole filter when it is shorter than a block
+            {
+                constexpr int END = NS < B ? NS : B;
+    #pragma unroll
+                for (int jj = 0; jj + 1 < END + 1; jj += 2) {
+                    if (jj + 1 < END || jj < END) {
+                        const float4 x = *reinterpret_cast<const float4*>(p + jj + 2 * (jj / D));
+                        if (jj >= JS && jj < END) mac(x.x, x.y, taps[jj - JS]);
+                        if (jj + 1 < END) mac(x.z, x.w, taps[jj + 1 - JS]);
+                    }
+                }
+            }
+    #ifdef HD_EXP_NOCOMPUTE
+            if (false) {
+    #else
+            if (NFULL > 1) {
+    #endif
+    #pragma unroll 1
+                for (int b = 1; b < NFULL; ++b) {
+                    const int j0 = b * B;
+                    const float2* pb = p + j0 + 2 * (j0 / D);
+                    const float* tb = taps + (j0 - JS);
+                    float4 x[B / 2];
+    #pragma unroll
+                    for (int q = 0; q < B / 2; ++q) x[q] = *reinterpret_cast<const float4*>(pb + 2 * q + 2 * ((2 * q) / D));
+    #pragma unroll
+                    for (int q = 0; q < B / 2; ++q) {
+                        mac(x[q].x, x[q].y, tb[2 * q]);
+                        mac(x[q].z, x[q].w, tb[2 * q + 1]);
+                    }
+                }
+            }
+            if (NS >= B && NS % B) {                            // tail block: slots [NFULL*B, NS)
+                constexpr int J0 = NFULL * B;
+    #pragma unroll
+                for (int jj = J0; jj < NS; jj += 2) {
                     const float4 x = *reinterpret_cast<const float4*>(p + jj + 2 * (jj / D));
-                    if (jj >= JS && jj < END) mac(x.x, x.y, taps[jj - JS]);
-                    if (jj + 1 < END) mac(x.z, x.w, taps[jj + 1 - JS]);
+                    mac(x.x, x.y, taps[jj - JS]);
+                    if (jj + 1 < NS) mac(x.z, x.w, taps[jj + 1 - JS]);
                 }
             }
-        }
-#ifdef HD_EXP_NOCOMPUTE
-        if (false) {
-#else
-        if (NFULL > 1) {
-#endif
+            yq[0] = make_float2(ar, ai);
+        } else {
+            // Lane-relative slot r holds tile sample OPL*tid*D + r - JS; output q of the lane takes it with tap r - JS - q*D.
+            float ar[OPL], ai[OPL];
+#pragma unroll
+            for (int q = 0; q < OPL; ++q) { ar[q] = 0.f; ai[q] = 0.f; }
+            constexpr int B = 16;                                       // slots per block (a multiple of the row, so pads are compile-time)
+            constexpr int W = (OPL - 1) * D + T + JS;                   // slots a lane reads
+            constexpr int NB = (W + B - 1) / B;
+            constexpr int B_LO = (JS + (OPL - 1) * D + B - 1) / B;      // first block in which every output takes every slot
+            constexpr int B_HI = (T + JS) / B - 1;                      // last such block
+            auto edge_block = [&](auto bc) {                            // head / tail blocks: per (slot, output) compile-time guards
+                constexpr int j0 = decltype(bc)::value * B;
+#pragma unroll
+                for (int k = 0; k < B; k += 2) {
+                    if (j0 + k < W) {
+                        const float4 x = *reinterpret_cast<const float4*>(p + j0 + k + 2 * ((j0 + k) / RD));
+#pragma unroll
+                        for (int q = 0; q < OPL; ++q) {
+                            const int t0 = j0 + k - JS - q * D, t1 = t0 + 1;
+                            if (t0 >= 0 && t0 < T) { ar[q] = ar[q] + x.x * taps[t0]; ai[q] = ai[q] + x.y * taps[t0]; }
+                            if (t1 >= 0 && t1 < T) { ar[q] = ar[q] + x.z * taps[t1]; ai[q] = ai[q] + x.w * taps[t1]; }
+                        }
+                    }
+                }
+            };
+            auto for_blocks = [&](auto lo, auto hi, auto self) {        // compile-time loop lo .. hi-1 over edge_block
+                if constexpr (decltype(lo)::value < decltype(hi)::value) {
+                    edge_block(lo);
+                    self(std::integral_constant<int, decltype(lo)::value + 1>{}, hi, self);
+                }
+            };
+            constexpr int HEAD_END = B_LO < NB ? (B_LO <= B_HI ? B_LO : NB) : NB;     // blocks [0, HEAD_END) are head blocks
+            for_blocks(std::integral_constant<int, 0>{}, std::integral_constant<int, HEAD_END>{}, for_blocks);
+            if constexpr (B_LO <= B_HI) {
 #pragma unroll 1
-            for (int b = 1; b < NFULL; ++b) {
-                const int j0 = b * B;
-                const float2* pb = p + j0 + 2 * (j0 / D);
-                const float* tb = taps + (j0 - JS);
-                float4 x[B / 2];
+                for (int b = B_LO; b <= B_HI; ++b) {                    // interior: rolled, ~B + (OPL-1)*D taps live in scalar registers
+                    const int j0 = b * B;
+                    const float2* pb = p + j0 + 2 * (j0 / RD);
+                    const float* tb = taps + (j0 - JS);
+                    float4 x[B / 2];
 #pragma unroll
-                for (int q = 0; q < B / 2; ++q) x[q] = *reinterpret_cast<const float4*>(pb + 2 * q + 2 * ((2 * q) / D));
+                    for (int k = 0; k < B / 2; ++k) x[k] = *reinterpret_cast<const float4*>(pb + 2 * k + 2 * ((2 * k) / RD));
 #pragma unroll
-                for (int q = 0; q < B / 2; ++q) {
-                    mac(x[q].x, x[q].y, tb[2 * q]);
-                    mac(x[q].z, x[q].w, tb[2 * q + 1]);
+                    for (int k = 0; k < B / 2; ++k) {
+#pragma unroll
+                        for (int q = 0; q < OPL; ++q) {
+                            const float k0 = tb[2 * k - q * D], k1 = tb[2 * k + 1 - q * D];
+                            ar[q] = ar[q] + x[k].x * k0; ai[q] = ai[q] + x[k].y * k0;
+                            ar[q] = ar[q] + x[k].z * k1; ai[q] = ai[q] + x[k].w * k1;
+                        }
+                    }
                 }
+                for_blocks(std::integral_constant<int, B_HI + 1>{}, std::integral_constant<int, NB>{}, for_blocks);
             }
-        }
-        if (NS >= B && NS % B) {                            // tail block: slots [NFULL*B, NS)
-            constexpr int J0 = NFULL * B;
 #pragma unroll
-            for (int jj = J0; jj < NS; jj += 2) {
-                const float4 x = *reinterpret_cast<const float4*>(p + jj + 2 * (jj / D));
-                mac(x.x, x.y, taps[jj - JS]);
-                if (jj + 1 < NS) mac(x.z, x.w, taps[jj + 1 - JS]);
-            }
+            for (int q = 0; q < OPL; ++q) yq[q] = make_float2(ar[q], ai[q]);
         }
-        const uint32_t o = tile_i * TO + threadIdx.x;
-        y_prev = make_float2(ar, ai);
-        dst_prev = o < nout ? out + (size_t)s * out_stride + (final_stage ? (size_t)fir_hist_cap + c.pend_before : 0) + o : nullptr;
-        fdst_prev = (fft_in && o < c.fft_take) ? fft_in + (size_t)s * kFftBins + c.fft_fill + o : nullptr;
-        ytile[threadIdx.x] = y_prev;
+        const uint32_t o = (tile_i * TO + threadIdx.x) * OPL;           // the lane's first output
+#pragma unroll
+        for (int q = 0; q < OPL; ++q) { y_prev[q] = yq[q]; ytile[threadIdx.x * OPL + q] = yq[q]; }
+        nv_prev = o < nout ? min((uint32_t)OPL, nout - o) : 0u;
+        dst_prev = out + (size_t)s * out_stride + (final_stage ? (size_t)fir_hist_cap + c.pend_before : 0) + o;
+        nf_prev = (fft_in && o < c.fft_take) ? min((uint32_t)OPL, c.fft_take - o) : 0u;
+        fdst_prev = fft_in ? fft_in + (size_t)s * kFftBins + c.fft_fill + o : nullptr;
         __syncthreads();                                    // everyone is done with this tile's LDS image
         DSTAMP(3);
         if (++tile_i == ntiles) {
@@ -301,7 +377,8 @@ static void launch_one(hipStream_t st, uint32_t n_streams, uint32_t max_out, con
                        const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride,
                        const StreamCall* call, int stage, int final_stage, uint32_t fir_hist_cap, float2* fft_in, uint32_t lin_wgs)
 {
-    const uint32_t ntiles = (max_out + TO - 1) / TO;
+    constexpr uint32_t TOUT = TO * dec_opl<D>();
+    const uint32_t ntiles = (max_out + TOUT - 1) / TOUT;
     // Linear split (single-wave instantiations, every stream the same size -- the caller vouches for that by passing lin_wgs):
     // exactly lin_wgs workgroups share the slab's tiles evenly.  The caller picks lin_wgs = k * CUs to decide how many of a CU's
     // eight 19.5 KB LDS slots this kernel takes -- the rest stays free for the back-half kernels of the previous call.
