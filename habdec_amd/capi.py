@@ -100,6 +100,8 @@ HOST_API = {
     "hd_host_afc_get": (None, [_vp] + [C.POINTER(_dbl)] * 4 + [C.POINTER(_int)] * 2),
     "hd_host_atan2f": (None, [_f32p, _f32p, _f32p, _sz]),
     "hd_host_discriminate": (None, [_f32p, _sz, _f, _f, _f32p]),
+    "hd_host_spectrum_payload": (_sz, [_f32p, _sz, _dbl, _dbl, _dbl, _dbl, _int, _int, _f, _int, _int, _u8p, _sz, C.POINTER(_sz)]),
+    "hd_host_demod_payload": (_sz, [_f32p, _sz, _int, _int, _u8p, _sz, C.POINTER(_sz)]),
     "hd_host_parse_time": (_int, [C.c_char_p, C.POINTER(_int), C.POINTER(_int), C.POINTER(_f)]),
     "hd_host_parse_gps_pos": (_int, [C.c_char_p, C.POINTER(_f)]),
     "hd_host_parse_sentence": (_int, [C.c_char_p, _vp]),

@@ -7,6 +7,7 @@
 #include "host/afc_tracker.hpp"
 #include "host/decim_plan.hpp"
 #include "host/fir_design.hpp"
+#include "host/gui_payload.hpp"
 #include "host/telemetry.hpp"
 #include "host/text_stage.hpp"
 #include "host/iq_file_batch.hpp"
@@ -109,6 +110,35 @@ void hd_host_atan2f(const float* y, const float* x, float* out, size_t n) { for 
 void hd_host_discriminate(const float* iq, size_t n, float pr, float pi, float* out)
 {
     for (size_t i = 0; i < n; ++i) { out[i] = hd::discriminate(iq[2 * i], iq[2 * i + 1], pr, pi); pr = iq[2 * i]; pi = iq[2 * i + 1]; }
+}
+
+/* ---- GUI payloads (habdec_ws_protocol.cpp:338-429, NetTransport.h, CompressedVector.cpp; see host/gui_payload.hpp) ---- */
+size_t hd_host_spectrum_payload(const float* bins, size_t n, double noise_floor, double noise_variance, double sampling_rate, double shift,
+                                int peak_left, int peak_right, float zoom, int resolution, int type_size, uint8_t* out, size_t cap,
+                                size_t* bins_sent)
+{
+    if (bins_sent) *bins_sent = 0;
+    if (!bins && n) return 0;
+    hd::gui::SpectrumMeta m;
+    m.noise_floor = noise_floor; m.noise_variance = noise_variance; m.sampling_rate = sampling_rate; m.shift = shift;
+    // Decoder::getSpectrumInfo (Decoder.h:823-828): the sign of a peak carries its validity
+    m.peak_left = peak_left < 0 ? -peak_left : peak_left; m.peak_left_valid = peak_left > 0;
+    m.peak_right = peak_right < 0 ? -peak_right : peak_right; m.peak_right_valid = peak_right > 0;
+    std::vector<uint8_t> o;
+    const size_t sent = hd::gui::spectrum_payload(std::vector<float>(bins, bins + n), m, zoom, resolution, type_size, o);
+    if (bins_sent) *bins_sent = sent;
+    if (out && cap >= o.size()) std::memcpy(out, o.data(), o.size());
+    return o.size();
+}
+size_t hd_host_demod_payload(const float* trace, size_t n, int resolution, int type_size, uint8_t* out, size_t cap, size_t* sent_out)
+{
+    if (sent_out) *sent_out = 0;
+    if (!trace && n) return 0;
+    std::vector<uint8_t> o;
+    const size_t sent = hd::gui::demod_payload(std::vector<float>(trace, trace + n), resolution, type_size, o);
+    if (sent_out) *sent_out = sent;
+    if (out && cap >= o.size()) std::memcpy(out, o.data(), o.size());
+    return o.size();
 }
 
 /* ---- post-decode telemetry (sentence_parse.cpp, GpsDistance.cpp; see host/telemetry.hpp) ---- */

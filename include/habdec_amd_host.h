@@ -56,6 +56,18 @@ void hd_host_afc_get(hd_host_afc*, double* correction, double* shift_hz, double*
 void hd_host_atan2f(const float* y, const float* x, float* out, size_t n);
 void hd_host_discriminate(const float* iq, size_t n, float prev_re, float prev_im, float* out);
 
+/* ---- GUI payloads: the websocket server's binary "PWR_" / "DEM_" bodies, per stream ----
+ * hd_host_spectrum_payload = SpectrumToStream (habdec_ws_protocol.cpp:355-405): zoom to the centre bins (zoom clamped to
+ * [0.01, 0.99]), thin to `resolution` bins (ShrinkVector, :338-351), quantise to type_size 1/2/4 bytes per bin against the
+ * slice's min/max (CompressedVector.cpp:75-118), behind the 52-byte SpectrumInfoHeader (NetTransport.h:29-47).  `bins` is
+ * hd_stream_power(), the scalars are hd_stream_afc() (peak_left/right signed like AFC::getPeaks) and the decimated rate.
+ * hd_host_demod_payload = DemodToStream + the 20-byte DemodHeader (:408-429, NetTransport.h:50-57) for hd_stream_demodulated().
+ * Both return the payload size in bytes (written to `out` when cap suffices) and the number of values sent. */
+size_t hd_host_spectrum_payload(const float* bins, size_t n, double noise_floor, double noise_variance, double sampling_rate, double shift,
+                                int peak_left, int peak_right, float zoom, int resolution, int type_size, uint8_t* out, size_t cap,
+                                size_t* bins_sent);
+size_t hd_host_demod_payload(const float* trace, size_t n, int resolution, int type_size, uint8_t* out, size_t cap, size_t* values_sent);
+
 /* ---- post-decode telemetry ----
  * Return convention of the parsers: 1 = parsed, 0 = the reference returns "nothing" (std::nullopt / no GPS fix / fewer than
  * six fields), -1 = an input on which the reference lets std::stoi / std::stof / std::string::at throw. */
