@@ -383,6 +383,14 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         for (auto& h : e->hist2) if (h.p) HD_HIP(hipMemset(h.p, 0, h.n * sizeof(float2)));
         for (auto& c : e->carry) HD_HIP(hipMemset(c.p, 0, c.n * sizeof(hd::DemodCarry)));
         HD_HIP(hipMemset(e->d_symstate.p, 0, S * sizeof(hd::SymState)));
+        if (const char* b0 = getenv("HD_SYM_BASE0")) {
+            // test hook: start every stream's monotonic 32-bit sample position somewhere else than 0 (e.g. just below 2^32, which
+            // a 32 kHz stream otherwise reaches after 37 hours), to exercise the wrap-around of the symbol rings' positions
+            hd::SymState st0{};
+            st0.base = st0.cached = st0.run_pos = (uint32_t)strtoul(b0, nullptr, 0);
+            std::vector<hd::SymState> v(S, st0);
+            HD_HIP(hipMemcpy(e->d_symstate.p, v.data(), S * sizeof(hd::SymState), hipMemcpyHostToDevice));
+        }
     }
     HD_HIP(hipDeviceSynchronize());
     *out = e.release();

@@ -346,6 +346,19 @@ def test_full_size_linear_split_stage1(hd, monkeypatch, wgs_per_cu):
     assert eng.sentences_ok() >= S * (len(orcs[0].sentences()) - 1)
 
 
+@pytest.mark.parametrize("base0", ["0xFFFFF000", "0xFFFFFF80", "0x7FFFFE00"])
+def test_symbol_ring_positions_wrap_around(hd, monkeypatch, base0):
+    """Positions in the symbol rings are monotonic 32-bit counters (a 32 kHz stream wraps them after 37 hours).  Started just
+    below 2^32 (and 2^31, for the signed comparisons) the decoder must produce the same bits, flips and text as the oracle."""
+    from oracle import pyoracle
+    monkeypatch.setenv("HD_SYM_BASE0", base0)
+    S, fs = 4, 2.048e6
+    iq, _ = make_streams(S, fs, 300, 8, 2, seed0=1200)
+    eng, orcs, stats = run_both(hd, pyoracle, iq, fs, factor=64, baud=300, bits=8, stops=2)
+    assert stats["demod_mismatch"] == 0                  # run_both has compared bits, backlog and text call by call
+    assert all(len(o.sentences()) >= 1 for o in orcs)
+
+
 @pytest.mark.parametrize("pipeline", [False, True])
 def test_switching_between_fused_and_unfused_back_end(hd, pipeline):
     """The DC blocker forces the unfused kernels (stage 2, DC, FIR separately, front half on the other queue); switching it
