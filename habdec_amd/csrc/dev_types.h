@@ -27,8 +27,16 @@ struct StreamCall {
     uint32_t pend_after;    // pending decimated samples left for the next call
     uint32_t dc_remove;     // 1 = per-chunk DC blocker on the decimated chunk
     uint32_t clear_pending; // 1 = rate gate hit: drop everything pending (Decoder.h:522-527)
-    uint32_t _pad;
+    uint32_t fir_taps_prev; // tap count of the stream's previous low-pass run (== fir_taps unless the design changed; see FirHistory)
 };
+
+// Low-pass history across a change of the tap count.  The reference keeps ONE buffer [history (T-1) | input (m)] per filter
+// (FirFilter.h:141-167): after a run its first T-1 slots hold the last T-1 inputs, the slots behind still hold the run's
+// input from its first sample on.  A following run with T' != T taps simply takes the first T'-1 slots as its history:
+// for T' < T the OLDEST T'-1 of the kept T-1 samples, for T' > T all T-1 of them followed by the first T'-T samples of the
+// previous run's input.  The kernels rebuild exactly that: history[j] = j < Tp-1 ? kept[j] : head_prev[j - (Tp-1)], where
+// `kept` are the last Tp-1 inputs (in the low-pass buffer) and `head_prev` the first samples of the previous run's input
+// (a small per-stream side buffer, ping-ponged like the discriminator carry; entries past what was saved count as zero).
 
 // Per-stream symbol-extractor constants (change only through the control plane).
 struct SymbolParams {

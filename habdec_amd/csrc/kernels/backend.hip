@@ -52,7 +52,9 @@ __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__
                                                        const DemodCarry* __restrict__ carry_in, DemodCarry* __restrict__ carry_out,
                                                        const StreamCall* __restrict__ call, float2* __restrict__ fft_in,
                                                        float* __restrict__ sym_ring, uint32_t ring_cap, const SymState* __restrict__ sym,
-                                                       uint32_t xin_cap /* float2 slots of the stage-2 input image, even */)
+                                                       uint32_t xin_cap /* float2 slots of the stage-2 input image, even */,
+                                                       const float2* __restrict__ head_in, const uint32_t* __restrict__ head_n_in,
+                                                       float2* __restrict__ head_out, uint32_t* __restrict__ head_n_out, uint32_t head_cap)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     // [xin: (T2-1) history + n1 chunk samples; reused for the low-pass outputs of a pass][fin: (T-1) history | pending | new]
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__
     float2* cur_w = fbuf_w + (size_t)s * fbuf_stride;
     float2* nxt = fbuf_next + (size_t)s * fbuf_stride;
     const uint32_t H = T ? T - 1 : 0;                       // low-pass history length in use
+    const uint32_t Tp = c.fir_taps_prev ? c.fir_taps_prev : T;   // tap count of the previous run (FirHistory, dev_types.h)
     const uint32_t f_old = H + pb;                          // fin slots that come from global memory
 
     BSTAMP(0);
@@ -88,6 +91,15 @@ __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__
 #pragma unroll
             for (int u = 0; u < 16; ++u) tap_touch += tt[u];
         }
+        // element k of the low-pass image [history (H) | pending]: the buffer as it is, or -- first run after a tap-count change
+        // -- the reference's view of its one buffer (FirHistory, dev_types.h)
+        auto fold = [&](uint32_t k) -> float2 {
+            if (k < H && c.fir_zero_hist) return make_float2(0.f, 0.f);
+            if (k >= H || Tp == T) return cur[fir_hist_cap - H + k];
+            if (k < Tp - 1) return cur[fir_hist_cap - (Tp - 1) + k];
+            const uint32_t h = k - (Tp - 1);
+            return h < head_n_in[s] ? head_in[(size_t)s * head_cap + h] : make_float2(0.f, 0.f);
+        };
         float2 ts[SB];
 #pragma unroll
         for (int u = 0; u < SB; ++u) { const uint32_t k = tid + u * kBeLanes; ts[u] = k < sl_deep ? cur[k + sl_off] : make_float2(0.f, 0.f); }
@@ -102,8 +114,7 @@ __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__
 #pragma unroll
         for (int u = 0; u < FB; ++u) {
             const uint32_t k = tid + u * kBeLanes;
-            tf[u] = make_float2(0.f, 0.f);
-            if (k < f_old && !(c.fir_zero_hist && k < H)) tf[u] = cur[fir_hist_cap - H + k];
+            tf[u] = k < f_old ? fold(k) : make_float2(0.f, 0.f);
         }
         if (tid < (uint32_t)(T2 - 1)) xin[tid] = th;
 #pragma unroll
@@ -120,8 +131,7 @@ __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__
             const float4 v = in4[k];
             xin[(T2 - 1) + 2 * k] = make_float2(v.x, v.y); xin[(T2 - 1) + 2 * k + 1] = make_float2(v.z, v.w);
         }
-        for (uint32_t k = tid + FB * kBeLanes; k < f_old; k += kBeLanes)
-            fin[k] = (c.fir_zero_hist && k < H) ? make_float2(0.f, 0.f) : cur[fir_hist_cap - H + k];
+        for (uint32_t k = tid + FB * kBeLanes; k < f_old; k += kBeLanes) fin[k] = fold(k);
     }
     __syncthreads();
     BSTAMP(1);
@@ -187,9 +197,15 @@ __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__
         float2 v = make_float2(0.f, 0.f);
         if (j - lds_from < f_old + n2) {
             v = fin[j - lds_from];
-            if (c.fir_zero_hist && j < fir_hist_cap) v = cur[j];         // the image holds zeros there; the slide moves the buffer as it is
+            if ((c.fir_zero_hist || Tp != T) && j < fir_hist_cap) v = cur[j];   // the image differs there; the slide moves the buffer as it is
         } else v = cur[j];
         nxt[k] = v;
+    }
+    {   // head of this run's input, for a later run with a different tap count (FirHistory); an idle stream keeps its old one
+        const bool ran = m && T;
+        const uint32_t hn = ran ? min(m, head_cap) : head_n_in[s];
+        for (uint32_t k = tid; k < hn; k += kBeLanes) head_out[(size_t)s * head_cap + k] = ran ? fin[H + k] : head_in[(size_t)s * head_cap + k];
+        if (tid == 0) head_n_out[s] = hn;
     }
     if (!m || !T) {
         if (tid == 0) carry_out[s] = carry_in[s];           // low-pass did not run: discriminator carry passes through
@@ -296,7 +312,8 @@ bool launch_backend(hipStream_t st, int ratio2, int ntaps2, uint32_t n_streams, 
                     const float2* dec1, size_t dec1_stride, const float2* hist2_in, float2* hist2_out, const float* taps2,
                     const float2* fbuf, float2* fbuf_w, float2* fbuf_next, size_t fbuf_stride, uint32_t fir_hist_cap, const float* lp_taps,
                     uint32_t taps_stride, float* demod, size_t demod_stride, float2* filtered, const DemodCarry* carry_in,
-                    DemodCarry* carry_out, const StreamCall* call, float2* fft_in, float* sym_ring, uint32_t ring_cap, const SymState* sym)
+                    DemodCarry* carry_out, const StreamCall* call, float2* fft_in, float* sym_ring, uint32_t ring_cap, const SymState* sym,
+                    const float2* head_in, const uint32_t* head_n_in, float2* head_out, uint32_t* head_n_out, uint32_t head_cap)
 {
     const size_t lds = backend_lds_bytes(ntaps2, max_n1, max_n2, max_taps);
     if (lds > 64 * 1024) return false;
@@ -306,7 +323,7 @@ bool launch_backend(hipStream_t st, int ratio2, int ntaps2, uint32_t n_streams, 
     if (ratio2 == D && ntaps2 == T) {                                                                                                 \
         hipLaunchKernelGGL((k_backend<D, T>), dim3(n_streams), dim3(kBeLanes), lds, st, dec1, dec1_stride, hist2_in, hist2_out, taps2, \
                            fbuf, fbuf_w, fbuf_next, fbuf_stride, fir_hist_cap, lp_taps, taps_stride, demod, demod_stride, filtered,   \
-                           carry_in, carry_out, call, fft_in, sym_ring, ring_cap, sym, (uint32_t)xin_cap);                            \
+                           carry_in, carry_out, call, fft_in, sym_ring, ring_cap, sym, (uint32_t)xin_cap, head_in, head_n_in, head_out, head_n_out, head_cap);                            \
         return true;                                                                                                                  \
     }
     HD_BE_CASE(2, 69) HD_BE_CASE(4, 139)

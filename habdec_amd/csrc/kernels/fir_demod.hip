@@ -38,12 +38,15 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
                                                           DemodCarry* __restrict__ carry_out,
                                                           const StreamCall* __restrict__ call, uint32_t fir_hist_cap,
                                                           float* __restrict__ sym_ring, uint32_t ring_cap,
-                                                          const SymState* __restrict__ sym, float2* __restrict__ fbuf_next)
+                                                          const SymState* __restrict__ sym, float2* __restrict__ fbuf_next,
+                                                          const float2* __restrict__ head_in, const uint32_t* __restrict__ head_n_in,
+                                                          float2* __restrict__ head_out, uint32_t* __restrict__ head_n_out, uint32_t head_cap)
 {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];   // [kFirTile + T + 1] inputs, then reused for outputs
     const uint32_t s = blockIdx.y;
     const StreamCall c = call[s];
     const uint32_t m = c.fir_m, T = c.fir_taps;
+    const uint32_t Tp = c.fir_taps_prev ? c.fir_taps_prev : T;     // tap count of the previous run
     const float2* buf = fbuf + (size_t)s * stride;                 // history occupies [fir_hist_cap-(T-1), fir_hist_cap)
     if (fbuf_next) {
         // Slide [history | leftover pending] to the front of the OTHER buffer for the next call (ping-pong instead of
@@ -58,6 +61,14 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
 #pragma unroll
             for (int u = 0; u < SB; ++u) { const uint32_t k = k0 + u * gridDim.x * kFirLanes; if (k < cnt) nx[k] = v[u]; }
         }
+    }
+    // head of this run's input for a later run with a different tap count (FirHistory, dev_types.h); an idle stream keeps its old one
+    if (blockIdx.x == 0) {
+        const float2* hi = head_in + (size_t)s * head_cap;
+        float2* ho = head_out + (size_t)s * head_cap;
+        const uint32_t hn = (m && T) ? min(m, head_cap) : head_n_in[s];
+        for (uint32_t k = threadIdx.x; k < hn; k += kFirLanes) ho[k] = (m && T) ? buf[fir_hist_cap + k] : hi[k];
+        if (threadIdx.x == 0) head_n_out[s] = hn;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && m == 0) carry_out[s] = carry_in[s];   // idle stream: carry passes through
     if (!m || !T) return;
@@ -74,7 +85,14 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
         for (int u = 0; u < LB; ++u) {
             const long b = b0 + (long)(j0 + u * kFirLanes);
             v[u] = make_float2(0.f, 0.f);
-            if (j0 + u * kFirLanes < need && b >= 0 && b < end && !(c.fir_zero_hist && b < (long)fir_hist_cap)) v[u] = buf[b];
+            if (j0 + u * kFirLanes < need && b >= 0 && b < end && !(c.fir_zero_hist && b < (long)fir_hist_cap)) {
+                if (Tp == T || b >= (long)fir_hist_cap) v[u] = buf[b];
+                else {                                           // first run after a tap-count change: FirHistory
+                    const uint32_t j = (uint32_t)(b - ((long)fir_hist_cap - (long)(T - 1)));      // history slot, 0 = oldest
+                    if (j < Tp - 1) v[u] = buf[fir_hist_cap - (Tp - 1) + j];
+                    else if (j - (Tp - 1) < head_n_in[s]) v[u] = head_in[(size_t)s * head_cap + j - (Tp - 1)];
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < LB; ++u) if (j0 + u * kFirLanes < need) lds[j0 + u * kFirLanes] = v[u];
@@ -186,13 +204,14 @@ void launch_fetch_params(hipStream_t st, const void* host_mapped, void* dst, siz
 void launch_fir_demod(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_taps, const float2* fbuf, size_t stride,
                       const float* taps, uint32_t taps_stride, float* demod, size_t demod_stride, float2* filtered,
                       const DemodCarry* carry_in, DemodCarry* carry_out, const StreamCall* call, uint32_t fir_hist_cap,
-                      float* sym_ring, uint32_t ring_cap, const SymState* sym, float2* fbuf_next)
+                      float* sym_ring, uint32_t ring_cap, const SymState* sym, float2* fbuf_next,
+                      const float2* head_in, const uint32_t* head_n_in, float2* head_out, uint32_t* head_n_out, uint32_t head_cap)
 {
     const uint32_t tiles = max_m ? (max_m + kFirAdvance - 1) / kFirAdvance : 1;
     const size_t lds = (size_t)(kFirTile + (max_taps ? max_taps : 1) + 2) * sizeof(float2);
     dim3 grid(tiles, n_streams);
     hipLaunchKernelGGL(k_fir_demod, grid, dim3(kFirLanes), lds, st, fbuf, stride, taps, taps_stride, demod, demod_stride, filtered,
-                       carry_in, carry_out, call, fir_hist_cap, sym_ring, ring_cap, sym, fbuf_next);
+                       carry_in, carry_out, call, fir_hist_cap, sym_ring, ring_cap, sym, fbuf_next, head_in, head_n_in, head_out, head_n_out, head_cap);
 }
 
 void launch_fft_feed(hipStream_t st, uint32_t n_streams, const float2* fbuf, size_t stride, float2* fft_in, const StreamCall* call,

@@ -37,7 +37,8 @@ void launch_spectrum_commit(hipStream_t st, uint32_t n_streams, const float2* ra
 void launch_fir_demod(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_taps, const float2* fbuf, size_t stride,
                       const float* taps, uint32_t taps_stride, float* demod, size_t demod_stride, float2* filtered /*or null*/,
                       const DemodCarry* carry_in, DemodCarry* carry_out, const StreamCall* call, uint32_t fir_hist_cap,
-                      float* sym_ring, uint32_t ring_cap, const SymState* sym, float2* fbuf_next);
+                      float* sym_ring, uint32_t ring_cap, const SymState* sym, float2* fbuf_next,
+                      const float2* head_in, const uint32_t* head_n_in, float2* head_out, uint32_t* head_n_out, uint32_t head_cap /* FirHistory, dev_types.h */);
 // Fused back end of a two-stage plan (second decimation stage + low-pass + discriminator + slide), one workgroup per stream;
 // returns false when the stage design or the LDS footprint (see backend_lds_bytes) does not allow it -- the caller then
 // runs launch_decimate(stage 2) + launch_fir_demod.  `fbuf` and `fbuf_w` are the same buffer (read: history + pending,
@@ -47,7 +48,8 @@ bool launch_backend(hipStream_t st, int ratio2, int ntaps2, uint32_t n_streams, 
                     const float2* dec1, size_t dec1_stride, const float2* hist2_in, float2* hist2_out, const float* taps2,
                     const float2* fbuf, float2* fbuf_w, float2* fbuf_next, size_t fbuf_stride, uint32_t fir_hist_cap, const float* lp_taps,
                     uint32_t taps_stride, float* demod, size_t demod_stride, float2* filtered, const DemodCarry* carry_in,
-                    DemodCarry* carry_out, const StreamCall* call, float2* fft_in, float* sym_ring, uint32_t ring_cap, const SymState* sym);
+                    DemodCarry* carry_out, const StreamCall* call, float2* fft_in, float* sym_ring, uint32_t ring_cap, const SymState* sym,
+                    const float2* head_in, const uint32_t* head_n_in, float2* head_out, uint32_t* head_n_out, uint32_t head_cap);
 // Symbol extractor: window kernel over the positions that became computable (at most max_new per stream) + scan kernel.
 void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_new, uint32_t max_R, const float* tail,
                     uint32_t ring_cap, SymState* sym, unsigned long long* flipmask, float* weight, const SymbolParams* sp,

@@ -363,8 +363,10 @@ class Decoder:
             self._held = fn("symex_held", _sz, _vp)
             self._reset = fn("reset_correction", None, _vp, _dbl)
         assert fn("setup_factor", _int, _vp, _sz if kind == "oracle" else _int)(self.h, factor) == factor or factor == 1
-        fn("baud", None, _vp, _dbl)(self.h, baud)
-        fn("rtty", None, _vp, _sz, C.c_float)(self.h, bits, stops)
+        self._baud = fn("baud", None, _vp, _dbl)
+        self._rtty = fn("rtty", None, _vp, _sz, C.c_float)
+        self._baud(self.h, baud)
+        self._rtty(self.h, bits, stops)
         self._dc_remove = fn("dc_remove", None, _vp, _int)
         self._dc_remove(self.h, int(dc_remove))
         self._lp_bw = fn("lowpass_bw", None, _vp, C.c_float)
@@ -402,6 +404,12 @@ class Decoder:
 
     def set_dc_remove(self, on: bool):
         self._dc_remove(self.h, int(on))
+
+    def set_baud(self, baud: float):
+        self._baud(self.h, baud)
+
+    def set_rtty(self, bits: int, stops: float):
+        self._rtty(self.h, bits, stops)
 
     def array(self, which: str) -> np.ndarray:
         p = C.POINTER(C.c_float)()

@@ -359,6 +359,43 @@ def test_symbol_ring_positions_wrap_around(hd, monkeypatch, base0):
     assert all(len(o.sentences()) >= 1 for o in orcs)
 
 
+@pytest.mark.parametrize("dc", [False, True])
+def test_control_plane_changes_mid_stream(hd, dc):
+    """baud / framing / low-pass bandwidth and transition set while samples flow (websocket clients do that): the symbol
+    extractor restarts its caches, the framer its bit queue, a bandwidth change with an unchanged tap count does NOT redesign
+    the filter (Q8), and a changed tap count reuses the filter's one buffer the way FirFilter does (stale-history transient)
+    -- all exactly as in the reference, call by call.  With the unfused back end (DC blocker on) as well."""
+    import habdec_amd
+    from oracle import pyoracle
+    S, fs = 3, 2.048e6
+    iq, _ = make_streams(S, fs, 300, 8, 2, seed0=1500, repeat=5)
+    nch = iq.shape[1] // C
+    assert nch >= 13
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=64, baud=300, rtty_bits=8, rtty_stops=2, keep_filtered=True, dc_remove=dc)
+    orcs = [pyoracle.Decoder("oracle", factor=64, baud=300, bits=8, stops=2, dc_remove=dc) for _ in range(S)]
+    plan = {2: ("baud", 100.0), 3: ("baud", 300.0), 4: ("lp_bw", 2000.0), 5: ("rtty", (7, 1.0)), 6: ("rtty", (8, 2.0)), 7: ("lp_bw", 1500.0),
+            8: ("lp_trans", 0.05), 9: ("lp_trans", 0.01), 10: ("lp_trans", 0.025), 11: ("lp_trans", 0.004)}     # 161 -> 81 -> 401 -> 161 -> 1001 taps
+    for k in range(nch):
+        if k in plan:
+            what, v = plan[k]
+            for s in range(S):
+                if what == "baud": eng.set_baud(s, v); orcs[s].set_baud(v)
+                elif what == "lp_bw": eng.set_lowpass_bw(s, v); orcs[s].lowpass_bw(v)
+                elif what == "lp_trans": eng.set_lowpass_trans(s, v); orcs[s].lowpass_trans(v)
+                else: eng.set_rtty(s, *v); orcs[s].set_rtty(int(v[0]), v[1])
+        eng.process_host(np.ascontiguousarray(iq[:, k * C:(k + 1) * C]))
+        for s in range(S):
+            o = orcs[s]
+            o(iq[s, k * C:(k + 1) * C], fs)
+            assert same_bits(eng.filtered(s), o.array("last_filtered")), ("filtered", k, s)
+            assert same_bits(eng.demodulated(s), o.array("last_demod")), ("demod", k, s)
+            assert np.array_equal(eng.bits(s), o.bits()), ("bits", k, s)
+            assert eng.symbol_backlog(s) == o.symex_held(), ("backlog", k, s)
+    for s in range(S):
+        assert eng.rtty(s) == orcs[s].text("rtty_stream") and eng.take_chars(s) == orcs[s].text("chars_log")
+        assert eng.take_sentences(s) == orcs[s].sentences()
+
+
 @pytest.mark.parametrize("pipeline", [False, True])
 def test_switching_between_fused_and_unfused_back_end(hd, pipeline):
     """The DC blocker forces the unfused kernels (stage 2, DC, FIR separately, front half on the other queue); switching it

@@ -231,3 +231,31 @@ def test_whole_chain_identical(case, ctx):
         want = [s[2:] for s in text.strip().split("\n")]
         got = do.sentences()   # the scan only runs while >20 chars are buffered, so a short last line may wait
         assert got == want[:len(got)] and len(got) >= len(want) - 1 and len(got) >= 1
+
+
+def test_whole_chain_with_control_plane_changes_mid_stream(ctx):
+    """baud / framing / low-pass bandwidth and transition changed while samples flow: the oracle's Decoder must follow the
+    reference's stage classes through every change (symbol-extractor restart, framer restart, the Q8 'same tap count -> no
+    redesign' rule, and a transition change that does redesign)."""
+    fs, C = 2.048e6, 65536
+    text = synth.make_sentence("CTRL", "1,12:00:00,52.1234,21.4321,1000") * 4
+    iq = synth.fsk_iq_for_text(text, fs, 300, 8, 2, sigma=0.08, seed=77, idle_before=8, idle_after=16)
+    kw = dict(factor=64, baud=300, bits=8, stops=2, mathh_context=ctx)
+    do, dr = pyoracle.Decoder("oracle", **kw), pyoracle.Decoder("ref", **kw)
+    plan = {2: ("baud", 100.0), 3: ("baud", 300.0), 4: ("lp_bw", 2000.0), 5: ("rtty", (7, 1.0)), 6: ("rtty", (8, 2.0)), 7: ("lp_trans", 0.05),
+            9: ("lp_bw", 1500.0), 10: ("lp_trans", 0.025)}
+    for k, i in enumerate(range(0, len(iq), C)):
+        if k in plan:
+            what, v = plan[k]
+            for d in (do, dr):
+                if what == "baud": d.set_baud(v)
+                elif what == "lp_bw": d.lowpass_bw(v)
+                elif what == "lp_trans": d.lowpass_trans(v)
+                else: d.set_rtty(int(v[0]), v[1])
+        do(iq[i:i + C], fs); dr(iq[i:i + C], fs)
+        for which in ("last_decimated", "last_filtered", "last_demod"):
+            assert same_bits(do.array(which), dr.array(which)), (which, k)
+        assert np.array_equal(do.bits(), dr.bits()), k
+    for which in ("rtty_stream", "last_sentence", "sentence_log", "match_log", "chars_log"):
+        assert do.text(which) == dr.text(which), which
+    assert len(do.sentences()) >= 1
