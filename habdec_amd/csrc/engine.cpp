@@ -129,8 +129,8 @@ struct hd_engine {
     DevBuf<uint32_t> flips_dbg;
     DevBuf<hd::SymState> d_symstate;
     DevBuf<hd::DemodCarry> carry[2];
-    DevBuf<float2> fir_head[2];       // first samples of the previous low-pass run's input (FirHistory, dev_types.h), with the carries' parity
-    DevBuf<uint32_t> fir_head_n[2];
+    DevBuf<float2> fir_head;          // [2][S][head_cap]: first samples of the previous low-pass run's input (FirHistory, dev_types.h), halves alternate like the carries
+    DevBuf<uint32_t> fir_head_n;      // [2][S]
     uint32_t head_cap = 0;
     DevBuf<hd::SymbolParams> d_sym;
     PinBuf<hd::SymbolParams> h_sym;
@@ -329,8 +329,8 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     if (e->flips_cap) HD_HIP(e->flips_dbg.alloc((size_t)S * e->flips_cap));
     for (auto& c : e->carry) HD_HIP(c.alloc(S));
     e->head_cap = std::min<uint32_t>(e->taps_cap, 8192u);   // a tap-count jump of more than 8192 reads zeros beyond (documented)
-    for (auto& h : e->fir_head) HD_HIP(h.alloc((size_t)S * e->head_cap));
-    for (auto& h : e->fir_head_n) HD_HIP(h.alloc(S));
+    HD_HIP(e->fir_head.alloc((size_t)2 * S * e->head_cap));
+    HD_HIP(e->fir_head_n.alloc((size_t)2 * S));
     HD_HIP(e->d_sym.alloc(S));
     HD_HIP(e->h_sym.alloc(S));
     for (auto& sl : e->slot) {
@@ -382,7 +382,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         }
         hd::launch_fir_demod(q, S, 0, 0, e->fbuf[0].p, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S, nullptr, e->carry[0].p,
                              e->carry[1].p, sl.d_call.p, e->fir_hist_cap, e->tail.p, e->tail_cap, e->d_symstate.p, e->fbuf[1].p,
-                             e->fir_head[0].p, e->fir_head_n[0].p, e->fir_head[1].p, e->fir_head_n[1].p, e->head_cap);
+                             e->fir_head.p, e->fir_head_n.p, e->fir_head.p + (size_t)S * e->head_cap, e->fir_head_n.p + S, e->head_cap);
         hd::launch_symbols(q, S, 1, 1, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p, sl.d_call.p,
                            sl.h_slots.dev, e->slot_words, nullptr, 0, e->min_R);
         HD_HIP(hipStreamSynchronize(q));
@@ -390,7 +390,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         for (auto& h : e->hist1) if (h.p) HD_HIP(hipMemset(h.p, 0, h.n * sizeof(float2)));
         for (auto& h : e->hist2) if (h.p) HD_HIP(hipMemset(h.p, 0, h.n * sizeof(float2)));
         for (auto& c : e->carry) HD_HIP(hipMemset(c.p, 0, c.n * sizeof(hd::DemodCarry)));
-        for (auto& h : e->fir_head_n) HD_HIP(hipMemset(h.p, 0, h.n * sizeof(uint32_t)));
+        HD_HIP(hipMemset(e->fir_head_n.p, 0, e->fir_head_n.n * sizeof(uint32_t)));
         HD_HIP(hipMemset(e->d_symstate.p, 0, S * sizeof(hd::SymState)));
         if (const char* b0 = getenv("HD_SYM_BASE0")) {
             // test hook: start every stream's monotonic 32-bit sample position somewhere else than 0 (e.g. just below 2^32, which
@@ -760,15 +760,14 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         if (!hd::launch_backend(qb, (int)R2, (int)T2, S, max_n1, max_n2, max_taps, d1, e->n1_cap, e->hist2[hin].p, e->hist2[hout].p,
                                 e->stage_taps[1].p, fcur, fcur, fnext, e->fbuf_stride, e->fir_hist_cap, e->lp_taps.p, e->taps_cap, e->demod.p,
                                 e->demod.n / S, e->cfg.keep_filtered ? e->filtered.p : nullptr, e->carry[cin].p, e->carry[cout].p, dcall, feed,
-                                e->tail.p, e->tail_cap, e->d_symstate.p, e->fir_head[cin].p, e->fir_head_n[cin].p, e->fir_head[cout].p,
-                                e->fir_head_n[cout].p, e->head_cap))
+                                e->tail.p, e->tail_cap, e->d_symstate.p, e->fir_head.p, e->fir_head_n.p, e->head_cap, (uint32_t)cin))
             return fail(HD_ERR_INVALID, "fused back end refused a shape it was selected for");
         if (const int r = spectrum(qb)) return r;
     } else {
         hd::launch_fir_demod(qb, S, max_m, max_taps, fcur, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S,
                              e->cfg.keep_filtered ? e->filtered.p : nullptr, e->carry[cin].p, e->carry[cout].p, dcall, e->fir_hist_cap,
-                             e->tail.p, e->tail_cap, e->d_symstate.p, fnext, e->fir_head[cin].p, e->fir_head_n[cin].p, e->fir_head[cout].p,
-                             e->fir_head_n[cout].p, e->head_cap);
+                             e->tail.p, e->tail_cap, e->d_symstate.p, fnext, e->fir_head.p + (size_t)cin * S * e->head_cap, e->fir_head_n.p + (size_t)cin * S,
+                             e->fir_head.p + (size_t)cout * S * e->head_cap, e->fir_head_n.p + (size_t)cout * S, e->head_cap);
     }
     mark();
     mark();

@@ -49,7 +49,7 @@ bool launch_backend(hipStream_t st, int ratio2, int ntaps2, uint32_t n_streams, 
                     const float2* fbuf, float2* fbuf_w, float2* fbuf_next, size_t fbuf_stride, uint32_t fir_hist_cap, const float* lp_taps,
                     uint32_t taps_stride, float* demod, size_t demod_stride, float2* filtered, const DemodCarry* carry_in,
                     DemodCarry* carry_out, const StreamCall* call, float2* fft_in, float* sym_ring, uint32_t ring_cap, const SymState* sym,
-                    const float2* head_in, const uint32_t* head_n_in, float2* head_out, uint32_t* head_n_out, uint32_t head_cap);
+                    float2* head_buf /* [2][S][head_cap] */, uint32_t* head_cnt /* [2][S] */, uint32_t head_cap, uint32_t head_par);
 // Symbol extractor: window kernel over the positions that became computable (at most max_new per stream) + scan kernel.
 void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_new, uint32_t max_R, const float* tail,
                     uint32_t ring_cap, SymState* sym, unsigned long long* flipmask, float* weight, const SymbolParams* sp,
