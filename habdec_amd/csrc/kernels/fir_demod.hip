@@ -85,12 +85,18 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
         for (int u = 0; u < LB; ++u) {
             const long b = b0 + (long)(j0 + u * kFirLanes);
             v[u] = make_float2(0.f, 0.f);
-            if (j0 + u * kFirLanes < need && b >= 0 && b < end && !(c.fir_zero_hist && b < (long)fir_hist_cap)) {
-                if (Tp == T || b >= (long)fir_hist_cap) v[u] = buf[b];
-                else {                                           // first run after a tap-count change: FirHistory
+            if (j0 + u * kFirLanes < need && b >= 0 && b < end && !(c.fir_zero_hist && b < (long)fir_hist_cap)) v[u] = buf[b];
+        }
+        if (Tp != T && !c.fir_zero_hist) {                       // first run after a tap-count change (wave-uniform, rare): FirHistory
+            const uint32_t head_n = head_n_in[s];
+#pragma unroll
+            for (int u = 0; u < LB; ++u) {
+                const long b = b0 + (long)(j0 + u * kFirLanes);
+                if (j0 + u * kFirLanes < need && b >= (long)fir_hist_cap - (long)(T - 1) && b < (long)fir_hist_cap) {
                     const uint32_t j = (uint32_t)(b - ((long)fir_hist_cap - (long)(T - 1)));      // history slot, 0 = oldest
+                    v[u] = make_float2(0.f, 0.f);
                     if (j < Tp - 1) v[u] = buf[fir_hist_cap - (Tp - 1) + j];
-                    else if (j - (Tp - 1) < head_n_in[s]) v[u] = head_in[(size_t)s * head_cap + j - (Tp - 1)];
+                    else if (j - (Tp - 1) < head_n) v[u] = head_in[(size_t)s * head_cap + j - (Tp - 1)];
                 }
             }
         }
