@@ -117,13 +117,13 @@ struct hd_engine {
     int last_fuse = -1;
     uint32_t n_cus = 0, dec_wgs_per_cu = 0;   // stage-1 linear split: workgroups per CU (0 = classic grid), see kernels/decimate.hip        // path of the previous call (the two paths use the stage-2 buffers on different queues)
     hipStream_t qa = nullptr, qb = nullptr, qc = nullptr;   // front (decimation, spectrum) and back (FIR, symbols, results) HIP streams
-    bool timing_on = true;
+    uint32_t timing_every = 8;   // HIP-event timing on every Nth call (0 = off): each event record is a barrier packet worth ~6 us of queue time
     hd_timing last_timing{};
     rocfft_plan fft_plan = nullptr;
     rocfft_execution_info fft_info = nullptr;
     DevBuf<char> fft_work;
 
-    DevBuf<float2> staging, dec1, dec1b, hist1[2], hist2[2], fbuf[2], fft_in, fft_raw, spec, filtered;   // dec1/dec1b: stage-1 output, alternating per call
+    DevBuf<float2> staging, dec1, dec1b, dec1c, hist1[2], hist2[2], fbuf[2], fft_in, fft_raw, spec, filtered;   // dec1/b/c: stage-1 output, rotating per call
     DevBuf<float> stage_taps[2], lp_taps, power, demod, tail, weight;
     DevBuf<unsigned long long> flipmask;
     DevBuf<uint32_t> flips_dbg;
@@ -141,6 +141,7 @@ struct hd_engine {
         PinBuf<hd::StreamCall> h_call;
         PinBuf<uint32_t> h_slots;                 // written by the symbol scan kernel over PCIe (zero-copy), read after ev_done
         PinBuf<hd::SpectrumStatsDev> h_stats;    // written by the spectrum kernel
+        bool timed = false;                       // this call carries the timing events
         hipEvent_t ev_front = nullptr, ev_done = nullptr, ev_params = nullptr, t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr;
         bool busy = false;
         uint64_t total_in = 0;
@@ -307,7 +308,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
 
     // device memory
     HD_HIP(e->staging.alloc((size_t)S * cfg->max_chunk));
-    if (e->stages.size() == 2) { HD_HIP(e->dec1.alloc((size_t)S * e->n1_cap)); HD_HIP(e->dec1b.alloc((size_t)S * e->n1_cap)); }
+    if (e->stages.size() == 2) for (auto* b : {&e->dec1, &e->dec1b, &e->dec1c}) HD_HIP(b->alloc((size_t)S * e->n1_cap));
     if (e->stages.size() >= 1) {
         for (auto& h : e->hist1) HD_HIP(h.alloc((size_t)S * (e->stages[0].taps.size() - 1)));
         HD_HIP(e->stage_taps[0].alloc(e->stages[0].taps.size()));
@@ -418,7 +419,7 @@ uint32_t hd_engine_streams(const hd_engine* e) { return e ? e->S : 0; }
 uint32_t hd_engine_decimation(const hd_engine* e) { return e ? e->D : 0; }
 double hd_engine_decimated_rate(const hd_engine* e) { return e ? e->fsd : 0; }
 uint64_t hd_engine_sentences_ok(const hd_engine* e) { return e ? e->sentences_ok : 0; }
-void hd_engine_set_timing(hd_engine* e, int on) { if (e) e->timing_on = on != 0; }
+void hd_engine_set_timing(hd_engine* e, int on) { if (e) e->timing_every = on < 0 ? 0u : (uint32_t)on; }
 int hd_engine_timing(hd_engine* e, hd_timing* out)
 {
     if (!e || !out) return fail(HD_ERR_INVALID, "null argument");
@@ -504,7 +505,7 @@ int collect(hd_engine* e, hd_engine::CallSlot& sl)
     HD_HIP(hipEventSynchronize(sl.ev_done));
     const auto w1 = std::chrono::steady_clock::now();
     sl.busy = false;
-    if (e->timing_on) {
+    if (sl.timed) {
         float a = 0, b = 0;
         HD_HIP(hipEventElapsedTime(&a, sl.t0, sl.t3));
         HD_HIP(hipEventElapsedTime(&b, sl.t1, sl.t2));
@@ -668,13 +669,29 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     double tp[12]; int ntp = 0;
     auto mark = [&] { if (ntp < 12) tp[ntp++] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count(); };
     mark();
-    // With two calls in flight the front half of call k could otherwise overwrite the low-pass input buffer that the
-    // back half of call k-2 is still reading (same ping-pong parity): order it behind that call's completion.
-    if (e->calls >= 2 && !e->one_stream) HD_HIP(hipStreamWaitEvent(qa, e->slot[(e->calls - 2) % hd_engine::kSlots].ev_done, 0));
-    if (e->timing_on) HD_HIP(hipEventRecord(sl.t0, qa));
-    // the parameter block is pulled on its own queue, so it does not wait for the previous call's stage 1 to drain
-    hd::launch_fetch_params(e->qc, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
-    if (!e->one_stream) { HD_HIP(hipEventRecord(sl.ev_params, e->qc)); HD_HIP(hipStreamWaitEvent(qa, sl.ev_params, 0)); }
+    // Two-stage plans at batch-decoding sizes: stage 2, low-pass, discriminator and slide run as ONE kernel per call on qb
+    // (kernels/backend.hip) when a stream's call fits in LDS and no DC blocker sits in between.
+    const bool fuse = nst == 2 && !any_dc && !e->no_fuse && ((R2 == 2 && T2 == 69) || (R2 == 4 && T2 == 139)) &&
+                      hd::backend_lds_bytes((int)T2, max_n1, max_n2, max_taps) <= 64 * 1024;
+    if (e->last_fuse >= 0 && e->last_fuse != (int)fuse) { HD_HIP(hipStreamSynchronize(qa)); HD_HIP(hipStreamSynchronize(qb)); }   // path switch: drain
+    e->last_fuse = (int)fuse;
+    // Cross-queue event waits cost ~18 us each on this platform (kernel trace: stage 1 of call k+1 started 37 us after stage 1
+    // of call k ended, two barrier packets later).  On the fused path the stage-1 queue therefore waits for NOTHING: it reads the
+    // call's parameters straight from the mapped host block (32 bytes per workgroup), its output rotates over three buffers --
+    // the one it writes was last read by call k-2, which the host has already collected -- and the parameter fetch for the back
+    // half rides in front of the back end on qb.  The unfused path keeps the fetch queue and the ordering behind call k-2 (its
+    // front half writes the low-pass buffer the back half of call k-2 may still be reading).
+    const bool lean = fuse && !e->one_stream;
+    if (!lean && e->calls >= 2 && !e->one_stream) HD_HIP(hipStreamWaitEvent(qa, e->slot[(e->calls - 2) % hd_engine::kSlots].ev_done, 0));
+    sl.timed = e->timing_every && (e->calls % e->timing_every) == 0;
+    if (sl.timed) HD_HIP(hipEventRecord(sl.t0, qa));
+    if (lean) {
+        if (e->sym_dirty && e->calls > e->delivered) { if (int rc = flush_locked(e)) return rc; }   // symbol parameters are uploaded below: nothing may still read them
+    } else {
+        // the parameter block is pulled on its own queue, so it does not wait for the previous call's stage 1 to drain
+        hd::launch_fetch_params(e->qc, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
+        if (!e->one_stream) { HD_HIP(hipEventRecord(sl.ev_params, e->qc)); HD_HIP(hipStreamWaitEvent(qa, sl.ev_params, 0)); }
+    }
     for (uint32_t s = 0; s < S; ++s) {
         StreamHost& st = e->st[s];
         if (!st.taps_dirty) continue;
@@ -701,29 +718,23 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     float2* fcur = e->fbuf[e->cur].p;
     float2* fnext = e->fbuf[e->cur ^ 1].p;
     const hd::StreamCall* dcall = sl.d_call.p;
-    // Two-stage plans at batch-decoding sizes: stage 2, low-pass, discriminator and slide run as ONE kernel per call on qb
-    // (kernels/backend.hip) when a stream's call fits in LDS and no DC blocker sits in between.
-    const bool fuse = nst == 2 && !any_dc && !e->no_fuse && ((R2 == 2 && T2 == 69) || (R2 == 4 && T2 == 139)) &&
-                      hd::backend_lds_bytes((int)T2, max_n1, max_n2, max_taps) <= 64 * 1024;
-    if (e->last_fuse >= 0 && e->last_fuse != (int)fuse) { HD_HIP(hipStreamSynchronize(qa)); HD_HIP(hipStreamSynchronize(qb)); }   // path switch: drain
-    e->last_fuse = (int)fuse;
-    float2* d1 = (e->calls & 1) ? e->dec1b.p : e->dec1.p;   // call k+1's stage 1 (qa) may overwrite nothing call k's back half (qb) reads
+    float2* d1 = (e->calls % 3 == 0) ? e->dec1.p : (e->calls % 3 == 1) ? e->dec1b.p : e->dec1c.p;   // never a buffer a call in flight still reads
     const int hin = e->hist_cur, hout = e->hist_cur ^ 1;
     // spectrum collection rides in the final stage's epilogue unless the DC blocker must see the samples first
     float2* feed = (e->cfg.enable_spectrum && !any_dc) ? e->fft_in.p : nullptr;
     if (nst == 0) {
-        if (e->timing_on) HD_HIP(hipEventRecord(sl.t1, qa));
+        if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
         hd::launch_passthrough(qa, S, max_in, iq, stride, fcur, e->fbuf_stride, dcall, e->fir_hist_cap);
-        if (e->timing_on) HD_HIP(hipEventRecord(sl.t2, qa));
+        if (sl.timed) HD_HIP(hipEventRecord(sl.t2, qa));
     } else {
         const bool single = nst == 1;
         float2* out1 = single ? fcur : d1;
         const size_t out1_stride = single ? e->fbuf_stride : e->n1_cap;
-        if (e->timing_on) HD_HIP(hipEventRecord(sl.t1, qa));
+        if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
         if (!hd::launch_decimate(qa, R1, T1, S, max_n1, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
-                                 dcall, 0, single ? 1 : 0, e->fir_hist_cap, single ? feed : nullptr, (min_in == max_in && max_in) ? e->dec_wgs_per_cu * e->n_cus : 0u))
+                                 lean ? sl.h_call.dev : dcall, 0, single ? 1 : 0, e->fir_hist_cap, single ? feed : nullptr, (min_in == max_in && max_in) ? e->dec_wgs_per_cu * e->n_cus : 0u))
             return fail(HD_ERR_INVALID, "no kernel for this decimation stage");
-        if (e->timing_on) HD_HIP(hipEventRecord(sl.t2, qa));
+        if (sl.timed) HD_HIP(hipEventRecord(sl.t2, qa));
         if (!single && !fuse) {
             if (!hd::launch_decimate(qa, R2, T2, S, max_n2, d1, e->n1_cap, e->hist2[hin].p, e->hist2[hout].p, e->stage_taps[1].p, fcur,
                                      e->fbuf_stride, dcall, 1, 1, e->fir_hist_cap, feed))
@@ -757,6 +768,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     mark();
     const int cin = e->carry_cur, cout = e->carry_cur ^ 1;
     if (fuse) {
+        if (lean) hd::launch_fetch_params(qb, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
         if (!hd::launch_backend(qb, (int)R2, (int)T2, S, max_n1, max_n2, max_taps, d1, e->n1_cap, e->hist2[hin].p, e->hist2[hout].p,
                                 e->stage_taps[1].p, fcur, fcur, fnext, e->fbuf_stride, e->fir_hist_cap, e->lp_taps.p, e->taps_cap, e->demod.p,
                                 e->demod.n / S, e->cfg.keep_filtered ? e->filtered.p : nullptr, e->carry[cin].p, e->carry[cout].p, dcall, feed,
@@ -774,7 +786,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     hd::launch_symbols(qb, S, max_m, max_new, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p,
                        dcall, sl.h_slots.dev, e->slot_words, e->flips_cap ? e->flips_dbg.p : nullptr, e->flips_cap, e->min_R);
     mark();
-    if (e->timing_on) HD_HIP(hipEventRecord(sl.t3, qb));
+    if (sl.timed) HD_HIP(hipEventRecord(sl.t3, qb));
     HD_HIP(hipEventRecord(sl.ev_done, qb));
     mark();
     HD_HIP(hipGetLastError());

@@ -162,8 +162,10 @@ typedef struct hd_timing {
     double host_text_us;    /* AFC state machines, RTTY framing, sentence scan, callbacks */
 } hd_timing;
 int hd_engine_timing(hd_engine* e, hd_timing* out);
-/* 1 = bracket kernels with HIP events on every call (default 1; tiny overhead) */
-void hd_engine_set_timing(hd_engine* e, int on);
+/* Bracket the kernels with HIP events on every `every`-th call (default 8; 0 = never; 1 = every call).  Each event record is
+ * a barrier packet that costs a few microseconds of queue time, so per-call timing slows a pipelined batch by ~8 %;
+ * hd_engine_timing() reports the most recent timed call. */
+void hd_engine_set_timing(hd_engine* e, int every);
 
 #ifdef __cplusplus
 }
