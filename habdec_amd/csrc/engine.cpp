@@ -513,6 +513,7 @@ int collect(hd_engine* e, hd_engine::CallSlot& sl)
         e->last_timing.ms_front = b;
         e->last_timing.samples = sl.total_in;
         e->last_timing.front_bytes = sl.total_in * 8 + (sl.total_in / sl.r1) * 8;
+        ++e->last_timing.timed_calls;
     }
     int rc = HD_OK;
     for (uint32_t s = 0; s < e->S; ++s) {

@@ -160,6 +160,7 @@ typedef struct hd_timing {
     double host_enqueue_us; /* size bookkeeping + uploads + kernel launches */
     double host_wait_us;    /* blocked on the GPU for the results being delivered */
     double host_text_us;    /* AFC state machines, RTTY framing, sentence scan, callbacks */
+    uint64_t timed_calls;   /* how many calls carried the HIP-event timing so far (ms_* are those of the latest one) */
 } hd_timing;
 int hd_engine_timing(hd_engine* e, hd_timing* out);
 /* Bracket the kernels with HIP events on every `every`-th call (default 8; 0 = never; 1 = every call).  Each event record is

@@ -5,6 +5,7 @@ import torch, bench, habdec_amd
 w = dict(bench.WORKLOADS["cfg4"]); S = 1024; C = w["C"]
 dev = torch.device("cuda", 0)
 eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"])
+eng.set_timing(1)
 for n in (1, 2, 8, 32, 128):
     ring = torch.randn((n, S, C, 2), device=dev) * 0.3
     torch.cuda.synchronize()

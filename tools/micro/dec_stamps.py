@@ -5,6 +5,7 @@ w = dict(bench.WORKLOADS["cfg4"]); S = 1024; C = w["C"]
 dev = torch.device("cuda", 0)
 ring = torch.randn((8, S, C, 2), device=dev) * 0.3
 eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"])
+eng.set_timing(1)
 L = habdec_amd.lib(); f = L.hd_debug_dec_stamps; f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 for i in range(12):
     eng.process_device(ring.data_ptr() + (i % 8) * S * C * 8, C, C)
