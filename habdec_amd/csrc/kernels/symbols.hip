@@ -182,7 +182,11 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     const SymbolParams q = sp[s];
     SymState st = state_after_push(old, q, m);
     const uint32_t h = st.held;
-    if (h < q.min_held || h < q.spb) {
+    // Too little backlog for the extractor to run (SymbolExtractor.h:134): the reference returns; here the window sums of the
+    // samples that arrived are still computed and cached (they are pure functions of the samples), so that the call that does
+    // run finds one sweep of work instead of two -- busy streams alternate between the two kinds of call.
+    const bool search = !(h < q.min_held || h < q.spb);
+    if (!search && (q.min_held == 0xFFFFFFFFu || h < q.R)) {
         if (tid == 0) { sym[s] = st; hdr->nbits = 0; hdr->held_after = h; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = st.base + h - st.cached; }
         return;
     }
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     float* gw = weight + (size_t)s * ring_cap;
     const uint32_t end = st.base + h;
     const uint32_t pend = end - R + 1;                      // first position whose right window is still incomplete
-    const uint32_t limit = h - q.spb;                       // backlog indices searched: [R, limit)
+    const uint32_t limit = search ? h - q.spb : 0u;         // backlog indices searched: [R, limit)
 
     if (tid == 0) s_flagged = 0u;
     STAMP(0);
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     {
         const uint32_t c0 = st.cached;
         const uint32_t wr0 = (st.base + R) & ~63u;                     // ring position of the first searchable word
-        const uint32_t nw = ((st.base + limit) - wr0 + 63u) >> 6;      // modular difference: safe across the 2^32 wrap
+        const uint32_t nw = search ? ((st.base + limit) - wr0 + 63u) >> 6 : 0u;      // modular difference: safe across the 2^32 wrap
         const bool sweep = (int32_t)(pend - c0) > 0;
         float tw[WB], tl[LB];
         unsigned long long tm[MB];
@@ -304,6 +308,14 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     bool lds_w = sweeps == 1;
     if (sweeps > 1) __threadfence_block();
     __syncthreads();
+    if (!search) {                                          // nothing to extract yet: only the cache moved on
+        if (tid == 0) {
+            if ((int32_t)(pend - st.cached) > 0) st.cached = pend;
+            sym[s] = st;
+            hdr->nbits = 0; hdr->held_after = h; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = end - st.cached;
+        }
+        return;
+    }
     // ---- A2: busy streams (off-tune or noisy: ten flips per call instead of one) would pay one global round trip per flip
     // for the zone weights.  When the mask image shows more flagged positions than a couple of clean edges produce, the
     // window sums of the searchable backlog (as much as fits) are pulled into LDS first, over win/wl, which are idle here.
