@@ -314,6 +314,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
             sym[s] = st;
             hdr->nbits = 0; hdr->held_after = h; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = end - st.cached;
         }
+        STAMP(2); STAMP(3); STAMP(4); STAMP(5);
         return;
     }
     // ---- A2: busy streams (off-tune or noisy: ten flips per call instead of one) would pay one global round trip per flip
