@@ -114,6 +114,8 @@ struct hd_engine {
     bool decode_enabled = true;
     bool one_stream = false;
     bool no_fuse = false;      // HD_NO_FUSE: never use the fused back end (kernels/backend.hip); A/B measurements
+    bool no_tail = false;      // HD_NO_TAIL: never use the one-wave stream tail (kernels/tail_body.h); A/B measurements
+    int tail_lanes = 0;        // HD_TAIL_LANES: 64 / 256 lanes per stream in the tail kernel (0 = by batch size)
     int last_fuse = -1;
     uint32_t n_cus = 0, dec_wgs_per_cu = 0;   // stage-1 linear split: workgroups per CU (0 = classic grid), see kernels/decimate.hip        // path of the previous call (the two paths use the stage-2 buffers on different queues)
     hipStream_t qa = nullptr, qb = nullptr, qc = nullptr;   // front (decimation, spectrum) and back (FIR, symbols, results) HIP streams
@@ -253,6 +255,8 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     }
     e->one_stream = getenv("HD_ONE_STREAM") != nullptr;
     e->no_fuse = getenv("HD_NO_FUSE") != nullptr;
+    e->no_tail = getenv("HD_NO_TAIL") != nullptr;
+    if (const char* v = getenv("HD_TAIL_LANES")) e->tail_lanes = atoi(v);
     {
         hipDeviceProp_t prop;
         HD_HIP(hipGetDeviceProperties(&prop, cfg->device));
@@ -672,10 +676,17 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     mark();
     // Two-stage plans at batch-decoding sizes: stage 2, low-pass, discriminator and slide run as ONE kernel per call on qb
     // (kernels/backend.hip) when a stream's call fits in LDS and no DC blocker sits in between.
-    const bool fuse = nst == 2 && !any_dc && !e->no_fuse && ((R2 == 2 && T2 == 69) || (R2 == 4 && T2 == 139)) &&
-                      hd::backend_lds_bytes((int)T2, max_n1, max_n2, max_taps) <= 64 * 1024;
-    if (e->last_fuse >= 0 && e->last_fuse != (int)fuse) { HD_HIP(hipStreamSynchronize(qa)); HD_HIP(hipStreamSynchronize(qb)); }   // path switch: drain
-    e->last_fuse = (int)fuse;
+    // The stream tail (kernels/tail_body.h) goes further: stage 2 through the symbol extractor as one wave per stream that walks the
+    // call in pieces, so neither the call size nor the tap count has to fit an LDS image.
+    hd::TailArgs ta{};
+    const int tail_lanes = e->tail_lanes ? e->tail_lanes : (S >= 2 * e->n_cus ? 64 : 256);
+    const bool tail = nst == 2 && !any_dc && !e->no_tail &&
+                      hd::tail_layout(ta, tail_lanes, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, 64 * 1024);
+    const bool fuse = tail || (nst == 2 && !any_dc && !e->no_fuse && ((R2 == 2 && T2 == 69) || (R2 == 4 && T2 == 139)) &&
+                      hd::backend_lds_bytes((int)T2, max_n1, max_n2, max_taps) <= 64 * 1024);
+    const int path = tail ? 2 : fuse ? 1 : 0;
+    if (e->last_fuse >= 0 && e->last_fuse != path) { HD_HIP(hipStreamSynchronize(qa)); HD_HIP(hipStreamSynchronize(qb)); }   // path switch: drain
+    e->last_fuse = path;
     // Cross-queue event waits cost ~18 us each on this platform (kernel trace: stage 1 of call k+1 started 37 us after stage 1
     // of call k ended, two barrier packets later).  On the fused path the stage-1 queue therefore waits for NOTHING: it reads the
     // call's parameters straight from the mapped host block (32 bytes per workgroup), its output rotates over three buffers --
@@ -768,7 +779,20 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     if (!e->one_stream) HD_HIP(hipStreamWaitEvent(qb, sl.ev_front, 0));
     mark();
     const int cin = e->carry_cur, cout = e->carry_cur ^ 1;
-    if (fuse) {
+    if (tail) {
+        if (lean) hd::launch_fetch_params(qb, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
+        ta.dec1 = d1; ta.dec1_stride = e->n1_cap; ta.hist2_in = e->hist2[hin].p; ta.hist2_out = e->hist2[hout].p; ta.taps2 = e->stage_taps[1].p;
+        ta.fbuf = fcur; ta.fbuf_next = fnext; ta.fbuf_stride = e->fbuf_stride; ta.fir_hist_cap = e->fir_hist_cap;
+        ta.lp_taps = e->lp_taps.p; ta.taps_stride = e->taps_cap; ta.demod = e->demod.p; ta.demod_stride = e->demod.n / S;
+        ta.filtered = e->cfg.keep_filtered ? e->filtered.p : nullptr; ta.carry_in = e->carry[cin].p; ta.carry_out = e->carry[cout].p;
+        ta.call = dcall; ta.fft_in = feed; ta.head_buf = e->fir_head.p; ta.head_cnt = e->fir_head_n.p; ta.head_cap = e->head_cap;
+        ta.head_par = (uint32_t)cin; ta.n_streams = S;
+        ta.ring = e->tail.p; ta.ring_cap = e->tail_cap; ta.sym = e->d_symstate.p; ta.flipmask = e->flipmask.p; ta.wsum = e->weight.p;
+        ta.sp = e->d_sym.p; ta.slots = sl.h_slots.dev; ta.slot_words = e->slot_words;
+        ta.flips_dbg = e->flips_cap ? e->flips_dbg.p : nullptr; ta.flips_cap = e->flips_cap;
+        if (!hd::launch_tail(qb, tail_lanes, (int)R2, (int)T2, S, ta)) return fail(HD_ERR_INVALID, "stream tail refused a shape it was selected for");
+        if (const int r = spectrum(qb)) return r;
+    } else if (fuse) {
         if (lean) hd::launch_fetch_params(qb, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
         if (!hd::launch_backend(qb, (int)R2, (int)T2, S, max_n1, max_n2, max_taps, d1, e->n1_cap, e->hist2[hin].p, e->hist2[hout].p,
                                 e->stage_taps[1].p, fcur, fcur, fnext, e->fbuf_stride, e->fir_hist_cap, e->lp_taps.p, e->taps_cap, e->demod.p,
@@ -784,6 +808,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     }
     mark();
     mark();
+    if (!tail)
     hd::launch_symbols(qb, S, max_m, max_new, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p,
                        dcall, sl.h_slots.dev, e->slot_words, e->flips_cap ? e->flips_dbg.p : nullptr, e->flips_cap, e->min_R);
     mark();

@@ -56,4 +56,28 @@ void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t
                     const StreamCall* call, uint32_t* slots, uint32_t slot_words, uint32_t* flips_dbg, uint32_t flips_cap,
                     uint32_t min_R /* smallest averaging half-window over the streams: bounds the flips one call can find */);
 
+// ---- the fused stream tail (tail_body.h / tail.hip): stage 2 + low-pass + discriminator + symbol extractor, one wave per stream
+struct TailArgs {
+    // stage 2 + low-pass + discriminator (same buffers and conventions as launch_backend)
+    const float2* dec1; size_t dec1_stride;
+    const float2* hist2_in; float2* hist2_out; const float* taps2;
+    float2* fbuf; float2* fbuf_next; size_t fbuf_stride; uint32_t fir_hist_cap;
+    const float* lp_taps; uint32_t taps_stride;
+    float* demod; size_t demod_stride; float2* filtered;
+    const DemodCarry* carry_in; DemodCarry* carry_out;
+    const StreamCall* call; float2* fft_in;
+    float2* head_buf; uint32_t* head_cnt; uint32_t head_cap, head_par, n_streams;
+    // symbol extractor (same rings and state as launch_symbols)
+    float* ring; uint32_t ring_cap; SymState* sym; unsigned long long* flipmask; float* wsum; const SymbolParams* sp;
+    uint32_t* slots; uint32_t slot_words; uint32_t* flips_dbg; uint32_t flips_cap;
+    // LDS carve in bytes from the base of the workgroup's scratch (tail_layout)
+    uint32_t f_off, v_off, ws_off, words_off, lmask_off, flips_off, fl_cap, strips_off, wc_off, wc_cap, lds_bytes;
+};
+// Fills the LDS carve for `lanes` (64 or 256) lanes per stream; returns false when (ratio2, ntaps2) has no tail instantiation or the
+// windows for max_taps / max_R do not fit into lds_limit bytes -- the caller then runs launch_backend / launch_decimate + launch_fir_demod
+// and launch_symbols instead.
+bool tail_layout(TailArgs& a, int lanes, int ratio2, int ntaps2, uint32_t max_taps, uint32_t max_R, uint32_t min_R, uint32_t ring_cap, uint32_t lds_limit);
+bool launch_tail(hipStream_t st, int lanes, int ratio2, int ntaps2, uint32_t n_streams, const TailArgs& a);
+constexpr uint32_t kStepLdsBytes = 20480;   // LDS of a stage-1 workgroup slot (eight per CU): what a tail riding in the stage-1 launch may use
+
 }  // namespace hd

@@ -22,68 +22,9 @@
 #include <cstdlib>
 
 #include "launch.h"
+#include "sym_common.h"
 
 namespace hd {
-
-constexpr int kAvgLanes = 256;
-constexpr uint32_t kMaxFlipsPerCall = 1024;   // upper bound of the LDS flip list (the launcher sizes it from backlog / R; overflow is flagged)
-
-__device__ __forceinline__ int sgnf(float v) { return (0.0f < v) - (v < 0.0f); }
-
-// State after this call's samples were appended (SymbolExtractor.h:116-124: the vent happens before the append).
-__device__ __forceinline__ SymState state_after_push(SymState st, const SymbolParams& q, uint32_t m)
-{
-    if (st.held > kVentLimit) { st.base += st.held; st.held = 0; st.cached = st.base; st.run_pos = st.base; st.run_sum = 0.0f; }
-    if (q.reset) st.cached = st.base;
-    st.held += m;
-    return st;
-}
-
-// Window sums for the NEW candidate positions.  One lane owns 4 consecutive positions: it walks its R+3 left-window
-// samples (then the R+3 right-window samples) once with 16-byte LDS reads and adds each sample to every one of its
-// four accumulators whose window contains it.  Each accumulator still receives exactly its own R samples in index
-// order, so the sums are bit-identical to std::accumulate, with 1/16 of the LDS instructions of the scalar form.
-constexpr int kAvgPos = 4;                                  // positions per lane
-constexpr int kAvgSpan = kAvgLanes * kAvgPos;               // positions per workgroup (1024)
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// acc[j] = w[j] + w[j+1] + ... + w[j+R-1] for j = 0..3, each in index order.  Interior samples feed all four sums:
-// two v_pk_add_f32 per sample.
-__device__ __forceinline__ void window_sums(const float* __restrict__ w, uint32_t R, float acc[kAvgPos])
-{
-    f32x2 a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f};
-    const uint32_t total = R + kAvgPos - 1;                 // samples touched: w[0 .. R+3)
-    {   // head chunk: element u feeds accumulators j <= u (R >= 4 always)
-        const float4 x = *reinterpret_cast<const float4*>(w);
-        a01.x = a01.x + x.x;
-        a01 = a01 + (f32x2){x.y, x.y};
-        a01 = a01 + (f32x2){x.z, x.z}; a23.x = a23.x + x.z;
-        a01 = a01 + (f32x2){x.w, x.w}; a23 = a23 + (f32x2){x.w, x.w};
-    }
-    uint32_t e = 4;
-    for (; e + 4 <= R; e += 4) {                            // interior: every element feeds all four
-        const float4 x = *reinterpret_cast<const float4*>(w + e);
-        a01 = a01 + (f32x2){x.x, x.x}; a23 = a23 + (f32x2){x.x, x.x};
-        a01 = a01 + (f32x2){x.y, x.y}; a23 = a23 + (f32x2){x.y, x.y};
-        a01 = a01 + (f32x2){x.z, x.z}; a23 = a23 + (f32x2){x.z, x.z};
-        a01 = a01 + (f32x2){x.w, x.w}; a23 = a23 + (f32x2){x.w, x.w};
-    }
-    float acc0 = a01.x, acc1 = a01.y, acc2 = a23.x, acc3 = a23.y;
-    for (; e < total; e += 4) {                             // tail chunks: element e+u feeds accumulators with e+u < j + R
-        const float4 x = *reinterpret_cast<const float4*>(w + e);
-        const float xs[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = e + u;
-            if (i < R) acc0 = acc0 + xs[u];
-            if (i < 1 + R) acc1 = acc1 + xs[u];
-            if (i < 2 + R) acc2 = acc2 + xs[u];
-            if (i < 3 + R) acc3 = acc3 + xs[u];
-        }
-    }
-    acc[0] = acc0; acc[1] = acc1; acc[2] = acc2; acc[3] = acc3;
-}
 
 #ifdef HD_STAMP   // diagnostic build only: s_memtime at the phase boundaries of k_symbols, per stream
 __device__ unsigned long long g_sym_stamps[8192 * 8];
@@ -95,59 +36,6 @@ extern "C" void hd_debug_sym_stamps(unsigned long long* host, size_t n) { (void)
 constexpr int kSymLanes = 256;
 constexpr uint32_t kRunStrip = 512;                       // samples per run-sum step
 
-
-// Wave-wide maximum of an unsigned 64-bit key with DPP moves (a ds_bpermute-based shuffle reduction costs an LDS round trip
-// per step, ~1.5k cycles for an arg-max; this is a few dozen).  Result is uniform.
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
-{
-#define HD_DPP_MAX(ctrl, rmask_)                                                                                         \
-    {                                                                                                                   \
-        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, ctrl, rmask_, 0xf, false);       \
-        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), ctrl, rmask_, 0xf, false); \
-        const unsigned long long o_ = ((unsigned long long)hi_ << 32) | lo_;                                            \
-        k = o_ > k ? o_ : k;                                                                                            \
-    }
-    HD_DPP_MAX(0x111, 0xf)   // row_shr:1
-    HD_DPP_MAX(0x112, 0xf)   // row_shr:2
-    HD_DPP_MAX(0x114, 0xf)   // row_shr:4
-    HD_DPP_MAX(0x118, 0xf)   // row_shr:8   -> lane 15 of every row holds the row's maximum
-    HD_DPP_MAX(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
-    HD_DPP_MAX(0x143, 0xc)   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
-#undef HD_DPP_MAX
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, 63);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k >> 32), 63);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-__device__ __forceinline__ uint32_t find_flag_lds(const unsigned long long* lmask, uint32_t base, uint32_t rmask,
-                                                  uint32_t from, uint32_t to, bool want)
-{
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wr0 = (base + from) & ~63u;
-    for (uint32_t it = 0;; ++it) {
-        const uint32_t wstart = wr0 + it * 4096u;
-        if ((int32_t)(wstart - base) >= (int32_t)to) break;
-        const uint32_t wr = wstart + lane * 64u;
-        const int32_t lw = (int32_t)(wr - base);
-        unsigned long long w = 0;
-        if (lw < (int32_t)to) {
-            w = lmask[(wr & rmask) >> 6];
-            if (!want) w = ~w;
-            const int32_t lo = (int32_t)from - lw;
-            if (lo > 0) w = lo >= 64 ? 0ull : (w & (~0ull << lo));
-            const int32_t hi = (int32_t)to - lw;
-            if (hi < 64) w &= (1ull << hi) - 1ull;
-        }
-        const unsigned long long hit = __ballot(w != 0ull);
-        if (hit) {
-            const int src = __ffsll((long long)hit) - 1;
-            const unsigned long long ww = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), src) << 32) |
-                                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, src);     // src is wave-uniform
-            return (uint32_t)((int32_t)(wstart - base) + src * 64 + (__ffsll((long long)ww) - 1));
-        }
-    }
-    return 0xFFFFFFFFu;
-}
 
 __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__ tail, uint32_t ring_cap, SymState* __restrict__ sym,
                                                         unsigned long long* __restrict__ flipmask, float* __restrict__ weight,
