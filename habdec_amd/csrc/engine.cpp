@@ -117,8 +117,20 @@ struct hd_engine {
     bool no_tail = false;      // HD_NO_TAIL: never use the one-wave stream tail (kernels/tail_body.h); A/B measurements
     int tail_lanes = 0;        // HD_TAIL_LANES: 64 / 256 lanes per stream in the tail kernel (0 = by batch size)
     int last_fuse = -1;
+    // Step mode (batch decoding, kernels/decimate.hip k_step): the stream tails of call k ride in the stage-1 launch of call k+1.
+    struct PendingTail { bool valid = false; hd::TailArgs ta{}; int slot = 0; bool any_fft = false; int r2 = 0, t2 = 0; } pend;
+    bool no_step = false;      // HD_NO_STEP: keep stage 1 and the tails in separate launches
+    uint32_t step_wgs = 0;     // HD_STEP_WGS: stage-1 workgroups of a step launch (default 8 per CU)
+    uint32_t pend_max_taps = 0;
     uint32_t n_cus = 0, dec_wgs_per_cu = 0;   // stage-1 linear split: workgroups per CU (0 = classic grid), see kernels/decimate.hip        // path of the previous call (the two paths use the stage-2 buffers on different queues)
     hipStream_t qa = nullptr, qb = nullptr, qc = nullptr;   // front (decimation, spectrum) and back (FIR, symbols, results) HIP streams
+    // hd_process_host: copies run on their own stream into two alternating slabs; a call returns once ITS copy has landed, so the
+    // caller may reuse (or free) the buffer at once, like Decoder::pushSamples' copy -- whatever the engine still has queued.
+    hipStream_t qh = nullptr;
+    DevBuf<float2> staging2;
+    hipEvent_t ev_copy[2] = {nullptr, nullptr}, ev_staging_free[2] = {nullptr, nullptr};
+    bool staging_used[2] = {false, false};
+    uint64_t host_calls = 0;
     uint32_t timing_every = 8;   // HIP-event timing on every Nth call (0 = off): each event record is a barrier packet worth ~6 us of queue time
     hd_timing last_timing{};
     rocfft_plan fft_plan = nullptr;
@@ -171,6 +183,8 @@ struct hd_engine {
         if (qa) (void)hipStreamDestroy(qa);
         if (qb && qb != qa) (void)hipStreamDestroy(qb);
         if (qc && qc != qa) (void)hipStreamDestroy(qc);
+        if (qh) (void)hipStreamDestroy(qh);
+        for (hipEvent_t ev : {ev_copy[0], ev_copy[1], ev_staging_free[0], ev_staging_free[1]}) if (ev) (void)hipEventDestroy(ev);
     }
 };
 
@@ -256,6 +270,8 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     e->one_stream = getenv("HD_ONE_STREAM") != nullptr;
     e->no_fuse = getenv("HD_NO_FUSE") != nullptr;
     e->no_tail = getenv("HD_NO_TAIL") != nullptr;
+    e->no_step = getenv("HD_NO_STEP") != nullptr;
+    if (const char* v = getenv("HD_STEP_WGS")) e->step_wgs = (uint32_t)atoi(v);
     if (const char* v = getenv("HD_TAIL_LANES")) e->tail_lanes = atoi(v);
     {
         hipDeviceProp_t prop;
@@ -267,6 +283,8 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         e->dec_wgs_per_cu = cfg->pipeline ? 6u : 0u;
         if (const char* v = getenv("HD_DEC_WGS_PER_CU")) e->dec_wgs_per_cu = (uint32_t)atoi(v);
     }
+    HD_HIP(hipStreamCreateWithFlags(&e->qh, hipStreamNonBlocking));
+    for (hipEvent_t* ev : {&e->ev_copy[0], &e->ev_copy[1], &e->ev_staging_free[0], &e->ev_staging_free[1]}) HD_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     if (e->one_stream) e->qb = e->qc = e->qa;
     else {
         HD_HIP(hipStreamCreateWithFlags(&e->qb, hipStreamNonBlocking));
@@ -500,11 +518,45 @@ int hd_stream_reset_frequency_correction(hd_engine* e, uint32_t s, double c)
 
 namespace {
 
+// rocFFT + commit for the streams whose 4096-sample buffer completed in the call that owns `sl` (Decoder.h:475-489)
+int run_spectrum(hd_engine* e, hipStream_t q, hd_engine::CallSlot& sl, bool any_fft)
+{
+    if (!e->cfg.enable_spectrum || !any_fft) return HD_OK;
+    void* in[1] = {e->fft_in.p};
+    void* outb[1] = {e->fft_raw.p};
+    rocfft_execution_info_set_stream(e->fft_info, q);
+    if (rocfft_execute(e->fft_plan, in, outb, e->fft_info) != rocfft_status_success) return fail(HD_ERR_DEVICE, "rocfft_execute failed");
+    hd::launch_spectrum_commit(q, e->S, e->fft_raw.p, e->spec.p, e->power.p, sl.h_stats.dev, sl.d_call.p, e->fsd, e->bins_sep);
+    return HD_OK;
+}
+
+// Step mode: the tails of the newest call have not been launched yet (they wait for the next call's launch).  Run them now, as a
+// kernel of their own -- the next call is not coming (flush), or its results are wanted first.
+int run_pending_tail(hd_engine* e)
+{
+    if (!e->pend.valid) return HD_OK;
+    hd_engine::CallSlot& ps = e->slot[e->pend.slot];
+    e->pend.valid = false;
+    hd::TailArgs ta = e->pend.ta;
+    const int lanes = e->tail_lanes ? e->tail_lanes : (e->S >= 2 * e->n_cus ? 64 : 256);
+    hd::TailArgs lay = ta;
+    if (lanes != 64) {      // the pending arguments carry the 64-lane carve of the step launch; a 256-lane kernel needs its own
+        // (same buffers, other LDS offsets)
+        if (!hd::tail_layout(lay, lanes, e->pend.r2, e->pend.t2, e->pend_max_taps, e->max_R, e->min_R, e->tail_cap, e->pend.ta.pend_max, 64 * 1024)) return fail(HD_ERR_INVALID, "stream tail layout");
+    }
+    if (!hd::launch_tail(e->qa, lanes, e->pend.r2, e->pend.t2, e->S, lay)) return fail(HD_ERR_INVALID, "stream tail refused a shape it was selected for");
+    if (const int r = run_spectrum(e, e->qa, ps, e->pend.any_fft)) return r;
+    HD_HIP(hipEventRecord(ps.ev_done, e->qa));
+    HD_HIP(hipGetLastError());
+    return HD_OK;
+}
+
 // Deliver the results of the call that ran in `sl`: wait for its back half, then the host stages, stream by stream
 // (AFC state machine Decoder.h:501-515; RTTY framing, sentence scan, callbacks Decoder.h:559-637).
 int collect(hd_engine* e, hd_engine::CallSlot& sl)
 {
     if (!sl.busy) return HD_OK;
+    if (e->pend.valid && &e->slot[e->pend.slot] == &sl) { if (const int r = run_pending_tail(e)) return r; }
     const auto w0 = std::chrono::steady_clock::now();
     HD_HIP(hipEventSynchronize(sl.ev_done));
     const auto w1 = std::chrono::steady_clock::now();
@@ -607,7 +659,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     }
 
     // ---- host mirror of the reference's size bookkeeping -> one StreamCall per stream
-    uint32_t max_in = 0, min_in = 0xFFFFFFFFu, max_n1 = 0, max_n2 = 0, max_m = 0, max_taps = 0, max_new = 0;
+    uint32_t max_in = 0, min_in = 0xFFFFFFFFu, max_n1 = 0, max_n2 = 0, max_m = 0, max_taps = 0, max_new = 0, max_pend = 0;
     bool any_fft = false, any_dc = false;
     uint64_t total_in = 0;
     for (uint32_t s = 0; s < S; ++s) {
@@ -660,6 +712,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             st.win_ub += m;
         }
         c.pend_after = (uint32_t)st.pending;
+        max_pend = std::max(max_pend, std::max(c.pend_before, c.pend_after));
         st.last_n2 = c.n2; st.last_pend_before = c.pend_before; st.last_buf = e->cur;
         sl.h_call.p[s] = c;
         max_in = std::max(max_in, n); min_in = std::min(min_in, n); max_n1 = std::max(max_n1, c.n1); max_n2 = std::max(max_n2, c.n2);
@@ -681,11 +734,19 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     hd::TailArgs ta{};
     const int tail_lanes = e->tail_lanes ? e->tail_lanes : (S >= 2 * e->n_cus ? 64 : 256);
     const bool tail = nst == 2 && !any_dc && !e->no_tail &&
-                      hd::tail_layout(ta, tail_lanes, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, 64 * 1024);
+                      hd::tail_layout(ta, tail_lanes, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, 64 * 1024);
     const bool fuse = tail || (nst == 2 && !any_dc && !e->no_fuse && ((R2 == 2 && T2 == 69) || (R2 == 4 && T2 == 139)) &&
                       hd::backend_lds_bytes((int)T2, max_n1, max_n2, max_taps) <= 64 * 1024);
-    const int path = tail ? 2 : fuse ? 1 : 0;
-    if (e->last_fuse >= 0 && e->last_fuse != path) { HD_HIP(hipStreamSynchronize(qa)); HD_HIP(hipStreamSynchronize(qb)); }   // path switch: drain
+    // Step mode: batch decoding of equally sized pushes through a single-wave first stage -- ONE launch per call, on one queue: this
+    // call's stage 1 with the previous call's stream tails in front (kernels/decimate.hip k_step).
+    hd::TailArgs ta_step{};
+    const bool step = tail && e->cfg.pipeline && !e->no_step && !e->one_stream && min_in == max_in && max_in && (R1 == 32 || R1 == 64) &&
+                      hd::tail_layout(ta_step, 64, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, hd::kStepLdsBytes);
+    const int path = step ? 3 : tail ? 2 : fuse ? 1 : 0;
+    if (e->last_fuse >= 0 && e->last_fuse != path) {   // path switch: drain (a pending tail first)
+        if (const int r = run_pending_tail(e)) return r;
+        HD_HIP(hipStreamSynchronize(qa)); HD_HIP(hipStreamSynchronize(qb));
+    }
     e->last_fuse = path;
     // Cross-queue event waits cost ~18 us each on this platform (kernel trace: stage 1 of call k+1 started 37 us after stage 1
     // of call k ended, two barrier packets later).  On the fused path the stage-1 queue therefore waits for NOTHING: it reads the
@@ -734,6 +795,52 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     const int hin = e->hist_cur, hout = e->hist_cur ^ 1;
     // spectrum collection rides in the final stage's epilogue unless the DC blocker must see the samples first
     float2* feed = (e->cfg.enable_spectrum && !any_dc) ? e->fft_in.p : nullptr;
+    const int cin = e->carry_cur, cout = e->carry_cur ^ 1;
+    auto fill_tail = [&](hd::TailArgs& t) {      // buffers of THIS call's stream tails (the LDS carve is already in t)
+        t.dec1 = d1; t.dec1_stride = e->n1_cap; t.hist2_in = e->hist2[hin].p; t.hist2_out = e->hist2[hout].p; t.taps2 = e->stage_taps[1].p;
+        t.fbuf = fcur; t.fbuf_next = fnext; t.fbuf_stride = e->fbuf_stride; t.fir_hist_cap = e->fir_hist_cap;
+        t.lp_taps = e->lp_taps.p; t.taps_stride = e->taps_cap; t.demod = e->demod.p; t.demod_stride = e->demod.n / S;
+        t.filtered = e->cfg.keep_filtered ? e->filtered.p : nullptr; t.carry_in = e->carry[cin].p; t.carry_out = e->carry[cout].p;
+        t.call = dcall; t.fft_in = feed; t.head_buf = e->fir_head.p; t.head_cnt = e->fir_head_n.p; t.head_cap = e->head_cap;
+        t.head_par = (uint32_t)cin; t.n_streams = S;
+        t.ring = e->tail.p; t.ring_cap = e->tail_cap; t.sym = e->d_symstate.p; t.flipmask = e->flipmask.p; t.wsum = e->weight.p;
+        t.sp = e->d_sym.p; t.slots = sl.h_slots.dev; t.slot_words = e->slot_words;
+        t.flips_dbg = e->flips_cap ? e->flips_dbg.p : nullptr; t.flips_cap = e->flips_cap;
+    };
+    if (step) {
+        // One launch: [tails of the previous call | this call's stage 1].  Stage 1 reads its parameters from the mapped host block and
+        // leaves the device copy the tails (next launch) and the spectrum commit read.
+        fill_tail(ta_step);
+        hd_engine::PendingTail prev = e->pend;
+        hd_engine::CallSlot* ps = prev.valid ? &e->slot[prev.slot] : nullptr;
+        if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
+        const uint32_t wgs = e->step_wgs ? e->step_wgs : 8u * e->n_cus;
+        if (!hd::launch_step(qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, max_n1, iq, stride, e->hist1[hin].p,
+                             e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, wgs, prev.ta, prev.valid ? S : 0u))
+            return fail(HD_ERR_INVALID, "no step kernel for this decimation plan");
+        if (sl.timed) HD_HIP(hipEventRecord(sl.t2, qa));
+        if (ps) {
+            if (const int r = run_spectrum(e, qa, *ps, prev.any_fft)) return r;
+            HD_HIP(hipEventRecord(ps->ev_done, qa));
+        }
+        if (sl.timed) HD_HIP(hipEventRecord(sl.t3, qa));
+        e->pend.valid = true; e->pend.ta = ta_step; e->pend.slot = (int)(e->calls % hd_engine::kSlots); e->pend.any_fft = any_fft;
+        e->pend.r2 = (int)R2; e->pend.t2 = (int)T2; e->pend_max_taps = max_taps;
+        HD_HIP(hipGetLastError());
+        sl.busy = true;
+        e->cur ^= 1;
+        e->carry_cur ^= 1;
+        e->hist_cur ^= 1;
+        ++e->calls;
+        e->last_timing.host_enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
+        int rc = HD_OK;
+        while (e->calls - e->delivered > 2) {
+            const int r = collect(e, e->slot[e->delivered % hd_engine::kSlots]);
+            if (r) rc = r;
+            ++e->delivered;
+        }
+        return rc;
+    }
     if (nst == 0) {
         if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
         hd::launch_passthrough(qa, S, max_in, iq, stride, fcur, e->fbuf_stride, dcall, e->fir_hist_cap);
@@ -778,18 +885,9 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     // "two-stream pipeline").
     if (!e->one_stream) HD_HIP(hipStreamWaitEvent(qb, sl.ev_front, 0));
     mark();
-    const int cin = e->carry_cur, cout = e->carry_cur ^ 1;
     if (tail) {
         if (lean) hd::launch_fetch_params(qb, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
-        ta.dec1 = d1; ta.dec1_stride = e->n1_cap; ta.hist2_in = e->hist2[hin].p; ta.hist2_out = e->hist2[hout].p; ta.taps2 = e->stage_taps[1].p;
-        ta.fbuf = fcur; ta.fbuf_next = fnext; ta.fbuf_stride = e->fbuf_stride; ta.fir_hist_cap = e->fir_hist_cap;
-        ta.lp_taps = e->lp_taps.p; ta.taps_stride = e->taps_cap; ta.demod = e->demod.p; ta.demod_stride = e->demod.n / S;
-        ta.filtered = e->cfg.keep_filtered ? e->filtered.p : nullptr; ta.carry_in = e->carry[cin].p; ta.carry_out = e->carry[cout].p;
-        ta.call = dcall; ta.fft_in = feed; ta.head_buf = e->fir_head.p; ta.head_cnt = e->fir_head_n.p; ta.head_cap = e->head_cap;
-        ta.head_par = (uint32_t)cin; ta.n_streams = S;
-        ta.ring = e->tail.p; ta.ring_cap = e->tail_cap; ta.sym = e->d_symstate.p; ta.flipmask = e->flipmask.p; ta.wsum = e->weight.p;
-        ta.sp = e->d_sym.p; ta.slots = sl.h_slots.dev; ta.slot_words = e->slot_words;
-        ta.flips_dbg = e->flips_cap ? e->flips_dbg.p : nullptr; ta.flips_cap = e->flips_cap;
+        fill_tail(ta);
         if (!hd::launch_tail(qb, tail_lanes, (int)R2, (int)T2, S, ta)) return fail(HD_ERR_INVALID, "stream tail refused a shape it was selected for");
         if (const int r = spectrum(qb)) return r;
     } else if (fuse) {
@@ -849,19 +947,34 @@ int hd_process_host(hd_engine* e, const float* iq, size_t stride, const uint32_t
     if (!iq) return fail(HD_ERR_INVALID, "null IQ pointer");
     HD_HIP(hipSetDevice(e->cfg.device));
     const size_t dstride = e->cfg.max_chunk;
+    // validate the sizes before anything is queued (hd_process_device checks the rest and leaves every stream untouched on error)
+    for (uint32_t s = 0; s < e->S; ++s)
+        if ((n_per_stream ? n_per_stream[s] : n_uniform) > e->cfg.max_chunk) return fail(HD_ERR_CAPACITY, "more samples than max_chunk");
+    const int j = (int)(e->host_calls & 1u);
+    if (j == 1 && !e->staging2.p) {
+        HD_HIP(e->staging2.alloc((size_t)e->S * e->cfg.max_chunk));
+        HD_HIP(hipDeviceSynchronize());      // the allocation's memset runs on the null stream: it must not trail the copy below
+    }
+    float2* dst = j ? e->staging2.p : e->staging.p;
+    if (e->staging_used[j]) HD_HIP(hipStreamWaitEvent(e->qh, e->ev_staging_free[j], 0));    // the call that read this slab two calls ago is past its stage 1
     if (!n_per_stream) {
-        if (n_uniform > e->cfg.max_chunk) return fail(HD_ERR_CAPACITY, "more samples than max_chunk");
         if (n_uniform)
-            HD_HIP(hipMemcpy2DAsync(e->staging.p, dstride * sizeof(float2), iq, stride * sizeof(float2), (size_t)n_uniform * sizeof(float2),
-                                    e->S, hipMemcpyHostToDevice, e->qa));
+            HD_HIP(hipMemcpy2DAsync(dst, dstride * sizeof(float2), iq, stride * sizeof(float2), (size_t)n_uniform * sizeof(float2),
+                                    e->S, hipMemcpyHostToDevice, e->qh));
     } else {
         for (uint32_t s = 0; s < e->S; ++s) {
             const uint32_t n = n_per_stream[s];
-            if (n > e->cfg.max_chunk) return fail(HD_ERR_CAPACITY, "more samples than max_chunk");
-            if (n) HD_HIP(hipMemcpyAsync(e->staging.p + (size_t)s * dstride, iq + 2 * (size_t)s * stride, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, e->qa));
+            if (n) HD_HIP(hipMemcpyAsync(dst + (size_t)s * dstride, iq + 2 * (size_t)s * stride, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, e->qh));
         }
     }
-    return hd_process_device(e, e->staging.p, dstride, n_per_stream, n_uniform);
+    HD_HIP(hipEventRecord(e->ev_copy[j], e->qh));
+    HD_HIP(hipStreamWaitEvent(e->qa, e->ev_copy[j], 0));
+    HD_HIP(hipEventSynchronize(e->ev_copy[j]));          // from here on the caller's buffer is his again
+    const int rc = hd_process_device(e, dst, dstride, n_per_stream, n_uniform);
+    HD_HIP(hipEventRecord(e->ev_staging_free[j], e->qa));
+    e->staging_used[j] = true;
+    ++e->host_calls;
+    return rc;
 }
 
 /* ---------------------------------------------------------------- batched file ingest -------------------------- */

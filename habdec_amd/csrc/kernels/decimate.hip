@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "launch.h"
+#include "tail_body.h"
 
 namespace hd {
 
@@ -33,7 +34,7 @@ extern "C" void hd_debug_dec_stamps(unsigned long long* host, size_t n) { (void)
 #define DSTAMP_DECL unsigned long long ds_t = __builtin_amdgcn_s_memtime(), ds_acc[4] = {0, 0, 0, 0}; const unsigned long long ds_r0 = __builtin_amdgcn_s_memrealtime(); unsigned long long ds_r1 = 0
 #define DSTAMP(i) do { if (D == 32) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ds_acc[i] += t_ - ds_t; ds_t = t_; } } while (0)
 #define DSTAMP_ARRIVED() do { if (D == 32) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DSTAMP(0); if (!ds_r1) ds_r1 = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#define DSTAMP_WRITE() do { if (D == 32 && threadIdx.x == 0) { const uint32_t w_ = blockIdx.y * gridDim.x + blockIdx.x; if (w_ < 4096) { \
+#define DSTAMP_WRITE() do { if (D == 32 && threadIdx.x == 0) { const uint32_t w_ = by * gdx + bx; if (w_ < 4096) { \
         unsigned long long* g_ = g_dec_stamps + w_ * 8; g_[0] = ds_r0; g_[1] = ds_r1; g_[2] = __builtin_amdgcn_s_memrealtime(); \
         g_[3] = ds_acc[0]; g_[4] = ds_acc[1]; g_[5] = ds_acc[2]; g_[6] = ds_acc[3]; g_[7] = count; } } } while (0)
 #else
@@ -50,13 +51,24 @@ extern "C" void hd_debug_dec_stamps(unsigned long long* host, size_t n) { (void)
 template <int D> constexpr int dec_opl() { return D == 2 ? 4 : D == 4 ? 4 : D == 8 ? 2 : 1; }
 
 template <int D, int T, int TO>
-__global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_decimate(const float2* __restrict__ in, size_t in_stride,
-                                                   const float2* __restrict__ hist_in, float2* __restrict__ hist_out,
-                                                   const float* __restrict__ taps,
-                                                   float2* __restrict__ out, size_t out_stride,
-                                                   const StreamCall* __restrict__ call, int stage, int final_stage,
-                                                   uint32_t fir_hist_cap, uint32_t tiles_per_wg, float2* __restrict__ fft_in,
-                                                   uint32_t n_streams, uint32_t lin_ntiles)
+constexpr int dec_tile_f4()                        // float4 slots of a workgroup's LDS tile (+ this tile's outputs)
+{
+    constexpr int OPL = dec_opl<D>(), TOUT = TO * OPL, RD = OPL * D, JS = (T - 1) & 1;
+    constexpr int NJJ = (TOUT - 1) * D + T + JS, NL = NJJ + 2 * (NJJ / RD) + 4;
+    return (NL + 1) / 2 + TOUT / 2 + 1;
+}
+
+// The stage body.  (bx, by, gdx) are the workgroup's coordinates in the stage's own grid -- blockIdx / gridDim when the stage is a
+// launch of its own (k_decimate), shifted when stream tails ride in front of it in the same launch (k_step).
+template <int D, int T, int TO>
+__device__ __forceinline__ void decimate_body(const float2* __restrict__ in, size_t in_stride,
+                                              const float2* __restrict__ hist_in, float2* __restrict__ hist_out,
+                                              const float* __restrict__ taps,
+                                              float2* __restrict__ out, size_t out_stride,
+                                              const StreamCall* __restrict__ call, int stage, int final_stage,
+                                              uint32_t fir_hist_cap, uint32_t tiles_per_wg, float2* __restrict__ fft_in,
+                                              uint32_t n_streams, uint32_t lin_ntiles, StreamCall* __restrict__ call_copy,
+                                              const uint32_t bx, const uint32_t by, const uint32_t gdx, float4* __restrict__ tile4)
 {
     constexpr int OPL = dec_opl<D>();              // outputs per lane
     constexpr int TOUT = TO * OPL;                 // outputs per tile
@@ -67,7 +79,7 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     constexpr int NL = NJJ + 2 * (NJJ / RD) + 4;   // + two pad slots per row
     constexpr int NP = (NJJ + 1) / 2;              // 16-byte pairs per tile
     constexpr int ITER = (NP + TO - 1) / TO;
-    __shared__ float4 tile4[(NL + 1) / 2 + TOUT / 2 + 1];
+    static_assert((NL + 1) / 2 + TOUT / 2 + 1 == dec_tile_f4<D, T, TO>(), "tile size helper out of step");
     float2* tile = reinterpret_cast<float2*>(tile4);
     float2* ytile = tile + ((NL + 1) & ~1);        // this tile's outputs (only needed for the Q4 history quirk)
 
@@ -82,19 +94,19 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     uint32_t s, first, count;                               // current stream, first tile in it, tiles this workgroup walks in total
     if (linear) {
         const uint64_t total = (uint64_t)n_streams * lin_ntiles;
-        const uint64_t g0 = (uint64_t)blockIdx.x * total / gridDim.x, g1 = (uint64_t)(blockIdx.x + 1) * total / gridDim.x;
+        const uint64_t g0 = (uint64_t)bx * total / gdx, g1 = (uint64_t)(bx + 1) * total / gdx;
         s = (uint32_t)(g0 / lin_ntiles);
         first = (uint32_t)(g0 - (uint64_t)s * lin_ntiles);
         count = (uint32_t)(g1 - g0);
     } else {
-        s = blockIdx.y; first = blockIdx.x * tiles_per_wg; count = tiles_per_wg;
+        s = by; first = bx * tiles_per_wg; count = tiles_per_wg;
     }
     CallHead c = *reinterpret_cast<const CallHead*>(call + s);
     const uint32_t n = stage == 0 ? c.n_in : c.n1;          // (linear: the same for every stream)
     const uint32_t nout = n / D;
     const uint32_t ntiles = (nout + TOUT - 1) / TOUT;
     if (!linear) {
-        if (!n && blockIdx.x == 0)                          // idle stream: its history passes through unchanged
+        if (!n && bx == 0)                                  // idle stream: its history passes through unchanged
             for (uint32_t j = threadIdx.x; j < (uint32_t)(T - 1); j += TO)
                 hist_out[(size_t)s * (T - 1) + j] = hist_in[(size_t)s * (T - 1) + j];
         if (first >= ntiles) return;
@@ -164,6 +176,12 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         nv_prev = nf_prev = 0;
     };
     uint32_t tile_i = first;                                // tile of stream s being computed; pf_* run one tile ahead
+    // The call's parameters live in mapped host memory; whoever owns a stream's first tile leaves a device copy for the kernels
+    // that read them later (the stream tail of this call runs inside the NEXT call's launch).
+    auto leave_copy = [&](uint32_t sc) {
+        if (call_copy && threadIdx.x < 4) reinterpret_cast<uint4*>(call_copy + sc)[threadIdx.x] = reinterpret_cast<const uint4*>(call + sc)[threadIdx.x];
+    };
+    if (first == 0) leave_copy(s);
     for (uint32_t done = 0; done < count; ++done) {
         DSTAMP_ARRIVED();
 #pragma unroll
@@ -325,11 +343,49 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (done + 1 < count) {                         // linear split: walk on into the next stream (its first tile is in flight)
                 __syncthreads();                            // ytile is rewritten by the next tile
                 ++s; tile_i = 0; c = c_next;
+                leave_copy(s);
             }
         }
     }
     store_prev();
     DSTAMP_WRITE();
+}
+
+template <int D, int T, int TO>
+__global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_decimate(const float2* __restrict__ in, size_t in_stride,
+                                                   const float2* __restrict__ hist_in, float2* __restrict__ hist_out,
+                                                   const float* __restrict__ taps,
+                                                   float2* __restrict__ out, size_t out_stride,
+                                                   const StreamCall* __restrict__ call, int stage, int final_stage,
+                                                   uint32_t fir_hist_cap, uint32_t tiles_per_wg, float2* __restrict__ fft_in,
+                                                   uint32_t n_streams, uint32_t lin_ntiles, StreamCall* __restrict__ call_copy)
+{
+    __shared__ float4 tile4[dec_tile_f4<D, T, TO>()];
+    decimate_body<D, T, TO>(in, in_stride, hist_in, hist_out, taps, out, out_stride, call, stage, final_stage, fir_hist_cap, tiles_per_wg, fft_in,
+                            n_streams, lin_ntiles, call_copy, blockIdx.x, blockIdx.y, gridDim.x, tile4);
+}
+
+// One launch per step in batch mode: workgroups [0, n_tail) are the stream tails of the PREVIOUS call (tail_body.h: stage 2, low-pass,
+// discriminator, symbol extractor -- one wave per stream), workgroups [n_tail, gridDim.x) share this call's stage-1 tiles as a linear
+// split.  Every workgroup is one wave with the same register and LDS footprint, eight slots per CU; the tails are dispatched first
+// and finish after a fraction of the launch, the hardware dispatcher hands their slots to stage-1 workgroups as they free up, and the
+// HBM-bound stage-1 waves that are resident from the start keep the memory system busy meanwhile.  No second queue, no event waits.
+template <int D, int T, int D2, int T2>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_step(const float2* __restrict__ in, size_t in_stride,
+                                                   const float2* __restrict__ hist_in, float2* __restrict__ hist_out,
+                                                   const float* __restrict__ taps,
+                                                   float2* __restrict__ out, size_t out_stride,
+                                                   const StreamCall* __restrict__ call, uint32_t n_streams, uint32_t lin_ntiles,
+                                                   StreamCall* __restrict__ call_copy, const TailArgs ta, const uint32_t n_tail)
+{
+    constexpr int kF4 = dec_tile_f4<D, T, 64>() > (int)(kStepLdsBytes / 16) ? dec_tile_f4<D, T, 64>() : (int)(kStepLdsBytes / 16);
+    __shared__ float4 tile4[kF4];
+    if (blockIdx.x < n_tail) {
+        tail_body<64, 4, D2, T2>(ta, blockIdx.x, reinterpret_cast<unsigned char*>(tile4));
+        return;
+    }
+    decimate_body<D, T, 64>(in, in_stride, hist_in, hist_out, taps, out, out_stride, call, 0, 0, 0u, 0u, nullptr, n_streams, lin_ntiles, call_copy,
+                            blockIdx.x - n_tail, 0u, gridDim.x - n_tail, tile4);
 }
 
 __global__ void k_passthrough(const float2* __restrict__ in, size_t in_stride, float2* __restrict__ out, size_t out_stride,
@@ -375,7 +431,7 @@ __global__ __launch_bounds__(64) void k_dc_remove(float2* __restrict__ fbuf, siz
 template <int D, int T, int TO>
 static void launch_one(hipStream_t st, uint32_t n_streams, uint32_t max_out, const float2* in, size_t in_stride,
                        const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride,
-                       const StreamCall* call, int stage, int final_stage, uint32_t fir_hist_cap, float2* fft_in, uint32_t lin_wgs)
+                       const StreamCall* call, int stage, int final_stage, uint32_t fir_hist_cap, float2* fft_in, uint32_t lin_wgs, StreamCall* call_copy)
 {
     constexpr uint32_t TOUT = TO * dec_opl<D>();
     const uint32_t ntiles = (max_out + TOUT - 1) / TOUT;
@@ -384,7 +440,7 @@ static void launch_one(hipStream_t st, uint32_t n_streams, uint32_t max_out, con
     // eight 19.5 KB LDS slots this kernel takes -- the rest stays free for the back-half kernels of the previous call.
     if (TO == 64 && lin_wgs && (uint64_t)ntiles * n_streams >= 4ull * lin_wgs) {
         hipLaunchKernelGGL((k_decimate<D, T, TO>), dim3(lin_wgs), dim3(TO), 0, st, in, in_stride, hist_in, hist_out, taps, out, out_stride, call,
-                           stage, final_stage, fir_hist_cap, 0u, fft_in, n_streams, ntiles);
+                           stage, final_stage, fir_hist_cap, 0u, fft_in, n_streams, ntiles, call_copy);
         return;
     }
     // Walk several tiles per workgroup (prefetch pipelining) once there are enough workgroups to fill the chip:
@@ -393,19 +449,35 @@ static void launch_one(hipStream_t st, uint32_t n_streams, uint32_t max_out, con
     while (per < 16 && (uint64_t)((ntiles + 2 * per - 1) / (2 * per)) * n_streams >= 2048) per *= 2;
     dim3 grid((ntiles + per - 1) / per, n_streams);
     hipLaunchKernelGGL((k_decimate<D, T, TO>), grid, dim3(TO), 0, st, in, in_stride, hist_in, hist_out, taps, out, out_stride, call,
-                       stage, final_stage, fir_hist_cap, per, fft_in, n_streams, 0u);
+                       stage, final_stage, fir_hist_cap, per, fft_in, n_streams, 0u, (StreamCall*)nullptr);
 }
 
 bool launch_decimate(hipStream_t st, int ratio, int ntaps, uint32_t n_streams, uint32_t max_out, const float2* in, size_t in_stride,
                      const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
-                     int stage, int final_stage, uint32_t fir_hist_cap, float2* fft_in, uint32_t lin_wgs)
+                     int stage, int final_stage, uint32_t fir_hist_cap, float2* fft_in, uint32_t lin_wgs, StreamCall* call_copy)
 {
     if (!max_out) return true;
 #define HD_CASE(D, T, TO) \
-    if (ratio == D && ntaps == T) { launch_one<D, T, TO>(st, n_streams, max_out, in, in_stride, hist_in, hist_out, taps, out, out_stride, call, stage, final_stage, fir_hist_cap, fft_in, lin_wgs); return true; }
+    if (ratio == D && ntaps == T) { launch_one<D, T, TO>(st, n_streams, max_out, in, in_stride, hist_in, hist_out, taps, out, out_stride, call, stage, final_stage, fir_hist_cap, fft_in, lin_wgs, call_copy); return true; }
     HD_CASE(2, 69, 256) HD_CASE(4, 139, 256) HD_CASE(8, 280, 256) HD_CASE(8, 54, 256)
     HD_CASE(16, 107, 128) HD_CASE(32, 212, 64) HD_CASE(32, 174, 64) HD_CASE(64, 348, 64)
 #undef HD_CASE
+    return false;
+}
+
+bool launch_step(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, uint32_t n_streams, uint32_t n_out, const float2* in, size_t in_stride,
+                 const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
+                 StreamCall* call_copy, uint32_t stage1_wgs, const TailArgs& ta, uint32_t n_tail)
+{
+#define HD_STEP_CASE(D, T, D2, T2)                                                                                                    \
+    if (ratio == D && ntaps == T && ratio2 == D2 && ntaps2 == T2) {                                                                   \
+        const uint32_t ntiles = (n_out + 63) / 64;                                                                                    \
+        hipLaunchKernelGGL((k_step<D, T, D2, T2>), dim3(n_tail + stage1_wgs), dim3(64), 0, st, in, in_stride, hist_in, hist_out, taps, out, \
+                           out_stride, call, n_streams, ntiles, call_copy, ta, n_tail);                                               \
+        return true;                                                                                                                  \
+    }
+    HD_STEP_CASE(32, 212, 2, 69) HD_STEP_CASE(32, 174, 4, 139) HD_STEP_CASE(64, 348, 4, 139)
+#undef HD_STEP_CASE
     return false;
 }
 

@@ -23,7 +23,8 @@ bool launch_decimate(hipStream_t st, int ratio, int ntaps, uint32_t n_streams, u
                      const float2* in, size_t in_stride, const float2* hist_in, float2* hist_out, const float* taps,
                      float2* out, size_t out_stride, const StreamCall* call, int stage, int final_stage,
                      uint32_t fir_hist_cap, float2* fft_in /* final stage: spectrum input buffer [S][4096], or null */,
-                     uint32_t lin_wgs = 0 /* != 0: every stream has the same size; use exactly this many workgroups (single-wave kernels) */);
+                     uint32_t lin_wgs = 0 /* != 0: every stream has the same size; use exactly this many workgroups (single-wave kernels) */,
+                     StreamCall* call_copy = nullptr /* linear split only: leave a device copy of each stream's parameters here */);
 // copy `bytes` (multiple of 16) from mapped pinned host memory into device memory with a kernel
 void launch_fetch_params(hipStream_t st, const void* host_mapped, void* dst, size_t bytes);
 // factor 1: copy the chunk behind the FIR history.
@@ -71,13 +72,20 @@ struct TailArgs {
     float* ring; uint32_t ring_cap; SymState* sym; unsigned long long* flipmask; float* wsum; const SymbolParams* sp;
     uint32_t* slots; uint32_t slot_words; uint32_t* flips_dbg; uint32_t flips_cap;
     // LDS carve in bytes from the base of the workgroup's scratch (tail_layout)
-    uint32_t f_off, v_off, ws_off, words_off, lmask_off, flips_off, fl_cap, strips_off, wc_off, wc_cap, lds_bytes;
+    uint32_t pend_max, f_off, v_off, ws_off, words_off, tp_off, h2_off, lmask_off, flips_off, fl_cap, strips_off, wc_off, wc_cap, vc_off, vc_cap, lds_bytes;
 };
 // Fills the LDS carve for `lanes` (64 or 256) lanes per stream; returns false when (ratio2, ntaps2) has no tail instantiation or the
 // windows for max_taps / max_R do not fit into lds_limit bytes -- the caller then runs launch_backend / launch_decimate + launch_fir_demod
 // and launch_symbols instead.
-bool tail_layout(TailArgs& a, int lanes, int ratio2, int ntaps2, uint32_t max_taps, uint32_t max_R, uint32_t min_R, uint32_t ring_cap, uint32_t lds_limit);
+bool tail_layout(TailArgs& a, int lanes, int ratio2, int ntaps2, uint32_t max_taps, uint32_t max_R, uint32_t min_R, uint32_t ring_cap,
+                 uint32_t pend_max /* most pending samples any stream has in front of or behind this call's low-pass run */, uint32_t lds_limit);
 bool launch_tail(hipStream_t st, int lanes, int ratio2, int ntaps2, uint32_t n_streams, const TailArgs& a);
+// Batch mode, two-stage plans whose first stage is a single-wave design: ONE launch per step -- the stream tails of the previous call
+// (workgroups [0, n_tail), arguments `ta`) in front of this call's stage 1 as a linear split over stage1_wgs workgroups; every stream
+// has n_out stage-1 outputs.  Returns false when there is no instantiation for the plan.
+bool launch_step(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, uint32_t n_streams, uint32_t n_out, const float2* in, size_t in_stride,
+                 const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
+                 StreamCall* call_copy, uint32_t stage1_wgs, const TailArgs& ta, uint32_t n_tail);
 constexpr uint32_t kStepLdsBytes = 20480;   // LDS of a stage-1 workgroup slot (eight per CU): what a tail riding in the stage-1 launch may use
 
 }  // namespace hd

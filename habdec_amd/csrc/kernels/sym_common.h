@@ -45,12 +45,15 @@ __device__ __forceinline__ void window_sums(const float* __restrict__ w, uint32_
         a01 = a01 + (f32x2){x.w, x.w}; a23 = a23 + (f32x2){x.w, x.w};
     }
     uint32_t e = 4;
+    float4 x = *reinterpret_cast<const float4*>(w + 4);    // one chunk ahead: the next 16-byte read is in flight during the adds
     for (; e + 4 <= R; e += 4) {                            // interior: every element feeds all four
-        const float4 x = *reinterpret_cast<const float4*>(w + e);
+        const float4 nx = *reinterpret_cast<const float4*>(w + e + 4);   // (callers pad their windows: a chunk past the last one is readable)
+        __builtin_amdgcn_sched_barrier(0);
         a01 = a01 + (f32x2){x.x, x.x}; a23 = a23 + (f32x2){x.x, x.x};
         a01 = a01 + (f32x2){x.y, x.y}; a23 = a23 + (f32x2){x.y, x.y};
         a01 = a01 + (f32x2){x.z, x.z}; a23 = a23 + (f32x2){x.z, x.z};
         a01 = a01 + (f32x2){x.w, x.w}; a23 = a23 + (f32x2){x.w, x.w};
+        x = nx;
     }
     float acc0 = a01.x, acc1 = a01.y, acc2 = a23.x, acc3 = a23.y;
     for (; e < total; e += 4) {                             // tail chunks: element e+u feeds accumulators with e+u < j + R
@@ -66,6 +69,63 @@ __device__ __forceinline__ void window_sums(const float* __restrict__ w, uint32_
         }
     }
     acc[0] = acc0; acc[1] = acc1; acc[2] = acc2; acc[3] = acc3;
+}
+
+// The same for a lane that owns EIGHT consecutive positions: acc[j] = w[j] + ... + w[j+R-1], j = 0..7.  Four packed accumulators are
+// four independent add chains -- what ONE wave needs to issue back to back (two chains wait out the add latency on every element).
+// Element e feeds accumulator j iff j <= e <= j + R - 1.  `w` is 16-byte aligned and readable up to w[R + 15].
+constexpr int kWidePos = 8;
+__device__ __forceinline__ void window_sums8(const float* __restrict__ w, uint32_t R, float acc[kWidePos])
+{
+    float s[kWidePos];
+#pragma unroll
+    for (int j = 0; j < kWidePos; ++j) s[j] = 0.0f;
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    if (R >= (uint32_t)kWidePos) {
+        {   // head: element u < 8 feeds the accumulators j <= u
+            const float4 x0 = w4[0], x1 = w4[1];
+            const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int j = 0; j <= u; ++j) s[j] = s[j] + xs[u];
+        }
+        f32x2 a01 = {s[0], s[1]}, a23 = {s[2], s[3]}, a45 = {s[4], s[5]}, a67 = {s[6], s[7]};
+        uint32_t e = 8;
+        float4 x = w4[2];
+        for (; e + 4 <= R; e += 4) {                        // interior: every element feeds all eight
+            const float4 nx = w4[(e >> 2) + 1];
+            __builtin_amdgcn_sched_barrier(0);
+            a01 = a01 + (f32x2){x.x, x.x}; a23 = a23 + (f32x2){x.x, x.x}; a45 = a45 + (f32x2){x.x, x.x}; a67 = a67 + (f32x2){x.x, x.x};
+            a01 = a01 + (f32x2){x.y, x.y}; a23 = a23 + (f32x2){x.y, x.y}; a45 = a45 + (f32x2){x.y, x.y}; a67 = a67 + (f32x2){x.y, x.y};
+            a01 = a01 + (f32x2){x.z, x.z}; a23 = a23 + (f32x2){x.z, x.z}; a45 = a45 + (f32x2){x.z, x.z}; a67 = a67 + (f32x2){x.z, x.z};
+            a01 = a01 + (f32x2){x.w, x.w}; a23 = a23 + (f32x2){x.w, x.w}; a45 = a45 + (f32x2){x.w, x.w}; a67 = a67 + (f32x2){x.w, x.w};
+            x = nx;
+        }
+        s[0] = a01.x; s[1] = a01.y; s[2] = a23.x; s[3] = a23.y; s[4] = a45.x; s[5] = a45.y; s[6] = a67.x; s[7] = a67.y;
+        for (; e < R; ++e) {                                // R % 4 elements that still feed all eight
+            const float xe = w[e];
+#pragma unroll
+            for (int j = 0; j < kWidePos; ++j) s[j] = s[j] + xe;
+        }
+        // tail: element R + d (d = 0..6) feeds the accumulators j > d
+        float xt[7];
+#pragma unroll
+        for (int d = 0; d < 7; ++d) xt[d] = w[R + d];
+#pragma unroll
+        for (int d = 0; d < 7; ++d)
+#pragma unroll
+            for (int j = d + 1; j < kWidePos; ++j) s[j] = s[j] + xt[d];
+    } else {                                                // tiny windows (fewer than 32 samples per bit): plain loops
+        for (uint32_t e = 0; e < R + kWidePos - 1; ++e) {
+            const float xe = w[e];
+#pragma unroll
+            for (int j = 0; j < kWidePos; ++j)
+                if (e < (uint32_t)j + R && (uint32_t)j <= e) s[j] = s[j] + xe;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kWidePos; ++j) acc[j] = s[j];
 }
 
 // Wave-wide maximum of an unsigned 64-bit key with DPP moves (a ds_bpermute-based shuffle reduction costs an LDS round trip

@@ -13,20 +13,28 @@ __global__ __launch_bounds__(NT) void k_tail(const TailArgs a)
     tail_body<NT, OP, D2, T2>(a, blockIdx.x, tail_lds);
 }
 
+#ifdef HD_STAMP_TAIL
+extern "C" void hd_debug_tail_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tail_stamps), n * 8); }
+#endif
+
 static constexpr int tail_op(int lanes) { return lanes == 64 ? 4 : 1; }
 
-bool tail_layout(TailArgs& a, int lanes, int ratio2, int ntaps2, uint32_t max_taps, uint32_t max_R, uint32_t min_R, uint32_t ring_cap, uint32_t lds_limit)
+bool tail_layout(TailArgs& a, int lanes, int ratio2, int ntaps2, uint32_t max_taps, uint32_t max_R, uint32_t min_R, uint32_t ring_cap, uint32_t pend_max, uint32_t lds_limit)
 {
     if (!((ratio2 == 2 && ntaps2 == 69) || (ratio2 == 4 && ntaps2 == 139))) return false;
     if (lanes != 64 && lanes != 256) return false;
-    const uint32_t NT = (uint32_t)lanes, P = NT * (uint32_t)tail_op(lanes), B = P + (kFirBatch - 1);
+    if (pend_max > kFirBatch - 1) pend_max = kFirBatch - 1;
+    a.pend_max = pend_max;
+    const uint32_t NT = (uint32_t)lanes, P = NT * (uint32_t)tail_op(lanes), B = 2 * P + pend_max;
     const uint32_t XN = (uint32_t)(ntaps2 - 1) + P * (uint32_t)ratio2;
     const uint32_t H = max_taps ? max_taps - 1 : 0;
-    uint32_t off = kTailHdrBytes + (((XN + 1) & ~1u) + 2 * NT + 2) * 8;
-    a.f_off = off; off += ((H + (kFirBatch - 1) + P + 4 + 1) & ~1u) * 8;
-    a.v_off = off; off += ((max_R + B + 8 + 3) & ~3u) * 4;
-    a.ws_off = off; off += ((max_R + B + 4 + 3) & ~3u) * 4;
-    a.words_off = off; off += (kAvgPos * NT / 64 + 2) * 8;
+    uint32_t off = kTailHdrBytes + (((XN + 4 + 1) & ~1u) + 2 * NT + 2) * 8;
+    a.f_off = off; off += ((H + B + 16 + 1) & ~1u) * 8;
+    a.v_off = off; off += ((max_R + B + 16 + 3) & ~3u) * 4;
+    a.ws_off = off; off += ((max_R + B + 8 + 3) & ~3u) * 4;
+    a.words_off = off; off += (kWidePos * NT / 64 + 2) * 8;
+    a.tp_off = off; off += ((max_taps + 8 + 3) & ~3u) * 4;
+    a.h2_off = off; off += (((uint32_t)ntaps2 + 7) & ~3u) * 4;
     const uint32_t stream_phase = off;
     // search phase (overlays the windows above): flag-mask image, flip list, run info, run-sum strips, window-sum cache
     off = kTailHdrBytes;
@@ -38,11 +46,15 @@ bool tail_layout(TailArgs& a, int lanes, int ratio2, int ntaps2, uint32_t max_ta
     a.flips_off = off; off += fl_cap * 8;
     a.strips_off = off; off += (NT / 64) * kTailStrip * 4;
     a.wc_off = off;
-    const uint32_t need = stream_phase > off + 4096 ? stream_phase : off + 4096;   // at least 1024 cached window sums
+    const uint32_t need = stream_phase > off + 6144 ? stream_phase : off + 6144;   // at least 1024 cached window sums + 512 cached samples
     if (need > lds_limit) return false;
-    a.lds_bytes = lds_limit < 65536 ? lds_limit : 65536;
-    if (a.lds_bytes < need) a.lds_bytes = need;
-    a.wc_cap = (a.lds_bytes - a.wc_off) / 4;
+    uint32_t want = off + 4 * (2560 + 1536);                             // window sums of ~four symbols of backlog at 50 baud, samples of one call and a half
+    if (want < need) want = need;
+    a.lds_bytes = want < lds_limit ? want : lds_limit;
+    const uint32_t room = ((a.lds_bytes - a.wc_off) / 4) & ~3u;          // split 5 : 3 between the window-sum cache and the sample cache
+    a.wc_cap = (room * 5 / 8) & ~3u;
+    a.vc_off = a.wc_off + a.wc_cap * 4;
+    a.vc_cap = room - a.wc_cap;
     return true;
 }
 

@@ -29,11 +29,58 @@ namespace hd {
 constexpr uint32_t kTailHdrBytes = 64;          // small shared scalars at the base of the workgroup's LDS scratch
 constexpr uint32_t kTailStrip = 512;            // samples per run-sum step (per wave)
 
-#define HD_TB_PAIR(P_, N_, k0, k1)                        \
-    a0r = a0r + (P_).x * (k0); a0i = a0i + (P_).y * (k0); \
-    a1r = a1r + (P_).z * (k0); a1i = a1i + (P_).w * (k0); \
-    a0r = a0r + (P_).z * (k1); a0i = a0i + (P_).w * (k1); \
-    a1r = a1r + (N_).x * (k1); a1i = a1i + (N_).y * (k1);
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Tap tables are read-only for the whole launch, but they hang off a by-value argument struct, so the compiler cannot prove that the
+// kernel's own stores leave them alone and would fetch them with VECTOR loads inside the loops (a vmcnt(0) wait per block of taps).
+// Reading them through the constant address space makes them scalar loads (wave-uniform address, scalar cache).
+typedef const float __attribute__((address_space(4)))* cfloat_ptr;
+__device__ __forceinline__ cfloat_ptr as_const(const float* p) { return (cfloat_ptr)(uintptr_t)p; }
+
+// One tap for a lane's four adjacent outputs: four independent products, then four independent adds.  Every accumulator still
+// receives its products in ascending tap order with separately rounded multiply and add; keeping the four chains apart is what lets
+// ONE wave issue back to back (a single chain waits out the add latency on every tap).
+#define HD_TB_TAP4(A_, B_, C_, D_, k_)                                                        \
+    {                                                                                         \
+        const f32x2 p0_ = (A_) * (k_), p1_ = (B_) * (k_), p2_ = (C_) * (k_), p3_ = (D_) * (k_); \
+        a0 = a0 + p0_; a1 = a1 + p1_; a2 = a2 + p2_; a3 = a3 + p3_;                           \
+    }
+
+#ifdef HD_STAMP_TAIL   // diagnostic build only (tools/micro/tail_stamps.py): cycles per phase of the tail, per stream
+__device__ unsigned long long g_tail_stamps[8192 * 24];
+#define TSTAMP_DECL unsigned long long ts_t = __builtin_amdgcn_s_memtime(), ts_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long ts_r0 = __builtin_amdgcn_s_memrealtime()
+#define TSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ts_acc[i] += t_ - ts_t; ts_t = t_; } while (0)
+#define TSTAMP_WRITE() do { if (threadIdx.x == 0 && s < 8192) { unsigned long long* g_ = g_tail_stamps + (size_t)s * 24; for (int i_ = 0; i_ < 20; ++i_) g_[i_] = ts_acc[i_]; g_[20] = ts_r0; g_[21] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define TSTAMP_DECL do { } while (0)
+#define TSTAMP(i) do { } while (0)
+#define TSTAMP_WRITE() do { } while (0)
+#endif
+
+#define HD_TB_TAPN(A_, B_, C_, D_, k_, a0_, a1_, a2_, a3_)                                    \
+    {                                                                                         \
+        const f32x2 p0_ = (A_) * (k_), p1_ = (B_) * (k_), p2_ = (C_) * (k_), p3_ = (D_) * (k_); \
+        a0_ = a0_ + p0_; a1_ = a1_ + p1_; a2_ = a2_ + p2_; a3_ = a3_ + p3_;                   \
+    }
+// Four taps K_ = (k, k+1, k+2, k+3) for four adjacent outputs whose inputs start in pair W0_: output q takes input q + u for tap u.
+#define HD_TB_BLK(W0_, W1_, W2_, W3_, K_, a0_, a1_, a2_, a3_)                      \
+    HD_TB_TAPN((W0_).xy, (W0_).zw, (W1_).xy, (W1_).zw, (K_).x, a0_, a1_, a2_, a3_) \
+    HD_TB_TAPN((W0_).zw, (W1_).xy, (W1_).zw, (W2_).xy, (K_).y, a0_, a1_, a2_, a3_) \
+    HD_TB_TAPN((W1_).xy, (W1_).zw, (W2_).xy, (W2_).zw, (K_).z, a0_, a1_, a2_, a3_) \
+    HD_TB_TAPN((W1_).zw, (W2_).xy, (W2_).zw, (W3_).xy, (K_).w, a0_, a1_, a2_, a3_)
+
+// One tap (position U of a block of four) for a lane's OP adjacent stage-2 outputs: sample D2*q + U of the rolling window for output q.
+template <int U, int OP, int D2, int NWIN>
+__device__ __forceinline__ void tb_s2_tap(f32x2 (&acc)[OP], const f32x4 (&win)[NWIN], const float k)
+{
+    f32x2 pr[OP];
+#pragma unroll
+    for (int q = 0; q < OP; ++q) {
+        const f32x4 w = win[(D2 * q + U) >> 1];
+        if constexpr (U & 1) pr[q] = w.zw * k; else pr[q] = w.xy * k;
+    }
+#pragma unroll
+    for (int q = 0; q < OP; ++q) acc[q] = acc[q] + pr[q];
+}
 
 template <int NT>
 __device__ __forceinline__ void tb_sync()
@@ -51,18 +98,21 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     constexpr int XB = XCH / 2 / NT;                // 16-byte loads per lane and piece
     constexpr int HB = (T2 - 1 + NT - 1) / NT;
     constexpr int NW = NT / 64;
-    constexpr uint32_t B = P + (kFirBatch - 1);     // most discriminator outputs one piece can release
+    const uint32_t B = 2 * P + a.pend_max;          // most discriminator outputs one low-pass round (two pieces) can release
     static_assert(((T2 - 1) & 1) == 0 && XCH % (2 * NT) == 0, "16-byte pairs must stay aligned");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
     uint32_t* sh = reinterpret_cast<uint32_t*>(lds);                    // [0] nfl [1] overflow [2] frontier [3] carry sum [4] flagged
     float2* X = reinterpret_cast<float2*>(lds + kTailHdrBytes);
-    float2* Y = X + ((XN + 1) & ~1);                                    // [1]: predecessor of this pass's first output; outputs from [2]
+    float2* Y = X + ((XN + 4 + 1) & ~1);                                // [0]: predecessor of this pass's first output; [1 + l], [1 + NT + l]: lane l's last outputs
     float2* F = reinterpret_cast<float2*>(lds + a.f_off);               // low-pass input window, F[0] = input index fbase
     float* V = reinterpret_cast<float*>(lds + a.v_off);                 // discriminator output from position c0 on
     float* WS = reinterpret_cast<float*>(lds + a.ws_off);               // window sums of [c0 - R, c0), then the new ones
     unsigned long long* words = reinterpret_cast<unsigned long long*>(lds + a.words_off);
+    float* TP = reinterpret_cast<float*>(lds + a.tp_off);              // this stream's low-pass taps
+    float* H2 = reinterpret_cast<float*>(lds + a.h2_off);              // stage-2 taps
 
+    TSTAMP_DECL;
     const StreamCall c = a.call[s];
     const uint32_t n1 = c.n1, n2 = c.n2, m = c.fir_m, T = c.fir_taps, pb = c.pend_before;
     const uint32_t H = T ? T - 1 : 0;
@@ -108,15 +158,6 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     // ---- every global read the first piece needs, issued back to back (one round trip): a touch of each 64-byte line of the
     // stream's low-pass taps (scalar cache), stage-2 history, the first piece of the stage-1 chunk, low-pass history + pending,
     // the backlog samples and window sums the first window sums build on, the boundary word of the flag mask.
-    float tap_touch = 0.f;
-    {
-        const uint32_t tl = T ? T - 1 : 0;
-        float tt[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) tt[u] = tp[min((uint32_t)u * 16u, tl)];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) tap_touch += tt[u];
-    }
     const bool refold = Tp != T && !c.fir_zero_hist && run;           // first run after a tap-count change (FirHistory, dev_types.h)
     const uint32_t head_n = refold ? head_n_in[0] : 0u;
     auto fold = [&](uint32_t k) -> float2 {                             // element k of [history (H) | pending]
@@ -137,9 +178,11 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
             tx[u] = k < n1p ? in4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    constexpr int FBN = 512 / NT, VBN = 512 / NT;
-    const uint32_t take0 = min(old_cnt, (uint32_t)(VBN * NT));
+    constexpr uint32_t kFirst = 256;                                    // backlog samples taken with the first batch (R-1 of them are due in steady state)
+    const uint32_t take0 = min(old_cnt, kFirst);
     {
+        // Tap tables go to LDS: inside the loops every operand then comes through ds_read (in-order, counted waits), so the next
+        // block's reads stay in flight under the math; scalar loads there would force a full lgkmcnt(0) stall per block.
         float2 th[HB];
 #pragma unroll
         for (int u = 0; u < HB; ++u) {
@@ -147,33 +190,58 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
             th[u] = (k < (uint32_t)(T2 - 1) && !c.zero_hist2) ? a.hist2_in[(size_t)s * (T2 - 1) + k] : make_float2(0.f, 0.f);
         }
         prefetch(0);
-        float2 tf[FBN];
-#pragma unroll
-        for (int u = 0; u < FBN; ++u) { const uint32_t k = tid + u * NT; tf[u] = k < f_old ? cur[fhc - H + k] : make_float2(0.f, 0.f); }
-        float tv[VBN], tw[VBN];
-#pragma unroll
-        for (int u = 0; u < VBN; ++u) { const uint32_t k = tid + u * NT; tv[u] = k < take0 ? vring[(c0 + k) & rmask] : 0.f; }
-#pragma unroll
-        for (int u = 0; u < VBN; ++u) { const uint32_t k = tid + u * NT; tw[u] = (do_sums && k < R) ? gw[(c0 - R + k) & rmask] : 0.f; }
         if (do_sums && (c0 & 63u)) carry_word = gmask[(c0 & rmask) >> 6] & ((1ull << (c0 & 63u)) - 1ull);
-        if (c.fir_zero_hist || refold) {
+        constexpr int LB = 4;                                           // loads per lane in flight per batch
+#pragma unroll 1
+        for (uint32_t k0 = 0; k0 < T + 8; k0 += LB * NT) {
+            float t[LB];
 #pragma unroll
-            for (int u = 0; u < FBN; ++u) { const uint32_t k = tid + u * NT; if (k < H) tf[u] = fold(k); }
+            for (int u = 0; u < LB; ++u) { const uint32_t k = k0 + tid + u * NT; t[u] = k < T ? tp[k] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < LB; ++u) { const uint32_t k = k0 + tid + u * NT; if (k < T + 8) TP[k] = t[u]; }
+        }
+#pragma unroll 1
+        for (uint32_t k0 = 0; k0 < (uint32_t)((T2 + 7) & ~3); k0 += LB * NT) {
+            float t[LB];
+#pragma unroll
+            for (int u = 0; u < LB; ++u) { const uint32_t k = k0 + tid + u * NT; t[u] = k < (uint32_t)T2 ? a.taps2[k] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < LB; ++u) { const uint32_t k = k0 + tid + u * NT; if (k < (uint32_t)((T2 + 7) & ~3)) H2[k] = t[u]; }
+        }
+        const bool special = c.fir_zero_hist || refold;               // history restarts from zeros / first run after a redesign
+#pragma unroll 1
+        for (uint32_t k0 = 0; k0 < f_old; k0 += LB * NT) {
+            float2 t[LB];
+#pragma unroll
+            for (int u = 0; u < LB; ++u) { const uint32_t k = k0 + tid + u * NT; t[u] = k < f_old ? (special ? fold(k) : cur[fhc - H + k]) : make_float2(0.f, 0.f); }
+#pragma unroll
+            for (int u = 0; u < LB; ++u) { const uint32_t k = k0 + tid + u * NT; if (k < f_old) F[k] = t[u]; }
+        }
+        if (do_sums) {
+#pragma unroll 1
+            for (uint32_t k0 = 0; k0 < take0; k0 += LB * NT) {
+                float t[LB];
+#pragma unroll
+                for (int u = 0; u < LB; ++u) { const uint32_t k = k0 + tid + u * NT; t[u] = k < take0 ? vring[(c0 + k) & rmask] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < LB; ++u) { const uint32_t k = k0 + tid + u * NT; if (k < take0) V[k] = t[u]; }
+            }
+#pragma unroll 1
+            for (uint32_t k0 = 0; k0 < R; k0 += LB * NT) {
+                float t[LB];
+#pragma unroll
+                for (int u = 0; u < LB; ++u) { const uint32_t k = k0 + tid + u * NT; t[u] = k < R ? gw[(c0 - R + k) & rmask] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < LB; ++u) { const uint32_t k = k0 + tid + u * NT; if (k < R) WS[k] = t[u]; }
+            }
         }
 #pragma unroll
         for (int u = 0; u < HB; ++u) { const uint32_t k = tid + u * NT; if (k < (uint32_t)(T2 - 1)) X[k] = th[u]; }
-#pragma unroll
-        for (int u = 0; u < FBN; ++u) { const uint32_t k = tid + u * NT; if (k < f_old) F[k] = tf[u]; }
-        for (uint32_t k = tid + FBN * NT; k < f_old; k += NT) F[k] = fold(k);
-#pragma unroll
-        for (int u = 0; u < VBN; ++u) { const uint32_t k = tid + u * NT; if (k < take0) V[k] = tv[u]; }
-#pragma unroll
-        for (int u = 0; u < VBN; ++u) { const uint32_t k = tid + u * NT; if (do_sums && k < R) WS[k] = tw[u]; }
-        if (do_sums) for (uint32_t k = tid + VBN * NT; k < R; k += NT) WS[k] = gw[(c0 - R + k) & rmask];
-        if (tid == 0) Y[1] = make_float2(kin.re, kin.im);
+        if (tid == 0) Y[0] = make_float2(kin.re, kin.im);
     }
     vcnt = take0;
     tb_sync<NT>();
+    TSTAMP(0);
     for (uint32_t k = tid; k < pb && k < hn; k += NT) head_out[k] = F[H + k];     // pending samples open this run's input (FirHistory)
 
     // ---- window sums + flags for every position whose right window is complete: positions [c0, c0 + vcnt - R + 1).
@@ -183,32 +251,39 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         uint32_t off = 0;
         const float tiny = (float)R * 2.8e-45f;
         auto avg_sign = [&](float wsum) { return __builtin_fabsf(wsum) > tiny ? sgnf(wsum) : sgnf(wsum / (float)R); };
+        constexpr uint32_t KP = kWidePos;                               // positions per lane
         while (npos > 0) {
-            const uint32_t cnt = min((uint32_t)npos, (uint32_t)(kAvgPos * NT));
+            const uint32_t cnt = min((uint32_t)npos, (uint32_t)(KP * NT));
             const uint32_t wb0 = c0 & ~63u, wsh = c0 & 63u;
             const uint32_t nwords = (wsh + cnt + 63u) >> 6;
-            if (tid < (uint32_t)(kAvgPos * NT / 64 + 2)) words[tid] = 0ull;
+            if (tid < (uint32_t)(KP * NT / 64 + 2)) words[tid] = 0ull;
             tb_sync<NT>();
-            const bool any = kAvgPos * tid < cnt;
-            float wp[kAvgPos];
+            const bool any = KP * tid < cnt;
+            float wp[KP];
             if (any) {
-                window_sums(V + off + kAvgPos * tid, R, wp);
+                window_sums8(V + off + KP * tid, R, wp);
 #pragma unroll
-                for (int j = 0; j < kAvgPos; ++j) {
-                    WS[off + R + kAvgPos * tid + j] = wp[j];
-                    if (kAvgPos * tid + j < cnt) gw[(c0 + kAvgPos * tid + j) & rmask] = wp[j];
+                for (int j = 0; j < (int)KP; ++j) WS[off + R + KP * tid + j] = wp[j];
+                float* gdst = gw + ((c0 + KP * tid) & rmask);           // c0 + KP*tid .. +7: contiguous unless the ring wraps inside
+                if (KP * tid + KP <= cnt && ((c0 + KP * tid) & rmask) + KP <= ring_cap && (((c0 + KP * tid) & 3u) == 0)) {
+                    *reinterpret_cast<float4*>(gdst) = make_float4(wp[0], wp[1], wp[2], wp[3]);
+                    *reinterpret_cast<float4*>(gdst + 4) = make_float4(wp[4], wp[5], wp[6], wp[7]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < (int)KP; ++j) if (KP * tid + j < cnt) gw[(c0 + KP * tid + j) & rmask] = wp[j];
                 }
             }
+            TSTAMP(15);
             tb_sync<NT>();
             if (any) {
                 unsigned int bits = 0;
 #pragma unroll
-                for (int j = 0; j < kAvgPos; ++j)
-                    if (kAvgPos * tid + j < cnt && avg_sign(WS[off + kAvgPos * tid + j]) != avg_sign(wp[j])) bits |= 1u << j;
+                for (int j = 0; j < (int)KP; ++j)
+                    if (KP * tid + j < cnt && avg_sign(WS[off + KP * tid + j]) != avg_sign(wp[j])) bits |= 1u << j;
                 if (bits) {
-                    const uint32_t bp = wsh + tid * kAvgPos, shb = bp & 63u;
+                    const uint32_t bp = wsh + tid * KP, shb = bp & 63u;
                     atomicOr(&words[bp >> 6], (unsigned long long)bits << shb);
-                    if (shb > 60u) atomicOr(&words[(bp >> 6) + 1], (unsigned long long)bits >> (64u - shb));
+                    if (shb > 64u - KP) atomicOr(&words[(bp >> 6) + 1], (unsigned long long)bits >> (64u - shb));
                 }
             }
             tb_sync<NT>();
@@ -225,6 +300,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
             }
             tb_sync<NT>();
             c0 += cnt; off += cnt; npos -= (int32_t)cnt;
+            TSTAMP(16);
         }
         if (off) {                                                      // slide both windows down by the positions done
             const uint32_t nv = vcnt - off;
@@ -246,24 +322,29 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
             }
             vcnt = nv;
             tb_sync<NT>();
+            TSTAMP(17);
         }
     };
-    if (do_sums) {
-        sym_feed();
-        for (uint32_t left = old_cnt - take0; left;) {                  // only after a parameter change: the whole backlog is due
-            const uint32_t take = min(left, B);
-            for (uint32_t k = tid; k < take; k += NT) V[vcnt + k] = vring[(c0 + vcnt + k) & rmask];
-            vcnt += take; left -= take;
-            tb_sync<NT>();
-            sym_feed();
-        }
-    }
-
+    TSTAMP(1);
     // ---- the call, piece by piece
     uint32_t fbase = 0, fcount = f_old, i_done = 0;
     const uint32_t npieces = (n2 + P - 1) / P;
-    if (tap_touch == 12345.678f) a.demod[0] = tap_touch;                // keeps the tap touch alive; never true for a low-pass design
-    for (uint32_t pc = 0; pc < npieces; ++pc) {
+    // One loop for both kinds of step -- first the backlog samples that are due beyond the first batch (only after a parameter
+    // change: the whole backlog is due), then the pieces of the call -- so that the window-sum code exists once.
+    uint32_t old_left = old_cnt - take0;
+    for (uint32_t pc = 0;;) {
+        if (do_sums) {
+            tb_sync<NT>();
+            sym_feed();
+        }
+        TSTAMP(6);
+        if (old_left) {
+            const uint32_t take = min(old_left, B);
+            for (uint32_t k = tid; k < take; k += NT) V[vcnt + k] = vring[(c0 + vcnt + k) & rmask];
+            vcnt += take; old_left -= take;
+            continue;
+        }
+        if (pc == npieces) break;
         const uint32_t o0 = pc * P, po = min((uint32_t)P, n2 - o0);
 #pragma unroll
         for (int u = 0; u < XB; ++u) {
@@ -272,49 +353,52 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         }
         tb_sync<NT>();
         if (pc + 1 < npieces) prefetch(pc + 1);
+        TSTAMP(2);
 
-        // stage 2: y2[o] = sum_t x[o*D2 + t] * h2[t]; two outputs (o, o + NT) share each block of eight taps
+        // stage 2: y2[o] = sum_t x[o*D2 + t] * h2[t].  A lane owns OP ADJACENT outputs of the piece (o = OP*tid + q): their inputs
+        // overlap, so a block of four taps costs two new 16-byte LDS reads (plus one for the taps) for 8*OP multiply-adds, and the OP
+        // sums are independent chains that keep one wave issuing back to back.  Sample j of the block, relative to the lane's first
+        // input, is D2*q + u for output q and tap u: pair (D2*q + u) / 2 of the rolling window, low or high half.
+        {
+            constexpr int NWIN = ((D2 * (OP - 1) + 3) >> 1) + 1;       // 16-byte pairs a block of four taps touches
+            const f32x4* h2 = reinterpret_cast<const f32x4*>(H2);
+            const f32x4* px = reinterpret_cast<const f32x4*>(X + (size_t)(OP * tid) * D2);
+            f32x4 kc = h2[0];
+            f32x2 acc[OP];
+            f32x4 win[NWIN];
 #pragma unroll
-        for (int jo = 0; jo < OP; jo += 2) {
-            const uint32_t oa = tid + jo * NT, ob = oa + NT;
-            if (oa < po) {
-                const bool has_b = (jo + 1 < OP) && ob < po;
-                const float4* p4 = reinterpret_cast<const float4*>(X + (size_t)oa * D2);
-                const float4* q4 = has_b ? reinterpret_cast<const float4*>(X + (size_t)ob * D2) : p4;
-                float ar = 0.f, ai = 0.f, br = 0.f, bi = 0.f;
-                int t = 0;
-#pragma unroll 1
-                for (; t + 8 <= T2; t += 8) {
-                    const float4 x0 = p4[(t >> 1)], x1 = p4[(t >> 1) + 1], x2 = p4[(t >> 1) + 2], x3 = p4[(t >> 1) + 3];
-                    const float4 z0 = q4[(t >> 1)], z1 = q4[(t >> 1) + 1], z2 = q4[(t >> 1) + 2], z3 = q4[(t >> 1) + 3];
-                    const float* tb = a.taps2 + t;
-                    const float k0 = tb[0], k1 = tb[1], k2 = tb[2], k3 = tb[3], k4 = tb[4], k5 = tb[5], k6 = tb[6], k7 = tb[7];
-                    ar = ar + x0.x * k0; ai = ai + x0.y * k0; br = br + z0.x * k0; bi = bi + z0.y * k0;
-                    ar = ar + x0.z * k1; ai = ai + x0.w * k1; br = br + z0.z * k1; bi = bi + z0.w * k1;
-                    ar = ar + x1.x * k2; ai = ai + x1.y * k2; br = br + z1.x * k2; bi = bi + z1.y * k2;
-                    ar = ar + x1.z * k3; ai = ai + x1.w * k3; br = br + z1.z * k3; bi = bi + z1.w * k3;
-                    ar = ar + x2.x * k4; ai = ai + x2.y * k4; br = br + z2.x * k4; bi = bi + z2.y * k4;
-                    ar = ar + x2.z * k5; ai = ai + x2.w * k5; br = br + z2.z * k5; bi = bi + z2.w * k5;
-                    ar = ar + x3.x * k6; ai = ai + x3.y * k6; br = br + z3.x * k6; bi = bi + z3.y * k6;
-                    ar = ar + x3.z * k7; ai = ai + x3.w * k7; br = br + z3.z * k7; bi = bi + z3.w * k7;
-                }
+            for (int q = 0; q < OP; ++q) acc[q] = (f32x2){0.f, 0.f};
 #pragma unroll
-                for (int u = 0; u < (T2 % 8); u += 2) {
-                    const float4 x = p4[(t + u) >> 1], z = q4[(t + u) >> 1];
-                    ar = ar + x.x * a.taps2[t + u]; ai = ai + x.y * a.taps2[t + u]; br = br + z.x * a.taps2[t + u]; bi = bi + z.y * a.taps2[t + u];
-                    if (u + 1 < (T2 % 8)) {
-                        ar = ar + x.z * a.taps2[t + u + 1]; ai = ai + x.w * a.taps2[t + u + 1]; br = br + z.z * a.taps2[t + u + 1]; bi = bi + z.w * a.taps2[t + u + 1];
-                    }
-                }
-                auto emit = [&](uint32_t ol, float2 y) {
+            for (int j = 0; j < NWIN; ++j) win[j] = px[j];
+            constexpr int NB4 = T2 / 4;
+#pragma unroll 2
+            for (int b = 0; b < NB4; ++b) {
+                const f32x4 n0 = px[2 * b + NWIN], n1 = px[2 * b + NWIN + 1];   // (the last block reads a few slots past its taps: in bounds, unused)
+                const f32x4 kn = h2[b + 1];
+                __builtin_amdgcn_sched_barrier(0);                      // keep those reads up here: one wave has nobody else to hide their latency
+                tb_s2_tap<0, OP, D2, NWIN>(acc, win, kc.x);
+                tb_s2_tap<1, OP, D2, NWIN>(acc, win, kc.y);
+                tb_s2_tap<2, OP, D2, NWIN>(acc, win, kc.z);
+                tb_s2_tap<3, OP, D2, NWIN>(acc, win, kc.w);
+#pragma unroll
+                for (int j = 0; j + 2 < NWIN; ++j) win[j] = win[j + 2];
+                win[NWIN - 2] = n0; win[NWIN - 1] = n1;
+                kc = kn;
+            }
+            if constexpr (T2 % 4 >= 1) tb_s2_tap<0, OP, D2, NWIN>(acc, win, kc.x);   // the T2 % 4 taps left over
+            if constexpr (T2 % 4 >= 2) tb_s2_tap<1, OP, D2, NWIN>(acc, win, kc.y);
+            if constexpr (T2 % 4 >= 3) tb_s2_tap<2, OP, D2, NWIN>(acc, win, kc.z);
+#pragma unroll
+            for (int q = 0; q < OP; ++q) {
+                const uint32_t ol = OP * tid + q;
+                if (ol < po) {
                     const uint32_t oo = o0 + ol;
+                    const float2 y = make_float2(acc[q].x, acc[q].y);
                     if (keepf || npieces == 1) F[f_old + oo - fbase] = y;
                     cur[fhc + pb + oo] = y;                             // the decimated chunk stays readable (getters, the unfused path next call)
                     if (a.fft_in && oo < c.fft_take) a.fft_in[(size_t)s * kFftBins + c.fft_fill + oo] = y;   // Decoder.h:467-473
                     if (pb + oo < hn) head_out[pb + oo] = y;
-                };
-                emit(oa, make_float2(ar, ai));
-                if (has_b) emit(ob, make_float2(br, bi));
+                }
             }
         }
         // the last T2-1 samples of this image are the next piece's history
@@ -334,83 +418,113 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
 #pragma unroll
         for (int u = 0; u < HB; ++u) { const uint32_t k = tid + u * NT; if (k < (uint32_t)(T2 - 1)) X[k] = xt[u]; }
         fcount += po;
+        TSTAMP(3);
 
-        // low-pass + discriminator over the outputs that became computable, 2*NT per pass, two adjacent outputs per lane
-        if (run) {
+        // low-pass + discriminator over the outputs that became computable, every second piece: 8*NT outputs per pass, a lane owns two
+        // runs of four ADJACENT outputs (i0 + 4*lane .. and the same 4*NT further on).  Four adjacent outputs share their inputs, so a
+        // block of four taps costs two new 16-byte reads per run for 32 multiply-adds, and the lane's eight sums are independent
+        // chains.  The inner loop walks three blocks per trip so that the six pairs a run keeps rotate without a register move.
+        if (run && ((pc & 1u) || pc + 1 == npieces)) {
             const uint32_t i_hi = (pc + 1 == npieces) ? m : min(m, (pb + o0 + po) & ~1u);
-            for (uint32_t i0 = i_done; i0 < i_hi; i0 += 2 * NT) {
-                const uint32_t live = min((uint32_t)(2 * NT), i_hi - i0);
-                const bool active = 2u * tid < live;
-                float a0r = 0.f, a0i = 0.f, a1r = 0.f, a1i = 0.f;
-                if (active) {
-                    const float4* p = reinterpret_cast<const float4*>(F + (i0 - fbase)) + tid;
+            const f32x4* hk = reinterpret_cast<const f32x4*>(TP);
+            float2* Yl = Y;                                              // Yl[0]: predecessor of the pass's first output; Yl[1 + l], Yl[1 + NT + l]: lane l's last outputs
+            const uint32_t c0v = c0;                                     // (the symbol extractor's position c0 does not move inside the passes)
+            for (uint32_t i0 = i_done; i0 < i_hi; i0 += 8 * NT) {
+                const uint32_t live = min((uint32_t)(8 * NT), i_hi - i0);
+                const uint32_t nvA = 4u * tid < live ? min(4u, live - 4u * tid) : 0u;
+                const uint32_t nvB = 4u * NT + 4u * tid < live ? min(4u, live - 4u * NT - 4u * tid) : 0u;
+                f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
+                f32x2 b0 = {0.f, 0.f}, b1 = {0.f, 0.f}, b2 = {0.f, 0.f}, b3 = {0.f, 0.f};
+                {
+                    const f32x4* pA = reinterpret_cast<const f32x4*>(F + (i0 - fbase)) + 2 * tid;   // pair j: inputs i + 2j, i + 2j + 1
+                    const f32x4* pB = live > 4u * NT ? pA + 2 * NT : pA;                            // (a pass with one run only: the second computes along, unused)
+                    f32x4 A0 = pA[0], A1 = pA[1], A2 = pA[2], A3 = pA[3], A4, A5;
+                    f32x4 B0 = pB[0], B1 = pB[1], B2 = pB[2], B3 = pB[3], B4, B5;
+                    f32x4 kc = hk[0], k1, k2;
                     uint32_t t = 0;
-                    float4 Pq = p[0];
-                    if (T >= 8) {
-                        float4 N0 = p[1], N1 = p[2], N2 = p[3], N3 = p[4];
-                        float k0 = tp[0], k1 = tp[1], k2 = tp[2], k3 = tp[3], k4 = tp[4], k5 = tp[5], k6 = tp[6], k7 = tp[7];
-                        for (; t + 8 <= T; t += 8) {
-                            float4 M0 = N3, M1 = N3, M2 = N3, M3 = N3;
-                            float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, q4 = 0.f, q5 = 0.f, q6 = 0.f, q7 = 0.f;
-                            if (t + 16 <= T) {
-                                const float4* pn = p + (t >> 1) + 5;
-                                M0 = pn[0]; M1 = pn[1]; M2 = pn[2]; M3 = pn[3];
-                                const float* tn = tp + t + 8;
-                                q0 = tn[0]; q1 = tn[1]; q2 = tn[2]; q3 = tn[3]; q4 = tn[4]; q5 = tn[5]; q6 = tn[6]; q7 = tn[7];
-                            }
-                            HD_TB_PAIR(Pq, N0, k0, k1)
-                            HD_TB_PAIR(N0, N1, k2, k3)
-                            HD_TB_PAIR(N1, N2, k4, k5)
-                            HD_TB_PAIR(N2, N3, k6, k7)
-                            Pq = N3;
-                            N0 = M0; N1 = M1; N2 = M2; N3 = M3;
-                            k0 = q0; k1 = q1; k2 = q2; k3 = q3; k4 = q4; k5 = q5; k6 = q6; k7 = q7;
-                        }
+                    for (; t + 12 <= T; t += 12) {                      // (reads run up to ten pairs past t: in bounds, the windows are padded)
+                        const uint32_t j = t >> 1, jk = t >> 2;
+                        A4 = pA[j + 4]; A5 = pA[j + 5]; B4 = pB[j + 4]; B5 = pB[j + 5]; k1 = hk[jk + 1];
+                        __builtin_amdgcn_sched_barrier(0);              // the next block's reads stay up here, in flight during this block's math
+                        HD_TB_BLK(A0, A1, A2, A3, kc, a0, a1, a2, a3)
+                        HD_TB_BLK(B0, B1, B2, B3, kc, b0, b1, b2, b3)
+                        A0 = pA[j + 6]; A1 = pA[j + 7]; B0 = pB[j + 6]; B1 = pB[j + 7]; k2 = hk[jk + 2];
+                        __builtin_amdgcn_sched_barrier(0);
+                        HD_TB_BLK(A2, A3, A4, A5, k1, a0, a1, a2, a3)
+                        HD_TB_BLK(B2, B3, B4, B5, k1, b0, b1, b2, b3)
+                        A2 = pA[j + 8]; A3 = pA[j + 9]; B2 = pB[j + 8]; B3 = pB[j + 9]; kc = hk[jk + 3];
+                        __builtin_amdgcn_sched_barrier(0);
+                        HD_TB_BLK(A4, A5, A0, A1, k2, a0, a1, a2, a3)
+                        HD_TB_BLK(B4, B5, B0, B1, k2, b0, b1, b2, b3)
                     }
-                    for (; t + 2 <= T; t += 2) {
-                        const float4 N = p[(t >> 1) + 1];
-                        const float k0 = tp[t], k1 = tp[t + 1];
-                        HD_TB_PAIR(Pq, N, k0, k1)
-                        Pq = N;
+                    for (; t + 4 <= T; t += 4) {                        // at most two blocks left
+                        const uint32_t j = t >> 1;
+                        A4 = pA[j + 4]; A5 = pA[j + 5]; B4 = pB[j + 4]; B5 = pB[j + 5]; k1 = hk[(t >> 2) + 1];
+                        HD_TB_BLK(A0, A1, A2, A3, kc, a0, a1, a2, a3)
+                        HD_TB_BLK(B0, B1, B2, B3, kc, b0, b1, b2, b3)
+                        A0 = A2; A1 = A3; A2 = A4; A3 = A5; B0 = B2; B1 = B3; B2 = B4; B3 = B5; kc = k1;
                     }
-                    if (t < T) {
-                        const float k0 = tp[t];
-                        a0r = a0r + Pq.x * k0; a0i = a0i + Pq.y * k0;
-                        a1r = a1r + Pq.z * k0; a1i = a1i + Pq.w * k0;
-                    }
-                    reinterpret_cast<float4*>(Y)[1 + tid] = make_float4(a0r, a0i, a1r, a1i);
+                    if (t < T) { HD_TB_TAPN(A0.xy, A0.zw, A1.xy, A1.zw, kc.x, a0, a1, a2, a3) HD_TB_TAPN(B0.xy, B0.zw, B1.xy, B1.zw, kc.x, b0, b1, b2, b3) ++t; }
+                    if (t < T) { HD_TB_TAPN(A0.zw, A1.xy, A1.zw, A2.xy, kc.y, a0, a1, a2, a3) HD_TB_TAPN(B0.zw, B1.xy, B1.zw, B2.xy, kc.y, b0, b1, b2, b3) ++t; }
+                    if (t < T) { HD_TB_TAPN(A1.xy, A1.zw, A2.xy, A2.zw, kc.z, a0, a1, a2, a3) HD_TB_TAPN(B1.xy, B1.zw, B2.xy, B2.zw, kc.z, b0, b1, b2, b3) ++t; }
+                    const f32x2 lastA = nvA == 4 ? a3 : nvA == 3 ? a2 : nvA == 2 ? a1 : a0;
+                    const f32x2 lastB = nvB == 4 ? b3 : nvB == 3 ? b2 : nvB == 2 ? b1 : b0;
+                    Yl[1 + tid] = make_float2(lastA.x, lastA.y);
+                    Yl[1 + NT + tid] = make_float2(lastB.x, lastB.y);
                 }
+                TSTAMP(12);
                 tb_sync<NT>();
-                if (active) {
-                    const uint32_t i = i0 + 2 * tid;
-                    float pr, pi;
-                    const float2 qv = Y[2 * tid + 1];
-                    if (i == 0 && !kin.primed) { pr = a0r; pi = a0i; }   // very first sample: arg(y0*conj(y0)) (FSK2_Demod.h:35)
-                    else { pr = qv.x; pi = qv.y; }
-                    const bool two = 2u * tid + 1 < live;
-                    const float d0 = discriminate(a0r, a0i, pr, pi);
-                    const float d1 = two ? discriminate(a1r, a1i, a0r, a0i) : 0.f;
-                    float* dm = a.demod + (size_t)s * a.demod_stride + i;
-                    if (two) *reinterpret_cast<float2*>(dm) = make_float2(d0, d1); else dm[0] = d0;
-                    const uint32_t pos = end_old + i;                   // SymbolExtractor::pushSamples: append to the backlog ring
-                    vring[pos & rmask] = d0;
-                    if (two) vring[(pos + 1) & rmask] = d1;
-                    if (do_sums) { V[pos - c0] = d0; if (two) V[pos + 1 - c0] = d1; }
-                    if (a.filtered) {
-                        a.filtered[(size_t)s * a.demod_stride + i] = make_float2(a0r, a0i);
-                        if (two) a.filtered[(size_t)s * a.demod_stride + i + 1] = make_float2(a1r, a1i);
-                    }
-                    const uint32_t last = m - 1;
-                    if (i == last || (two && i + 1 == last)) {
-                        DemodCarry k; k.primed = 1; k._pad = 0;
-                        if (i == last) { k.re = a0r; k.im = a0i; } else { k.re = a1r; k.im = a1i; }
-                        a.carry_out[s] = k;
+                {
+                    // discriminator, run by run (one copy of the code): d[i] = arg(y[i] * conj(y[i-1]))
+                    f32x2 c0 = a0, c1 = a1, c2 = a2, c3 = a3;
+                    uint32_t nv = nvA, i = i0 + 4 * tid;
+                    float2 qv = Yl[tid];
+#pragma unroll 1
+                    for (int w = 0; w < 2; ++w) {
+                        if (nv) {
+                            float pr = qv.x, pi = qv.y;
+                            if (i == 0 && !kin.primed) { pr = c0.x; pi = c0.y; }   // very first sample: arg(y0*conj(y0)) (FSK2_Demod.h:35)
+                            float d[4];
+#if defined(HD_TB_EXP) && (HD_TB_EXP & 4)
+                            d[0] = c0.x * pr; d[1] = c1.x * pi; d[2] = c2.x; d[3] = c3.y;
+#else
+                            d[0] = discriminate(c0.x, c0.y, pr, pi);
+                            d[1] = discriminate(c1.x, c1.y, c0.x, c0.y);
+                            d[2] = discriminate(c2.x, c2.y, c1.x, c1.y);
+                            d[3] = discriminate(c3.x, c3.y, c2.x, c2.y);
+#endif
+                            const f32x2 av[4] = {c0, c1, c2, c3};
+                            float* dm = a.demod + (size_t)s * a.demod_stride + i;   // i and demod_stride are even
+                            if (nv >= 2) *reinterpret_cast<float2*>(dm) = make_float2(d[0], d[1]); else dm[0] = d[0];
+                            if (nv == 4) *reinterpret_cast<float2*>(dm + 2) = make_float2(d[2], d[3]); else if (nv == 3) dm[2] = d[2];
+                            const uint32_t pos = end_old + i;           // SymbolExtractor::pushSamples: append to the backlog ring
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                if ((uint32_t)u < nv) {
+                                    vring[(pos + u) & rmask] = d[u];
+                                    if (do_sums) V[pos + u - c0v] = d[u];
+                                    if (a.filtered) a.filtered[(size_t)s * a.demod_stride + i + u] = make_float2(av[u].x, av[u].y);
+                                }
+                            }
+                            if (i + nv == m) {                          // the lane that owns the run's last output
+                                DemodCarry k; k.primed = 1; k._pad = 0;
+                                const f32x2 lastv = nv == 4 ? c3 : nv == 3 ? c2 : nv == 2 ? c1 : c0;
+                                k.re = lastv.x; k.im = lastv.y;
+                                a.carry_out[s] = k;
+                            }
+                        }
+                        c0 = b0; c1 = b1; c2 = b2; c3 = b3; nv = nvB; i = i0 + 4 * NT + 4 * tid; qv = Yl[NT + tid];
                     }
                 }
-                tb_sync<NT>();                                          // Y is read above; its carry slot and the next pass rewrite it
-                if (active && (2u * tid + 2 >= live)) Y[1] = (2u * tid + 1 < live) ? make_float2(a1r, a1i) : make_float2(a0r, a0i);
+                TSTAMP(14);
+                tb_sync<NT>();                                          // Yl is read above; its carry slot and the next pass rewrite it
+                {   // the pass's last output becomes the next pass's predecessor
+                    const uint32_t lo = live - 1, lw = lo / (4u * NT), ll = (lo % (4u * NT)) >> 2;
+                    if (tid == ll) Yl[0] = Yl[1 + lw * NT + tid];
+                }
             }
             i_done = i_hi;
+            TSTAMP(4);
             {   // slide the low-pass window: what is still needed starts at input index i_done
                 const uint32_t shf = i_done - fbase, keep = fcount - shf;
                 if (shf) {
@@ -426,12 +540,10 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
                     fbase = i_done; fcount = keep;
                 }
             }
-            if (do_sums) {
-                vcnt = end_old + i_done - c0;
-                tb_sync<NT>();
-                sym_feed();
-            }
+            TSTAMP(5);
+            if (do_sums) vcnt = end_old + i_done - c0;
         }
+        ++pc;
     }
     tb_sync<NT>();
 
@@ -454,6 +566,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         if (tid == 0) head_n_out[0] = hk;
     }
     if (!run && tid == 0) a.carry_out[s] = kin;
+    TSTAMP(7);
 
     // ---- symbol extractor, second half: edge search, run means, bits (SymbolExtractor.h:129-158)
     uint32_t* outw = slot + sizeof(BitsHeader) / 4;
@@ -488,6 +601,11 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     __threadfence_block();
     tb_sync<NT>();
     const uint32_t wc_n = limit <= a.wc_cap ? limit : 0u;               // window sums of the searchable backlog, when they fit
+    // The run sums below add up the backlog samples [carried_to, frontier) (frontier <= limit), in pieces: they are fetched here, with
+    // the other reads of this phase, instead of one round trip per run later.
+    const uint32_t carried_to = st.run_pos - st.base;
+    float* vc = reinterpret_cast<float*>(lds + a.vc_off);              // vc[k] = backlog sample carried_to + k
+    const uint32_t vc_n = (limit > carried_to && limit - carried_to <= a.vc_cap) ? limit - carried_to : 0u;
     {
         const uint32_t wr0 = (st.base + R) & ~63u;
         const uint32_t nw = ((st.base + limit) - wr0 + 63u) >> 6;
@@ -507,8 +625,17 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
             for (int u = 0; u < MB; ++u) { const uint32_t i = i0 + tid + u * NT; if (i < nw) lmask[((wr0 + 64u * i) & rmask) >> 6] = tm[u]; }
         }
         for (uint32_t k = tid + CB * NT; k < wc_n; k += NT) wc[k] = gw[(st.base + k) & rmask];
+#pragma unroll 1
+        for (uint32_t k0 = 0; k0 < vc_n; k0 += 8 * NT) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const uint32_t k = k0 + tid + u * NT; t[u] = k < vc_n ? vring[(st.base + carried_to + k) & rmask] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const uint32_t k = k0 + tid + u * NT; if (k < vc_n) vc[k] = t[u]; }
+        }
     }
     tb_sync<NT>();
+    TSTAMP(8);
     auto wsum = [&](uint32_t i) -> float { return i < wc_n ? wc[i] : gw[(st.base + i) & rmask]; };
     if (wave == 0) {
         uint32_t pos = R, nfl = 0, overflow = 0;
@@ -548,6 +675,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     }
     tb_sync<NT>();
     const uint32_t nfl = sh[0];
+    TSTAMP(9);
 
     // per-run sums in element order (std::accumulate); the run in progress is carried across calls (SymState::run_sum covers
     // [base, run_pos)) up to the search frontier -- the same left-to-right chain of adds the reference performs in one go
@@ -555,6 +683,32 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     constexpr int NX = kTailStrip / 64;
     auto chain = [&](float acc, uint32_t a0, uint32_t b) -> float {     // acc + v[a0] + ... + v[b-1] (backlog indices)
         if (a0 >= b) return acc;
+        if (a0 >= carried_to && b - carried_to <= vc_n) {               // the samples are in LDS already (wave-uniform addresses: broadcast reads)
+            const float* v0 = vc + (a0 - carried_to);
+            uint32_t n = b - a0, i = 0;
+            for (; i < n && ((a0 - carried_to + i) & 3u); ++i) acc = acc + v0[i];
+            const float4* v4 = reinterpret_cast<const float4*>(v0 + i);
+            float4 cc[4];
+            uint32_t nq = (n - i) >> 2, q = 0;
+            if (nq >= 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) cc[u] = v4[u];
+                for (; q + 8 <= nq; q += 4) {
+                    float4 nn[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) nn[u] = v4[q + 4 + u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { acc = acc + cc[u].x; acc = acc + cc[u].y; acc = acc + cc[u].z; acc = acc + cc[u].w; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) cc[u] = nn[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { acc = acc + cc[u].x; acc = acc + cc[u].y; acc = acc + cc[u].z; acc = acc + cc[u].w; }
+                q += 4;
+            }
+            for (i += 4 * q; i < n; ++i) acc = acc + v0[i];
+            return acc;
+        }
         float nx[NX];
 #pragma unroll
         for (int j = 0; j < NX; ++j) { const uint32_t k = a0 + 64 * j + lane; nx[j] = k < b ? vring[(st.base + k) & rmask] : 0.0f; }
@@ -591,23 +745,26 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         }
         return acc;
     };
-    const uint32_t carried_to = st.run_pos - st.base;
-    for (uint32_t r = wave; r < nfl; r += NW) {
-        const uint32_t ra = r ? flips[r - 1] : 0u, rb = flips[r];
-        const float acc = r ? chain(0.0f, ra, rb) : chain(st.run_sum, min(carried_to, rb), rb);
+    const uint32_t frontier = sh[2];
+    for (uint32_t r = wave; r <= nfl; r += NW) {                        // runs dealt to the waves; task nfl is the carry for the next call
+        const bool tail_task = r == nfl;
+        const uint32_t ra = r ? flips[r - 1] : 0u;
+        uint32_t from, to;
+        float acc0 = 0.0f;
+        if (!tail_task) { to = flips[r]; from = r ? ra : min(carried_to, to); if (!r) acc0 = st.run_sum; }
+        else { from = nfl ? ra : carried_to; to = max(from, frontier); if (!nfl) acc0 = st.run_sum; }
+        const float acc = chain(acc0, from, to);
         if (lane == 0) {
-            const float mean = acc / (float)(rb - ra);
-            const uint32_t cnt = (uint32_t)roundf((float)(rb - ra) / (float)q.spb);
-            runinfo[r] = (cnt << 1) | (mean > 0.0f ? 1u : 0u);
+            if (tail_task) sh[3] = __builtin_bit_cast(uint32_t, acc);
+            else {
+                const float mean = acc / (float)(to - ra);
+                const uint32_t cnt = (uint32_t)roundf((float)(to - ra) / (float)q.spb);
+                runinfo[r] = (cnt << 1) | (mean > 0.0f ? 1u : 0u);
+            }
         }
     }
-    const uint32_t frontier = sh[2];
-    if (wave == (nfl % NW)) {
-        const uint32_t ra = nfl ? flips[nfl - 1] : carried_to;
-        const float acc = chain(nfl ? 0.0f : st.run_sum, ra, max(ra, frontier));
-        if (lane == 0) sh[3] = __builtin_bit_cast(uint32_t, acc);
-    }
     tb_sync<NT>();
+    TSTAMP(10);
     if (tid == 0) {
         uint32_t nbits = 0, curw = 0, overflow = sh[1];
         for (uint32_t r = 0; r < nfl; ++r) {
@@ -631,6 +788,8 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         a.sym[s] = st;
         hdr->nbits = nbits; hdr->held_after = st.held; hdr->nflips = nfl; hdr->overflow = overflow; hdr->uncached = end - st.cached;
     }
+    TSTAMP(11);
+    TSTAMP_WRITE();
 }
 
 }  // namespace hd

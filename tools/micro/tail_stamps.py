@@ -1,0 +1,23 @@
+"""Phase clocks of the stream tail (diagnostic build: HD_EXTRA_FLAGS=-DHD_STAMP_TAIL python -m habdec_amd.build --force)."""
+import sys, ctypes, numpy as np
+sys.path.insert(0, '/root/repo')
+import torch, bench, habdec_amd
+w = dict(bench.WORKLOADS["cfg4"]); S = 1024; C = w["C"]
+dev = torch.device("cuda", 0)
+ring, rc, _ = bench.generate_ring(torch, dev, w, S, 0, 1234)
+eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"])
+L = habdec_amd.lib(); f = L.hd_debug_tail_stamps; f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+acc = np.zeros(20); mx = np.zeros(20); n = 0; spans = []
+for i in range(40):
+    eng.process_device(ring.data_ptr() + (i % rc) * S * C * 8, C, C)
+    if i >= 10:
+        st = np.zeros(S * 24, np.uint64); f(st.ctypes.data, S * 24); st = st.reshape(S, 24).astype(np.int64)
+        d = st[:, :20].astype(np.float64)
+        acc += d.mean(axis=0); mx = np.maximum(mx, d.max(axis=0)); n += 1
+        spans.append([np.percentile((st[:, 21] - st[:, 20]) * 10.0, q) for q in (50, 90, 100)])   # 100 MHz realtime ticks -> ns
+names = ["initial loads", "backlog window sums", "piece: X to LDS", "piece: stage 2", "piece: low-pass+discriminator", "piece: F slide", "piece: window sums",
+         "carries+slide", "search loads", "edge search", "run sums", "bits+state",
+         "  lp: tap loop", "  lp: exchange+discriminator", "  lp: stores", "  ws: sums", "  ws: flags+mask", "  ws: slide", "-", "-"]
+for k, a_, m_ in zip(names, acc / n, mx):
+    print(f"{k:32s} mean {a_:9.0f} cycles   max {m_:9.0f}")
+print("total cycles mean", (acc / n).sum().round(0), " per-stream wall ns p50/p90/max:", np.mean(spans, axis=0).round(0).tolist())
