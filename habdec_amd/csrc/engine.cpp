@@ -814,7 +814,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         hd_engine::PendingTail prev = e->pend;
         hd_engine::CallSlot* ps = prev.valid ? &e->slot[prev.slot] : nullptr;
         if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
-        const uint32_t wgs = e->step_wgs ? e->step_wgs : 8u * e->n_cus;
+        const uint32_t wgs = e->step_wgs ? e->step_wgs : 32u * e->n_cus;   // short runs of tiles: the dispatcher evens out the tail of the launch
         if (!hd::launch_step(qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, max_n1, iq, stride, e->hist1[hin].p,
                              e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, wgs, prev.ta, prev.valid ? S : 0u))
             return fail(HD_ERR_INVALID, "no step kernel for this decimation plan");

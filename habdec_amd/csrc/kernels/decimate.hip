@@ -381,6 +381,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     constexpr int kF4 = dec_tile_f4<D, T, 64>() > (int)(kStepLdsBytes / 16) ? dec_tile_f4<D, T, 64>() : (int)(kStepLdsBytes / 16);
     __shared__ float4 tile4[kF4];
     if (blockIdx.x < n_tail) {
+        // the tails are latency chains with nobody to hide behind; the stage-1 waves beside them are waiting for HBM most of the
+        // time and lose nothing when the arbiter prefers the tail
+        __builtin_amdgcn_s_setprio(3);
         tail_body<64, 4, D2, T2>(ta, blockIdx.x, reinterpret_cast<unsigned char*>(tile4));
         return;
     }

@@ -262,6 +262,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
             float wp[KP];
             if (any) {
                 window_sums8(V + off + KP * tid, R, wp);
+                TSTAMP(19);
 #pragma unroll
                 for (int j = 0; j < (int)KP; ++j) WS[off + R + KP * tid + j] = wp[j];
                 float* gdst = gw + ((c0 + KP * tid) & rmask);           // c0 + KP*tid .. +7: contiguous unless the ring wraps inside
@@ -388,16 +389,47 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
             if constexpr (T2 % 4 >= 1) tb_s2_tap<0, OP, D2, NWIN>(acc, win, kc.x);   // the T2 % 4 taps left over
             if constexpr (T2 % 4 >= 2) tb_s2_tap<1, OP, D2, NWIN>(acc, win, kc.y);
             if constexpr (T2 % 4 >= 3) tb_s2_tap<2, OP, D2, NWIN>(acc, win, kc.z);
+            TSTAMP(18);
+            const bool keepF = keepf || npieces == 1;
+            bool done4 = false;
+            if constexpr (OP == 4) {
+                // four adjacent outputs per lane: 16-byte stores whenever all four exist and the destinations are 16-byte aligned
+                // (a global store instruction costs the lone wave a couple of hundred cycles: four times fewer of them)
+                const uint32_t oo = o0 + 4 * tid;
+                if (4 * tid + 3 < po && !(pb & 1u)) {
+                    const float4 y01 = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y), y23 = make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y);
+                    if (keepF) { float4* f4 = reinterpret_cast<float4*>(F + (f_old + oo - fbase)); f4[0] = y01; f4[1] = y23; }
+                    { float4* c4 = reinterpret_cast<float4*>(cur + fhc + pb + oo); c4[0] = y01; c4[1] = y23; }   // the decimated chunk stays readable (getters, the unfused path next call)
+                    if (a.fft_in && oo < c.fft_take) {                  // Decoder.h:467-473
+                        float2* fi = a.fft_in + (size_t)s * kFftBins + c.fft_fill + oo;
+                        if (oo + 3 < c.fft_take && !(c.fft_fill & 1u)) { reinterpret_cast<float4*>(fi)[0] = y01; reinterpret_cast<float4*>(fi)[1] = y23; }
+                        else {
 #pragma unroll
-            for (int q = 0; q < OP; ++q) {
-                const uint32_t ol = OP * tid + q;
-                if (ol < po) {
-                    const uint32_t oo = o0 + ol;
-                    const float2 y = make_float2(acc[q].x, acc[q].y);
-                    if (keepf || npieces == 1) F[f_old + oo - fbase] = y;
-                    cur[fhc + pb + oo] = y;                             // the decimated chunk stays readable (getters, the unfused path next call)
-                    if (a.fft_in && oo < c.fft_take) a.fft_in[(size_t)s * kFftBins + c.fft_fill + oo] = y;   // Decoder.h:467-473
-                    if (pb + oo < hn) head_out[pb + oo] = y;
+                            for (int q = 0; q < 4; ++q) if (oo + q < c.fft_take) fi[q] = make_float2(acc[q].x, acc[q].y);
+                        }
+                    }
+                    if (pb + oo < hn) {
+                        if (pb + oo + 3 < hn) { float4* h4 = reinterpret_cast<float4*>(head_out + pb + oo); h4[0] = y01; h4[1] = y23; }
+                        else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) if (pb + oo + q < hn) head_out[pb + oo + q] = make_float2(acc[q].x, acc[q].y);
+                        }
+                    }
+                    done4 = true;
+                }
+            }
+            if (!done4) {
+#pragma unroll
+                for (int q = 0; q < OP; ++q) {
+                    const uint32_t ol = OP * tid + q;
+                    if (ol < po) {
+                        const uint32_t oo = o0 + ol;
+                        const float2 y = make_float2(acc[q].x, acc[q].y);
+                        if (keepF) F[f_old + oo - fbase] = y;
+                        cur[fhc + pb + oo] = y;
+                        if (a.fft_in && oo < c.fft_take) a.fft_in[(size_t)s * kFftBins + c.fft_fill + oo] = y;
+                        if (pb + oo < hn) head_out[pb + oo] = y;
+                    }
                 }
             }
         }
@@ -495,16 +527,28 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
 #endif
                             const f32x2 av[4] = {c0, c1, c2, c3};
                             float* dm = a.demod + (size_t)s * a.demod_stride + i;   // i and demod_stride are even
-                            if (nv >= 2) *reinterpret_cast<float2*>(dm) = make_float2(d[0], d[1]); else dm[0] = d[0];
-                            if (nv == 4) *reinterpret_cast<float2*>(dm + 2) = make_float2(d[2], d[3]); else if (nv == 3) dm[2] = d[2];
                             const uint32_t pos = end_old + i;           // SymbolExtractor::pushSamples: append to the backlog ring
+                            const float4 d4 = make_float4(d[0], d[1], d[2], d[3]);
+                            if (nv == 4 && !(i & 3u)) *reinterpret_cast<float4*>(dm) = d4;
+                            else {
+                                if (nv >= 2) *reinterpret_cast<float2*>(dm) = make_float2(d[0], d[1]); else dm[0] = d[0];
+                                if (nv == 4) *reinterpret_cast<float2*>(dm + 2) = make_float2(d[2], d[3]); else if (nv == 3) dm[2] = d[2];
+                            }
+                            if (nv == 4 && !(pos & 3u)) *reinterpret_cast<float4*>(vring + (pos & rmask)) = d4;   // (an aligned quad never straddles the ring's end)
+                            else {
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                if ((uint32_t)u < nv) {
-                                    vring[(pos + u) & rmask] = d[u];
-                                    if (do_sums) V[pos + u - c0v] = d[u];
-                                    if (a.filtered) a.filtered[(size_t)s * a.demod_stride + i + u] = make_float2(av[u].x, av[u].y);
+                                for (int u = 0; u < 4; ++u) if ((uint32_t)u < nv) vring[(pos + u) & rmask] = d[u];
+                            }
+                            if (do_sums) {
+                                if (nv == 4 && !((pos - c0v) & 3u)) *reinterpret_cast<float4*>(V + (pos - c0v)) = d4;
+                                else {
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) if ((uint32_t)u < nv) V[pos + u - c0v] = d[u];
                                 }
+                            }
+                            if (a.filtered) {
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) if ((uint32_t)u < nv) a.filtered[(size_t)s * a.demod_stride + i + u] = make_float2(av[u].x, av[u].y);
                             }
                             if (i + nv == m) {                          // the lane that owns the run's last output
                                 DemodCarry k; k.primed = 1; k._pad = 0;
@@ -547,6 +591,33 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     }
     tb_sync<NT>();
 
+    // ---- The second half of the symbol extractor (edge search, run means) reads back what this call and earlier ones left in the global
+    // rings: flag mask, window sums, samples.  Those reads are issued HERE, into registers, so that their round trip runs under the
+    // carry / slide stores below; they land in LDS (over the stream windows, which are dead by then) afterwards.
+    const uint32_t h = st.held;
+    const uint32_t end = st.base + h;
+    const uint32_t pend = end - R + 1;
+    const bool hunt = m && do_sums && search;
+    const uint32_t limit = hunt ? h - q.spb : 0u;                      // backlog indices searched: [R, limit)
+    const uint32_t carried_to = st.run_pos - st.base;
+    const uint32_t wc_n = (hunt && limit <= a.wc_cap) ? limit : 0u;    // window sums of the searchable backlog, when they fit
+    // the run sums add up the backlog samples [carried_to, frontier) (frontier <= limit), in pieces
+    const uint32_t vc_n = (hunt && limit > carried_to && limit - carried_to <= a.vc_cap) ? limit - carried_to : 0u;
+    const uint32_t wr0 = (st.base + R) & ~63u;
+    const uint32_t nw = hunt ? ((st.base + limit) - wr0 + 63u) >> 6 : 0u;
+    constexpr int MB = 512 / NT, CB = 1024 / NT, SB = 1024 / NT;
+    unsigned long long tm0[MB];
+    float tc0[CB], ts0[SB];
+    if (hunt) {
+        __threadfence_block();                                          // this call's own ring stores first
+#pragma unroll
+        for (int u = 0; u < MB; ++u) { const uint32_t i = tid + u * NT; tm0[u] = i < nw ? gmask[((wr0 + 64u * i) & rmask) >> 6] : 0ull; }
+#pragma unroll
+        for (int u = 0; u < CB; ++u) { const uint32_t k = tid + u * NT; tc0[u] = k < wc_n ? gw[(st.base + k) & rmask] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) { const uint32_t k = tid + u * NT; ts0[u] = k < vc_n ? vring[(st.base + carried_to + k) & rmask] : 0.f; }
+    }
+
     // ---- what the next call finds: stage-2 history of an idle stream, [history | leftover pending] at the front of the other
     // low-pass buffer, the head of this run's input (FirHistory), the discriminator carry
     if (!n1) for (uint32_t k = tid; k < (uint32_t)(T2 - 1); k += NT) a.hist2_out[(size_t)s * (T2 - 1) + k] = a.hist2_in[(size_t)s * (T2 - 1) + k];
@@ -575,9 +646,6 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         if (tid == 0) { hdr->nbits = 0; hdr->held_after = old.held; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = old.base + old.held - old.cached; }
         return;
     }
-    const uint32_t h = st.held;
-    const uint32_t end = st.base + h;
-    const uint32_t pend = end - R + 1;
     if (!do_sums) {
         if (tid == 0) { a.sym[s] = st; hdr->nbits = 0; hdr->held_after = h; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = st.base + h - st.cached; }
         return;
@@ -590,49 +658,25 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         }
         return;
     }
-    const uint32_t limit = h - q.spb;                                   // backlog indices searched: [R, limit)
     unsigned long long* lmask = reinterpret_cast<unsigned long long*>(lds + a.lmask_off);
     uint32_t* flips = reinterpret_cast<uint32_t*>(lds + a.flips_off);
     uint32_t* runinfo = flips + a.fl_cap;
     float* strips = reinterpret_cast<float*>(lds + a.strips_off);
     float* wc = reinterpret_cast<float*>(lds + a.wc_off);
-    const uint32_t fl_cap = a.fl_cap;
-    // this call's window sums, flags and samples were written to the global rings above; what follows reads them back
-    __threadfence_block();
-    tb_sync<NT>();
-    const uint32_t wc_n = limit <= a.wc_cap ? limit : 0u;               // window sums of the searchable backlog, when they fit
-    // The run sums below add up the backlog samples [carried_to, frontier) (frontier <= limit), in pieces: they are fetched here, with
-    // the other reads of this phase, instead of one round trip per run later.
-    const uint32_t carried_to = st.run_pos - st.base;
     float* vc = reinterpret_cast<float*>(lds + a.vc_off);              // vc[k] = backlog sample carried_to + k
-    const uint32_t vc_n = (limit > carried_to && limit - carried_to <= a.vc_cap) ? limit - carried_to : 0u;
+    const uint32_t fl_cap = a.fl_cap;
+    tb_sync<NT>();                                                      // the slide above read the stream windows these images overwrite
     {
-        const uint32_t wr0 = (st.base + R) & ~63u;
-        const uint32_t nw = ((st.base + limit) - wr0 + 63u) >> 6;
-        constexpr int MB = 512 / NT, CB = 1024 / NT;
-        for (uint32_t i0 = 0; i0 < nw; i0 += MB * NT) {
-            unsigned long long tm[MB];
 #pragma unroll
-            for (int u = 0; u < MB; ++u) { const uint32_t i = i0 + tid + u * NT; tm[u] = i < nw ? gmask[((wr0 + 64u * i) & rmask) >> 6] : 0ull; }
-            if (i0 == 0) {
-                float t[CB];
+        for (int u = 0; u < MB; ++u) { const uint32_t i = tid + u * NT; if (i < nw) lmask[((wr0 + 64u * i) & rmask) >> 6] = tm0[u]; }
 #pragma unroll
-                for (int u = 0; u < CB; ++u) { const uint32_t k = tid + u * NT; t[u] = k < wc_n ? gw[(st.base + k) & rmask] : 0.f; }
+        for (int u = 0; u < CB; ++u) { const uint32_t k = tid + u * NT; if (k < wc_n) wc[k] = tc0[u]; }
 #pragma unroll
-                for (int u = 0; u < CB; ++u) { const uint32_t k = tid + u * NT; if (k < wc_n) wc[k] = t[u]; }
-            }
-#pragma unroll
-            for (int u = 0; u < MB; ++u) { const uint32_t i = i0 + tid + u * NT; if (i < nw) lmask[((wr0 + 64u * i) & rmask) >> 6] = tm[u]; }
-        }
+        for (int u = 0; u < SB; ++u) { const uint32_t k = tid + u * NT; if (k < vc_n) vc[k] = ts0[u]; }
+        // longer backlogs than the first batches cover (idle or freshly re-parameterised streams): plain loops
+        for (uint32_t i = tid + MB * NT; i < nw; i += NT) { const uint32_t wi = ((wr0 + 64u * i) & rmask) >> 6; lmask[wi] = gmask[wi]; }
         for (uint32_t k = tid + CB * NT; k < wc_n; k += NT) wc[k] = gw[(st.base + k) & rmask];
-#pragma unroll 1
-        for (uint32_t k0 = 0; k0 < vc_n; k0 += 8 * NT) {
-            float t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const uint32_t k = k0 + tid + u * NT; t[u] = k < vc_n ? vring[(st.base + carried_to + k) & rmask] : 0.f; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const uint32_t k = k0 + tid + u * NT; if (k < vc_n) vc[k] = t[u]; }
-        }
+        for (uint32_t k = tid + SB * NT; k < vc_n; k += NT) vc[k] = vring[(st.base + carried_to + k) & rmask];
     }
     tb_sync<NT>();
     TSTAMP(8);
@@ -688,24 +732,24 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
             uint32_t n = b - a0, i = 0;
             for (; i < n && ((a0 - carried_to + i) & 3u); ++i) acc = acc + v0[i];
             const float4* v4 = reinterpret_cast<const float4*>(v0 + i);
-            float4 cc[4];
-            uint32_t nq = (n - i) >> 2, q = 0;
+            const uint32_t nq = (n - i) >> 2;
+            uint32_t q = 0;
+#define HD_TB_ADD4(c_) { acc = acc + (c_).x; acc = acc + (c_).y; acc = acc + (c_).z; acc = acc + (c_).w; }
             if (nq >= 4) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) cc[u] = v4[u];
-                for (; q + 8 <= nq; q += 4) {
-                    float4 nn[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) nn[u] = v4[q + 4 + u];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { acc = acc + cc[u].x; acc = acc + cc[u].y; acc = acc + cc[u].z; acc = acc + cc[u].w; }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) cc[u] = nn[u];
+                float4 c0_ = v4[0], c1_ = v4[1], c2_ = v4[2], c3_ = v4[3], d0_, d1_, d2_, d3_;
+                for (; q + 12 <= nq; q += 8) {                          // two blocks of 16 samples per trip: each block's reads fly under the other's adds
+                    d0_ = v4[q + 4]; d1_ = v4[q + 5]; d2_ = v4[q + 6]; d3_ = v4[q + 7];
+                    __builtin_amdgcn_sched_barrier(0);
+                    HD_TB_ADD4(c0_) HD_TB_ADD4(c1_) HD_TB_ADD4(c2_) HD_TB_ADD4(c3_)
+                    c0_ = v4[q + 8]; c1_ = v4[q + 9]; c2_ = v4[q + 10]; c3_ = v4[q + 11];
+                    __builtin_amdgcn_sched_barrier(0);
+                    HD_TB_ADD4(d0_) HD_TB_ADD4(d1_) HD_TB_ADD4(d2_) HD_TB_ADD4(d3_)
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { acc = acc + cc[u].x; acc = acc + cc[u].y; acc = acc + cc[u].z; acc = acc + cc[u].w; }
+                HD_TB_ADD4(c0_) HD_TB_ADD4(c1_) HD_TB_ADD4(c2_) HD_TB_ADD4(c3_)
                 q += 4;
             }
+            for (; q < nq; ++q) { const float4 c_ = v4[q]; HD_TB_ADD4(c_) }
+#undef HD_TB_ADD4
             for (i += 4 * q; i < n; ++i) acc = acc + v0[i];
             return acc;
         }

@@ -17,7 +17,7 @@ for i in range(40):
         spans.append([np.percentile((st[:, 21] - st[:, 20]) * 10.0, q) for q in (50, 90, 100)])   # 100 MHz realtime ticks -> ns
 names = ["initial loads", "backlog window sums", "piece: X to LDS", "piece: stage 2", "piece: low-pass+discriminator", "piece: F slide", "piece: window sums",
          "carries+slide", "search loads", "edge search", "run sums", "bits+state",
-         "  lp: tap loop", "  lp: exchange+discriminator", "  lp: stores", "  ws: sums", "  ws: flags+mask", "  ws: slide", "-", "-"]
+         "  lp: tap loop", "  lp: exchange+discriminator", "  lp: stores", "  ws: sums", "  ws: flags+mask", "  ws: slide", "  stage 2: tap loop only", "  ws: window_sums8 only"]
 for k, a_, m_ in zip(names, acc / n, mx):
     print(f"{k:32s} mean {a_:9.0f} cycles   max {m_:9.0f}")
 print("total cycles mean", (acc / n).sum().round(0), " per-stream wall ns p50/p90/max:", np.mean(spans, axis=0).round(0).tolist())
