@@ -17,10 +17,12 @@ AFC every call ("cfg4" in SURVEY.md's 1-based numbering) -- the batched 2.048 MS
 1/2/4/8 GPUs, sharded 1024 streams per GPU (weak scaling).  Each stream carries its own CRC-valid telemetry
 sentence in a seamless ring of HBM-resident chunks; the line reports how many sentences were decoded.
 
-Output: ONE JSON line on rank 0 (contract in the round prompt) with `roofline` for the dominant kernel (the
-first-stage decimator, the only kernel that touches full-rate IQ; its duration is measured with HIP events on the
-engine's own stream) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample of the
-same streams, whose decoded sentences are also compared with the GPU's).
+Output: ONE JSON line on rank 0 (contract in the round prompt) with `roofline` for the dominant kernel -- in batch mode
+the step kernel (this call's first decimation stage, the only code that touches full-rate IQ, with the previous call's
+stream tails riding in the same launch); its duration is measured with HIP events on the engine's own stream -- and
+`cpu_baseline` (the CPU oracle timed on ALL of this box's host cores on a bounded sample of the same streams, whose
+characters, bit counts and sentences are also compared with the GPU's).  `also` carries BASELINE configs[2] (/4, the
+VALU-bound single-GPU configuration) measured in the same run.
 """
 from __future__ import annotations
 
@@ -40,6 +42,7 @@ if str(ROOT) not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
 HBM_COPY_GBS = 6290.0          # measured float4 copy on gfx950 (same table)
+VALU_NONFMA_TFLOPS = 78.6      # FP32 vector peak with separately rounded multiply and add (157.3 TF with FMA)
 
 WORKLOADS = {
     # name: fs, decimation, baud, bits, stops, streams/GPU, chunk, lowpass_bw, lowpass_trans, ungated, carrier offsets
@@ -59,6 +62,17 @@ WORKLOADS = {
 def bytes_per_sample(D: int) -> float:
     """Algorithmic HBM bytes per input sample of the whole chain: 8 + 12/D."""
     return 8.0 + 12.0 / D
+
+
+def flops_per_sample(w) -> float:
+    """Multiply-add flops of the FIR chain per input sample (complex x real MAC = 4 flop), exact mode."""
+    stages = {64: [(32, 212), (2, 69)], 16: [(8, 54), (2, 69)], 4: [(4, 139)], 256: [(64, 348), (4, 139)]}[w["D"]]
+    f, d = 0.0, 1
+    for r, t in stages:
+        d *= r
+        f += 4.0 * t / d
+    taps = 4097 if w["D"] == 256 else 161
+    return f + 4.0 * taps / w["D"]
 
 
 def shard(rank: int, world: int, streams_per_gpu: int):
@@ -124,20 +138,161 @@ def generate_ring(torch, dev, w, S, rank, seed):
 
 
 def cpu_baseline(w, host_iq, chunks, C, lookup_mode=1):
-    """Oracle (CPU restatement of the reference chain, oracle/liboracle.so) on the host cores: one decoder per
-    thread (std::thread inside the library), each fed the same chunk sequence the GPU consumed, repeated with
-    fresh decoders to reach ~10-15 s of work.  Returns (MS/s, threads, sample description, first-pass sentences)."""
+    """Oracle (CPU restatement of the reference chain, oracle/liboracle.so) on ALL host cores: one decoder per thread
+    (std::thread inside the library), each fed the chunk sequence the GPU consumed on its stream, repeated with fresh
+    decoders to reach ~10-15 s of work.  Returns (MS/s, threads, sample description, per-stream first-pass logs)."""
     from oracle import pyoracle
     kw = dict(fs=w["fs"], factor=w["D"], baud=w["baud"], bits=w["bits"], stops=w["stops"], lowpass_bw=w["lp_bw"],
               lowpass_trans=w["lp_trans"], mathh_context=lookup_mode, ungated=w["ungated"])
     t_one, _ = pyoracle.bench_run(host_iq[:1], chunks, C, 1, **kw)
-    repeats = int(min(max(round(12.0 / max(t_one, 1e-3)), 1), 500))
-    dt, sentences = pyoracle.bench_run(host_iq, chunks, C, repeats, **kw)
     nthreads = len(host_iq)
+    repeats = int(min(max(round(12.0 / max(t_one, 1e-3)), 1), 2000))
+    dt, logs = pyoracle.bench_run(host_iq, chunks, C, repeats, **kw)
     total = nthreads * repeats * len(chunks) * C
     sample = (f"{nthreads} streams x {len(chunks)} chunks of {C} samples x {repeats} repeats = {total / 1e6:.0f} MS; "
               f"one oracle decoder per thread, {nthreads} threads; single-thread rate {len(chunks) * C / t_one / 1e6:.1f} MS/s")
-    return total / dt / 1e6, nthreads, sample, sentences
+    return total / dt / 1e6, nthreads, sample, logs
+
+
+STAGE1 = {64: "k_decimate<32,212,64>", 16: "k_decimate<8,54,256>", 4: "k_decimate<4,139,256>", 256: "k_decimate<64,348,64>"}
+STEP = {64: "k_step<32,212,2,69>", 256: "k_step<64,348,4,139>"}
+PATHS = {0: "separate kernels", 1: "fused back end", 2: "stream tail kernel", 3: "step kernel (stage 1 + previous call's stream tails)"}
+
+
+def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync, cpu_leg):
+    """Time K steps of one workload (after W warm-up steps) and describe the result; rank 0 gets the full dictionary."""
+    import habdec_amd
+    w = dict(WORKLOADS[name])
+    S = S or w["S"]
+    C = w["C"]
+    ring, ring_chunks, texts = generate_ring(torch, dev, w, S, rank, seed=1234 + rank)
+    K = K or ring_chunks
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"],
+                            rtty_stops=w["stops"], lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"],
+                            device=local_rank, pipeline=not sync)
+    eng.set_timing(4)
+    base = ring.data_ptr()
+
+    def step(i):
+        eng.process_device(base + (i % ring_chunks) * S * C * 8, C, C)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    for i in range(W):
+        step(i)
+    eng.flush()
+    front_ms, total_ms, host_us = [], [], []
+    barrier()
+    t0 = time.perf_counter()
+    seen = eng.timing()["timed_calls"]
+    for i in range(W, W + K):
+        step(i)
+        t = eng.timing()
+        if t["timed_calls"] != seen:          # the engine brackets every 4th call with HIP events (each record costs queue time)
+            seen = t["timed_calls"]
+            front_ms.append(t["ms_front"])
+            total_ms.append(t["ms_total"])
+        host_us.append((t["host_enqueue_us"], t["host_wait_us"], t["host_text_us"]))
+    eng.flush()          # the last step's text is delivered inside the timed region
+    barrier()
+    dt = time.perf_counter() - t0
+    dt = job_time(dist, dt, dev)
+    tm = eng.timing()
+    front_bytes, path = tm["front_bytes"], tm.get("path", 0)
+    sentences_ok = eng.sentences_ok()
+    if rank != 0:
+        eng.close()
+        return None
+
+    value = world * S * C * K / dt / 1e6
+    if not front_ms:                            # fewer steps than the timing period
+        front_ms.append(tm["ms_front"]); total_ms.append(tm["ms_total"])
+    avg_front_ms = float(np.mean(front_ms))
+    # The timed kernel and its algorithmic bytes per launch (DESIGN.md section 6): the step kernel does one call's whole chain --
+    # stage 1 of this call and the stream tails of the previous one -- B(D) = 8 + 12/D bytes per input sample (SURVEY.md 8(d));
+    # a stage-1 kernel on its own reads the IQ slab and writes its decimated output.
+    if path == 3:
+        kernel, alg_bytes = STEP.get(w["D"], "k_step"), int(S * C * bytes_per_sample(w["D"]))
+    else:
+        kernel, alg_bytes = STAGE1.get(w["D"], "k_decimate"), int(front_bytes)
+    achieved = alg_bytes / (avg_front_ms * 1e-3) / 1e9
+    traffic = None
+    tf = ROOT / "profiles" / "traffic.json"
+    if tf.exists():
+        try:
+            traffic = json.loads(tf.read_text()).get(name, {}).get("front_kernel_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    valu = w["D"] == 4                                      # configs[2]: the FIR chain's multiply-adds bind, not HBM (SURVEY.md 8(d))
+    tflops = value / world * 1e6 * flops_per_sample(w) / 1e12
+    res = {
+        "value": round(value, 1), "ms_per_step": round(dt / K * 1e3, 4), "steps": K, "S": S, "C": C, "ring_chunks": ring_chunks, "w": w,
+        "timed_region_ms": round(dt * 1e3, 2),
+        "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_front_ms, 5),
+                     "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 4)},
+        "pipeline": {"bytes_per_sample": round(bytes_per_sample(w["D"]), 3),
+                     "hbm_frac_end_to_end": round(value / world * 1e6 * bytes_per_sample(w["D"]) / 1e9 / HBM_PEAK_GBS, 4),
+                     "launch_path": PATHS.get(path, str(path)),
+                     "call_latency_ms": round(float(np.mean(total_ms)), 4),
+                     "sentences_ok_rank0": int(sentences_ok),
+                     "host_us_enqueue_p50_p90_max": [round(float(np.percentile([h[0] for h in host_us], q)), 1) for q in (50, 90, 100)],
+                     "host_us_per_step": {"enqueue": round(float(np.mean([h[0] for h in host_us])), 1),
+                                          "wait_gpu": round(float(np.mean([h[1] for h in host_us])), 1),
+                                          "text_stage": round(float(np.mean([h[2] for h in host_us])), 1)},
+                     "mode": "sync" if sync else "batch (calls pipelined)"},
+    }
+    if valu:
+        res["roofline"] = {"bound": "valu", "kernel": "FIR chain: " + kernel + " + k_fir_demod (exact mode: separately rounded multiply and add)",
+                           "achieved": round(tflops, 2), "peak": VALU_NONFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / VALU_NONFMA_TFLOPS, 4),
+                           "traffic": traffic, "algorithmic_flop_per_sample": round(flops_per_sample(w), 1),
+                           "stage1_hbm": {"achieved": round(achieved, 1), "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_front_ms, 5)}}
+    if dt * 1e3 < 50.0:
+        res["pipeline"]["note"] = f"timed region is only {dt * 1e3:.1f} ms ({K} steps): start-up and the final flush weigh in; --steps 0 times one pass over the ring"
+    if not sync and path in (0, 1, 2, 3):
+        # In batch mode the timed kernel shares the GPU (or its own launch) with the previous call's back half.  A short synchronous
+        # pass (outside the timed region, own engine) gives the stage-1 kernel's isolated duration next to the contract figure above.
+        eng1 = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"],
+                                 rtty_stops=w["stops"], lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"],
+                                 device=local_rank, pipeline=False)
+        eng1.set_timing(1)
+        iso = []
+        for i in range(4 + 24):
+            eng1.process_device(base + (i % ring_chunks) * S * C * 8, C, C)
+            if i >= 4:
+                iso.append(eng1.timing()["ms_front"])
+        iso_bytes = eng1.timing()["front_bytes"]
+        eng1.close()
+        iso_ms = float(np.mean(iso))
+        iso_bw = iso_bytes / (iso_ms * 1e-3) / 1e9
+        tgt = res["roofline"] if not valu else res["roofline"]["stage1_hbm"]
+        tgt["isolated"] = {"kernel": STAGE1.get(w["D"], "k_decimate"), "algorithmic_bytes_per_launch": int(iso_bytes), "avg_launch_ms": round(iso_ms, 5),
+                           "achieved": round(iso_bw, 1), "frac": round(iso_bw / HBM_PEAK_GBS, 4),
+                           "frac_of_measured_copy_peak": round(iso_bw / HBM_COPY_GBS, 4),
+                           "note": "stage 1 alone: synchronous calls (nothing else on the GPU), 24 launches after the timed region"}
+    if cpu_leg:
+        nproc = os.cpu_count() or 1
+        nthreads = int(min(nproc, S))
+        chunks = [i % ring_chunks for i in range(W + K)]
+        host_iq = [ring[:, s].cpu().numpy().view(np.complex64).reshape(-1) for s in range(nthreads)]
+        v, c, sample, logs = cpu_baseline(w, host_iq, chunks, C)
+        gpu_sent = [eng.take_sentences(s) for s in range(nthreads)]
+        gpu_chars = [eng.take_chars(s) for s in range(nthreads)]
+        gpu_bits = [eng.bits_total(s) for s in range(nthreads)]
+        n_chars, n_bits = int(sum(len(x.chars) for x in logs)), int(sum(x.bits for x in logs))
+        same = gpu_sent == [list(x) for x in logs] and gpu_chars == [x.chars for x in logs] and gpu_bits == [x.bits for x in logs]
+        res["cpu_baseline"] = {"value": round(v, 1), "unit": "MS/s", "cores": c, "threads": c, "nproc": nproc, "kind": "port", "sample": sample,
+                               "gpu_matches_oracle_on_sample": (bool(same) if n_bits else None),
+                               "compared": "per stream: symbols produced, characters emitted, sentences -- GPU engine vs oracle over warm-up + timed steps",
+                               "bits_in_sample": n_bits, "chars_in_sample": n_chars, "sentences_in_sample": int(sum(len(x) for x in logs))}
+    eng.close()
+    del ring
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -148,7 +303,8 @@ def main():
     ap.add_argument("--workload", default="cfg4", choices=list(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sync", action="store_true", help="deliver each step's text before the next step starts (no two-stream pipelining)")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary line for BASELINE configs[2] (/4)")
+    ap.add_argument("--sync", action="store_true", help="deliver each step's text before the next step starts (no pipelining of calls)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -165,122 +321,36 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    import habdec_amd
-    w = dict(WORKLOADS[args.workload])
-    S = args.streams or w["S"]
-    C = w["C"]
-    ring, ring_chunks, texts = generate_ring(torch, dev, w, S, rank, seed=1234 + rank)
-    L = ring_chunks * C
-    K = args.steps or ring_chunks
-    W = args.warmup
-    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"],
-                            rtty_stops=w["stops"], lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"],
-                            device=local_rank, pipeline=not args.sync)
-    eng.set_timing(4)
-    base = ring.data_ptr()
-
-    def step(i):
-        eng.process_device(base + (i % ring_chunks) * S * C * 8, C, C)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
-
-    for i in range(W):
-        step(i)
-    eng.flush()
-    front_ms = []
-    total_ms = []
-    host_us = []
-    barrier()
-    t0 = time.perf_counter()
-    seen = eng.timing()["timed_calls"]
-    for i in range(W, W + K):
-        step(i)
-        t = eng.timing()
-        if t["timed_calls"] != seen:          # the engine brackets every 4th call with HIP events (each record costs queue time)
-            seen = t["timed_calls"]
-            front_ms.append(t["ms_front"])
-            total_ms.append(t["ms_total"])
-        host_us.append((t["host_enqueue_us"], t["host_wait_us"], t["host_text_us"]))
-    eng.flush()          # the last step's text is delivered inside the timed region
-    barrier()
-    dt = time.perf_counter() - t0
-    dt = job_time(dist, dt, dev)
-    front_bytes = eng.timing()["front_bytes"]
-    sentences_ok = eng.sentences_ok()
-
+    r = run_workload(torch, dist, dev, rank, local_rank, world, args.workload, args.steps, args.warmup, args.streams, args.sync,
+                     cpu_leg=not args.no_cpu_baseline)
+    also = None
+    if args.workload == "cfg4" and not args.no_also and world == 1:
+        # BASELINE configs[2] ("1024 batched IQ streams @ 2.048 MS/s, dec=2, on 1 MI355X"): the harder, VALU-bound single-GPU
+        # configuration, measured beside the headline (its own ring, a short timed region).
+        also = run_workload(torch, dist, dev, rank, local_rank, world, "cfg3", 24, 4, 0, args.sync, cpu_leg=False)
     if rank != 0:
         if dist is not None:
             dist.barrier(device_ids=[local_rank])
             dist.destroy_process_group()
         return
-
-    samples_per_step = world * S * C
-    value = samples_per_step * K / dt / 1e6
-    if not front_ms:                            # fewer steps than the timing period
-        t = eng.timing(); front_ms.append(t["ms_front"]); total_ms.append(t["ms_total"])
-    avg_front_ms = float(np.mean(front_ms))
-    achieved = front_bytes / (avg_front_ms * 1e-3) / 1e9
-    traffic = None
-    tf = ROOT / "profiles" / "traffic.json"
-    if tf.exists():
-        try:
-            traffic = json.loads(tf.read_text()).get(args.workload, {}).get("front_kernel_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    stage1 = {64: "k_decimate<32,212,64>", 16: "k_decimate<8,54,256>", 4: "k_decimate<4,139,256>", 256: "k_decimate<64,348,64>"}.get(w["D"], "k_decimate")
+    w = r["w"]
     line = {
         "metric": "IQ Msamples/s (batched 2.048 MS/s streams)" if w["fs"] == 2.048e6 else "IQ Msamples/s (batched streams)",
-        "value": round(value, 1), "unit": "MS/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": r["value"], "unit": "MS/s", "n_gpus": world, "steps": r["steps"], "warmup": args.warmup,
+        "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic: per-stream CRC-valid RTTY sentence as continuous-phase 2-FSK + Gaussian noise, generated on the GPU, HBM-resident ring",
-        "config": {"workload": f"{args.workload}: {w['desc']}", "streams_per_gpu": S, "chunk_samples": C, "ring_chunks": ring_chunks,
-                   "sharding": f"{S} independent streams per GPU, no data-path collective"},
-        "roofline": {"bound": "hbm", "kernel": stage1, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": front_bytes, "avg_launch_ms": round(avg_front_ms, 5),
-                     "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 4)},
-        "pipeline": {"bytes_per_sample": round(bytes_per_sample(w["D"]), 3),
-                     "hbm_frac_end_to_end": round(value / world * 1e6 * bytes_per_sample(w["D"]) / 1e9 / HBM_PEAK_GBS, 4),
-                     "gpu_ms_per_step_all_kernels": round(float(np.mean(total_ms)), 4),
-                     "sentences_ok_rank0": int(sentences_ok),
-                     "host_us_enqueue_p50_p90_max": [round(float(np.percentile([h[0] for h in host_us], q)), 1) for q in (50, 90, 100)],
-                     "host_us_per_step": {"enqueue": round(float(np.mean([h[0] for h in host_us])), 1),
-                                          "wait_gpu": round(float(np.mean([h[1] for h in host_us])), 1),
-                                          "text_stage": round(float(np.mean([h[2] for h in host_us])), 1)},
-                     "mode": "sync" if args.sync else "two-stream pipelined"},
+        "config": {"workload": f"{args.workload}: {w['desc']}", "streams_per_gpu": r["S"], "chunk_samples": r["C"], "ring_chunks": r["ring_chunks"],
+                   "sharding": f"{r['S']} independent streams per GPU, no data-path collective"},
+        "timed_region_ms": r["timed_region_ms"],
+        "roofline": r["roofline"], "pipeline": r["pipeline"],
     }
-    if not args.sync:
-        # In pipelined mode the stage-1 kernel shares the GPU with the previous call's back half, so its launch DURATION
-        # stretches while the job gets faster.  A short synchronous pass (outside the timed region, own engine) gives the
-        # kernel's isolated duration next to the contract figure above.
-        eng1 = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"],
-                                 rtty_stops=w["stops"], lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"],
-                                 device=local_rank, pipeline=False)
-        eng1.set_timing(1)
-        iso = []
-        for i in range(4 + 24):
-            eng1.process_device(base + (i % ring_chunks) * S * C * 8, C, C)
-            if i >= 4:
-                iso.append(eng1.timing()["ms_front"])
-        eng1.close()
-        iso_ms = float(np.mean(iso))
-        iso_bw = front_bytes / (iso_ms * 1e-3) / 1e9
-        line["roofline"]["isolated"] = {"avg_launch_ms": round(iso_ms, 5), "achieved": round(iso_bw, 1), "frac": round(iso_bw / HBM_PEAK_GBS, 4),
-                                        "frac_of_measured_copy_peak": round(iso_bw / HBM_COPY_GBS, 4),
-                                        "note": "same kernel, synchronous calls (nothing else on the GPU), 24 launches after the timed region"}
-    if not args.no_cpu_baseline:
-        cores = os.cpu_count() or 1
-        nthreads = int(min(cores, S, 64))
-        chunks = [i % ring_chunks for i in range(W + K)]
-        host_iq = [ring[:, s].cpu().numpy().view(np.complex64).reshape(-1) for s in range(nthreads)]
-        v, c, sample, sent = cpu_baseline(w, host_iq, chunks, C)
-        gpu_sent = [eng.take_sentences(s) for s in range(nthreads)]
-        line["cpu_baseline"] = {"value": round(v, 1), "unit": "MS/s", "cores": c, "kind": "port", "sample": sample,
-                                "gpu_matches_oracle_on_sample": bool(gpu_sent == sent),
-                                "sentences_in_sample": int(sum(len(x) for x in sent))}
+    if "cpu_baseline" in r:
+        line["cpu_baseline"] = r["cpu_baseline"]
+    if also:
+        aw = also["w"]
+        line["also"] = {"workload": f"cfg3: {aw['desc']}", "value": also["value"], "unit": "MS/s", "ms_per_step": also["ms_per_step"], "steps": also["steps"],
+                        "timed_region_ms": also["timed_region_ms"], "roofline": also["roofline"],
+                        "hbm_frac_end_to_end": also["pipeline"]["hbm_frac_end_to_end"], "launch_path": also["pipeline"]["launch_path"]}
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier(device_ids=[local_rank])

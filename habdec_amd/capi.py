@@ -28,7 +28,8 @@ class hd_afc_info(C.Structure):
 
 class hd_timing(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("ms_front", C.c_double), ("front_bytes", C.c_uint64), ("samples", C.c_uint64),
-                ("host_enqueue_us", C.c_double), ("host_wait_us", C.c_double), ("host_text_us", C.c_double), ("timed_calls", C.c_uint64)]
+                ("host_enqueue_us", C.c_double), ("host_wait_us", C.c_double), ("host_text_us", C.c_double), ("timed_calls", C.c_uint64),
+                ("path", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 SENTENCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p)
@@ -76,6 +77,8 @@ ENGINE_API = {
     "hd_stream_flips": (_sz, [_vp, _u32, _u32p, _sz]),
     "hd_stream_fir_taps": (_sz, [_vp, _u32, _f32p, _sz]),
     "hd_stream_symbol_backlog": (_u32, [_vp, _u32]),
+    "hd_stream_bits_total": (C.c_uint64, [_vp, _u32]),
+    "hd_min_chunk": (_u32, [_u32]),
     "hd_engine_timing": (_int, [_vp, C.POINTER(hd_timing)]),
     "hd_engine_set_timing": (None, [_vp, _int]),
 }

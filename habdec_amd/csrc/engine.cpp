@@ -95,6 +95,7 @@ struct StreamHost {
     hd::SpectrumStats stats{};
     // last call (for the getters)
     uint32_t last_n2 = 0, last_pend_before = 0, last_m = 0, last_nbits = 0, last_nflips = 0;
+    uint64_t bits_total = 0;
     int last_buf = 0;
     std::vector<uint32_t> last_words;
 };
@@ -171,7 +172,8 @@ struct hd_engine {
     bool sym_dirty = true;
 
     std::vector<StreamHost> st;
-    std::mutex mtx;
+    std::recursive_mutex mtx;   // recursive: a sentence / character callback (fired under it, on the calling thread) may call the text getters
+    bool in_callback = false;   // ... but not the data getters that would have to flush the pipeline from inside a delivery
     hd_sentence_cb sentence_cb = nullptr; void* sentence_user = nullptr;
     hd_chars_cb chars_cb = nullptr; void* chars_user = nullptr;
     uint64_t sentences_ok = 0;
@@ -224,6 +226,19 @@ extern "C" {
 
 const char* hd_last_error(void) { return g_err.c_str(); }
 
+/* Smallest non-empty per-stream sample count hd_process_* accepts for a decimation factor: a multiple of the factor that covers the
+ * history of every stage (shorter inputs are undefined behaviour in the reference, Q4).  0 = unsupported factor. */
+uint32_t hd_min_chunk(uint32_t decimation)
+{
+    std::vector<hd::DecimStage> st;
+    if (!hd::decim_plan(decimation, st)) return 0;
+    uint64_t need = decimation ? decimation : 1;
+    uint64_t r = 1;
+    for (const auto& g : st) { need = std::max<uint64_t>(need, (uint64_t)(g.taps.size() - 1) * r); r *= (uint64_t)g.ratio; }
+    const uint64_t d = decimation ? decimation : 1;
+    return (uint32_t)((need + d - 1) / d * d);
+}
+
 void hd_engine_config_default(hd_engine_config* c)
 {
     std::memset(c, 0, sizeof(*c));
@@ -249,6 +264,8 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     e->fs = (double)(float)cfg->sampling_rate;        // Decoder::init(const float) (Decoder.h:223-225)
     e->fsd = e->fs / (double)e->D;
     e->decode_enabled = cfg->ungated || !(e->fsd > 4 * 40e3);   // Decoder.h:522
+    if (cfg->baud > 0 && e->fsd / cfg->baud < 3.5)
+        return fail(HD_ERR_UNSUPPORTED, "symbol rate above a third of the decimated rate (fewer than 4 samples per bit): the symbol extractor's windows would overlap");
     {   // AFC::FindPeaks separation in bins (AFC.h:110-111, 299-300)
         const float rel = (float)(500.0f / e->fsd);
         e->bins_sep = std::max(8, (int)std::round((double)rel * (double)hd::kFftBins));
@@ -409,6 +426,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         hd::launch_symbols(q, S, 1, 1, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p, sl.d_call.p,
                            sl.h_slots.dev, e->slot_words, nullptr, 0, e->min_R);
         HD_HIP(hipStreamSynchronize(q));
+        HD_HIP(hipGetLastError());        // a kernel this shape cannot launch (LDS, grid) fails the creation, not every later call
         // the all-idle call moved nothing, but the history / carry ping-pong "out" buffers were written: restore zeros
         for (auto& h : e->hist1) if (h.p) HD_HIP(hipMemset(h.p, 0, h.n * sizeof(float2)));
         for (auto& h : e->hist2) if (h.p) HD_HIP(hipMemset(h.p, 0, h.n * sizeof(float2)));
@@ -457,7 +475,9 @@ void hd_set_chars_callback(hd_engine* e, hd_chars_cb cb, void* user) { if (e) { 
 int hd_stream_set_baud(hd_engine* e, uint32_t s, double baud)
 {
     if (int r = check_stream(e, s)) return r;
-    std::lock_guard<std::mutex> l(e->mtx);
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
+    if (baud > 0 && e->fsd / baud < 3.5)
+        return fail(HD_ERR_UNSUPPORTED, "symbol rate above a third of the decimated rate (fewer than 4 samples per bit): the symbol extractor's windows would overlap");
     StreamHost probe = e->st[s];
     probe.baud = baud;
     const hd::SymbolParams p = symbol_params(e, probe);
@@ -476,7 +496,7 @@ int hd_stream_set_baud(hd_engine* e, uint32_t s, double baud)
 int hd_stream_set_rtty(hd_engine* e, uint32_t s, uint32_t bits, float stops)
 {
     if (int r = check_stream(e, s)) return r;
-    std::lock_guard<std::mutex> l(e->mtx);
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
     e->st[s].text.framer.nbits = bits;
     e->st[s].text.framer.nstops = stops;
     return HD_OK;
@@ -484,7 +504,7 @@ int hd_stream_set_rtty(hd_engine* e, uint32_t s, uint32_t bits, float stops)
 int hd_stream_set_lowpass_bw(hd_engine* e, uint32_t s, float hz)         // Decoder.h:238-243
 {
     if (int r = check_stream(e, s)) return r;
-    std::lock_guard<std::mutex> l(e->mtx);
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
     StreamHost& st = e->st[s];
     st.lp_bw = hz;
     if (st.lp.design(cutoff_rel(e, st), st.lp_trans)) st.taps_dirty = true;
@@ -493,7 +513,7 @@ int hd_stream_set_lowpass_bw(hd_engine* e, uint32_t s, float hz)         // Deco
 int hd_stream_set_lowpass_trans(hd_engine* e, uint32_t s, float trans)   // Decoder.h:252-257
 {
     if (int r = check_stream(e, s)) return r;
-    std::lock_guard<std::mutex> l(e->mtx);
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
     StreamHost& st = e->st[s];
     st.lp_trans = trans;
     if (st.lp.design(cutoff_rel(e, st), st.lp_trans)) st.taps_dirty = true;
@@ -502,14 +522,14 @@ int hd_stream_set_lowpass_trans(hd_engine* e, uint32_t s, float trans)   // Deco
 int hd_stream_set_dc_remove(hd_engine* e, uint32_t s, int on)
 {
     if (int r = check_stream(e, s)) return r;
-    std::lock_guard<std::mutex> l(e->mtx);
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
     e->st[s].dc = on != 0;
     return HD_OK;
 }
 int hd_stream_reset_frequency_correction(hd_engine* e, uint32_t s, double c)
 {
     if (int r = check_stream(e, s)) return r;
-    std::lock_guard<std::mutex> l(e->mtx);
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
     e->st[s].afc.reset(c, hd::kFftBins, e->fsd);
     return HD_OK;
 }
@@ -588,6 +608,7 @@ int collect(hd_engine* e, hd_engine::CallSlot& sl)
         st.inflight_m -= c.fir_m;
         st.win_ub = hdr->uncached + st.inflight_m;
         st.last_nbits = hdr->nbits; st.last_nflips = hdr->nflips;
+        st.bits_total += hdr->nbits;
         if (hdr->overflow) rc = fail(HD_ERR_CAPACITY, "symbol result slot overflow on stream " + std::to_string(s));
         const uint32_t* words = slot + sizeof(hd::BitsHeader) / 4;
         st.last_words.assign(words, words + (hdr->nbits + 31) / 32);
@@ -595,9 +616,9 @@ int collect(hd_engine* e, hd_engine::CallSlot& sl)
         if (hdr->nbits) st.text.framer.push_packed(words, hdr->nbits);
         const std::string chars = st.text.run(hdr->nbits != 0, [&](const hd::SentenceMatch& m) {
             ++e->sentences_ok;
-            if (e->sentence_cb) e->sentence_cb(e->sentence_user, s, m.callsign.c_str(), m.data.c_str(), m.crc.c_str());
+            if (e->sentence_cb) { e->in_callback = true; e->sentence_cb(e->sentence_user, s, m.callsign.c_str(), m.data.c_str(), m.crc.c_str()); e->in_callback = false; }
         });
-        if (!chars.empty() && e->chars_cb) e->chars_cb(e->chars_user, s, chars.data(), chars.size());
+        if (!chars.empty() && e->chars_cb) { e->in_callback = true; e->chars_cb(e->chars_user, s, chars.data(), chars.size()); e->in_callback = false; }
     }
     e->last_timing.host_wait_us = std::chrono::duration<double, std::micro>(w1 - w0).count();
     e->last_timing.host_text_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w1).count();
@@ -620,7 +641,7 @@ int flush_locked(hd_engine* e)
 int hd_flush(hd_engine* e)
 {
     if (!e) return fail(HD_ERR_INVALID, "null engine");
-    std::lock_guard<std::mutex> lock(e->mtx);
+    std::lock_guard<std::recursive_mutex> lock(e->mtx);
     HD_HIP(hipSetDevice(e->cfg.device));
     return flush_locked(e);
 }
@@ -630,7 +651,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     if (!e) return fail(HD_ERR_INVALID, "null engine");
     if (!d_iq) return fail(HD_ERR_INVALID, "null IQ pointer");
     if ((reinterpret_cast<uintptr_t>(d_iq) & 15) || (stride & 1)) return fail(HD_ERR_INVALID, "IQ base must be 16-byte aligned and stream_stride even");
-    std::lock_guard<std::mutex> lock(e->mtx);
+    std::lock_guard<std::recursive_mutex> lock(e->mtx);
     const auto h0 = std::chrono::steady_clock::now();
     HD_HIP(hipSetDevice(e->cfg.device));
     const uint32_t S = e->S;
@@ -748,6 +769,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         HD_HIP(hipStreamSynchronize(qa)); HD_HIP(hipStreamSynchronize(qb));
     }
     e->last_fuse = path;
+    e->last_timing.path = (uint32_t)path;
     // Cross-queue event waits cost ~18 us each on this platform (kernel trace: stage 1 of call k+1 started 37 us after stage 1
     // of call k ended, two barrier packets later).  On the fused path the stage-1 queue therefore waits for NOTHING: it reads the
     // call's parameters straight from the mapped host block (32 bytes per workgroup), its output rotates over three buffers --
@@ -1003,8 +1025,10 @@ int hd_ingest_run(hd_engine* e, hd_host_iqfiles* src, uint64_t max_rounds, uint6
     std::condition_variable cv;
     uint64_t filled = 0, consumed = 0;       // rounds read by the reader / handed back by the pump
     bool stop = false;
+    src->batch.set_min_take(hd_min_chunk(e->D));      // a file tail shorter than the stage histories waits for the next round
+    const bool looping = src->batch.looping();
     std::thread reader([&] {
-        for (uint64_t r = 0;; ++r) {
+        for (uint64_t r = 0; r < max_rounds; ++r) {       // never read past the stop: a later hd_ingest_run resumes where this one ended
             {
                 std::unique_lock<std::mutex> l(m);
                 cv.wait(l, [&] { return stop || r < consumed + (uint64_t)kSlabs - 2; });   // two slabs may still belong to calls in flight
@@ -1017,7 +1041,7 @@ int hd_ingest_run(hd_engine* e, hd_host_iqfiles* src, uint64_t max_rounds, uint6
                 filled = r + 1;
             }
             cv.notify_all();
-            if (!b.alive) return;
+            if (!b.alive && !looping) return;
         }
     });
     int rc = HD_OK;
@@ -1028,7 +1052,13 @@ int hd_ingest_run(hd_engine* e, hd_host_iqfiles* src, uint64_t max_rounds, uint6
             cv.wait(l, [&] { return filled > r; });
         }
         Slab& b = slab[r % kSlabs];
-        if (!b.alive) break;
+        if (!b.alive) {
+            if (!looping) break;
+            // looping files of equal length a whole number of chunks long: the reference's one empty read before the rewind
+            { std::lock_guard<std::mutex> l(m); consumed = r + 1; }
+            cv.notify_all();
+            continue;
+        }
         bool uniform = true;
         for (uint32_t s = 1; s < S; ++s) uniform = uniform && b.n[s] == b.n[0];
         rc = hd_process_host(e, b.iq, stride, uniform ? nullptr : b.n.data(), uniform ? b.n[0] : 0);
@@ -1068,21 +1098,21 @@ static size_t take_out(std::string& s, char* buf, size_t cap)
 }
 
 size_t hd_stream_rtty(hd_engine* e, uint32_t s, char* buf, size_t cap)
-{ if (check_stream(e, s)) return 0; std::lock_guard<std::mutex> l(e->mtx); return copy_out(e->st[s].text.stream, buf, cap); }
+{ if (check_stream(e, s)) return 0; std::lock_guard<std::recursive_mutex> l(e->mtx); return copy_out(e->st[s].text.stream, buf, cap); }
 size_t hd_stream_last_sentence(hd_engine* e, uint32_t s, char* buf, size_t cap)
-{ if (check_stream(e, s)) return 0; std::lock_guard<std::mutex> l(e->mtx); return copy_out(e->st[s].text.last_sentence, buf, cap); }
+{ if (check_stream(e, s)) return 0; std::lock_guard<std::recursive_mutex> l(e->mtx); return copy_out(e->st[s].text.last_sentence, buf, cap); }
 size_t hd_stream_take_sentences(hd_engine* e, uint32_t s, char* buf, size_t cap)
-{ if (check_stream(e, s)) return 0; std::lock_guard<std::mutex> l(e->mtx); return take_out(e->st[s].text.ok_log, buf, cap); }
+{ if (check_stream(e, s)) return 0; std::lock_guard<std::recursive_mutex> l(e->mtx); return take_out(e->st[s].text.ok_log, buf, cap); }
 size_t hd_stream_take_matches(hd_engine* e, uint32_t s, char* buf, size_t cap)
-{ if (check_stream(e, s)) return 0; std::lock_guard<std::mutex> l(e->mtx); return take_out(e->st[s].text.match_log, buf, cap); }
+{ if (check_stream(e, s)) return 0; std::lock_guard<std::recursive_mutex> l(e->mtx); return take_out(e->st[s].text.match_log, buf, cap); }
 size_t hd_stream_take_chars(hd_engine* e, uint32_t s, char* buf, size_t cap)
-{ if (check_stream(e, s)) return 0; std::lock_guard<std::mutex> l(e->mtx); return take_out(e->st[s].text.char_log, buf, cap); }
+{ if (check_stream(e, s)) return 0; std::lock_guard<std::recursive_mutex> l(e->mtx); return take_out(e->st[s].text.char_log, buf, cap); }
 
 int hd_stream_afc(hd_engine* e, uint32_t s, hd_afc_info* out)
 {
     if (int r = check_stream(e, s)) return r;
     if (!out) return fail(HD_ERR_INVALID, "null argument");
-    std::lock_guard<std::mutex> l(e->mtx);
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
     const StreamHost& st = e->st[s];
     out->frequency_correction = st.afc.correction; out->shift_hz = st.afc.shift_hz;
     out->noise_floor = st.afc.noise_floor; out->noise_variance = st.afc.noise_sigma;
@@ -1092,6 +1122,7 @@ int hd_stream_afc(hd_engine* e, uint32_t s, hd_afc_info* out)
 
 static size_t fetch(hd_engine* e, const void* dev, size_t count, size_t elem, void* host, size_t cap)
 {
+    if (e->in_callback) { fail(HD_ERR_INVALID, "data getters cannot be called from a sentence / character callback (text getters can)"); return 0; }
     (void)flush_locked(e);                                  // pipelined mode: wait for the call in flight
     const size_t n = std::min(count, cap);
     if (!n || !host) return count;
@@ -1103,27 +1134,27 @@ static size_t fetch(hd_engine* e, const void* dev, size_t count, size_t elem, vo
 size_t hd_stream_spectrum(hd_engine* e, uint32_t s, float* iq, size_t cap)
 {
     if (check_stream(e, s)) return 0;
-    std::lock_guard<std::mutex> l(e->mtx);
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
     if (!e->cfg.enable_spectrum || !e->st[s].have_spectrum) return 0;
     return fetch(e, e->spec.p + (size_t)s * hd::kFftBins, hd::kFftBins, sizeof(float2), iq, cap);
 }
 size_t hd_stream_power(hd_engine* e, uint32_t s, float* p, size_t cap)
 {
     if (check_stream(e, s)) return 0;
-    std::lock_guard<std::mutex> l(e->mtx);
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
     if (!e->cfg.enable_spectrum || !e->st[s].have_spectrum) return 0;
     return fetch(e, e->power.p + (size_t)s * hd::kFftBins, hd::kFftBins, sizeof(float), p, cap);
 }
 size_t hd_stream_demodulated(hd_engine* e, uint32_t s, float* v, size_t cap)
 {
     if (check_stream(e, s)) return 0;
-    std::lock_guard<std::mutex> l(e->mtx);
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
     return fetch(e, e->demod.p + (size_t)s * (e->demod.n / e->S), e->st[s].last_m, sizeof(float), v, cap);
 }
 size_t hd_stream_decimated(hd_engine* e, uint32_t s, float* iq, size_t cap)
 {
     if (check_stream(e, s)) return 0;
-    std::lock_guard<std::mutex> l(e->mtx);
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
     const StreamHost& st = e->st[s];
     const float2* src = e->fbuf[st.last_buf].p + (size_t)s * e->fbuf_stride + e->fir_hist_cap + st.last_pend_before;
     return fetch(e, src, st.last_n2, sizeof(float2), iq, cap);
@@ -1131,14 +1162,14 @@ size_t hd_stream_decimated(hd_engine* e, uint32_t s, float* iq, size_t cap)
 size_t hd_stream_filtered(hd_engine* e, uint32_t s, float* iq, size_t cap)
 {
     if (check_stream(e, s)) return 0;
-    std::lock_guard<std::mutex> l(e->mtx);
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
     if (!e->cfg.keep_filtered) return 0;
     return fetch(e, e->filtered.p + (size_t)s * (e->demod.n / e->S), e->st[s].last_m, sizeof(float2), iq, cap);
 }
 size_t hd_stream_bits(hd_engine* e, uint32_t s, uint8_t* bits, size_t cap)
 {
     if (check_stream(e, s)) return 0;
-    std::lock_guard<std::mutex> l(e->mtx);
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
     const StreamHost& st = e->st[s];
     for (uint32_t i = 0; i < st.last_nbits && i < cap; ++i) bits[i] = (st.last_words[i >> 5] >> (i & 31)) & 1u;
     return st.last_nbits;
@@ -1146,7 +1177,7 @@ size_t hd_stream_bits(hd_engine* e, uint32_t s, uint8_t* bits, size_t cap)
 size_t hd_stream_flips(hd_engine* e, uint32_t s, uint32_t* flips, size_t cap)
 {
     if (check_stream(e, s)) return 0;
-    std::lock_guard<std::mutex> l(e->mtx);
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
     if (!e->flips_cap) return 0;
     const size_t n = std::min<size_t>(e->st[s].last_nflips, e->flips_cap);
     return fetch(e, e->flips_dbg.p + (size_t)s * e->flips_cap, n, sizeof(uint32_t), flips, cap);
@@ -1154,15 +1185,21 @@ size_t hd_stream_flips(hd_engine* e, uint32_t s, uint32_t* flips, size_t cap)
 size_t hd_stream_fir_taps(hd_engine* e, uint32_t s, float* taps, size_t cap)
 {
     if (check_stream(e, s)) return 0;
-    std::lock_guard<std::mutex> l(e->mtx);
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
     const auto& t = e->st[s].lp.taps;
     if (taps) std::memcpy(taps, t.data(), std::min(cap, t.size()) * sizeof(float));
     return t.size();
 }
+uint64_t hd_stream_bits_total(hd_engine* e, uint32_t s)
+{
+    if (check_stream(e, s)) return 0;
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
+    return e->st[s].bits_total;
+}
 uint32_t hd_stream_symbol_backlog(hd_engine* e, uint32_t s)
 {
     if (check_stream(e, s)) return 0;
-    std::lock_guard<std::mutex> l(e->mtx);
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
     return e->st[s].held;
 }
 

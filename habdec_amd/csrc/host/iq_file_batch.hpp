@@ -36,6 +36,7 @@ class IqFile {
         return f_.is_open();
     }
     uint64_t count() const { return count_; }
+    bool loops() const { return loop_; }
     uint64_t rewinds() const { return rewinds_; }
     // IQSource_File::get: up to `want` complex samples into dst (2 floats each); returns the number read
     size_t get(float* dst, size_t want)
@@ -74,6 +75,14 @@ class IqFileBatch {
         }
         return true;
     }
+    // Rounds smaller than `n` samples (but not empty) are held back and joined with the stream's next round: the engine rejects
+    // chunks shorter than its stage histories (undefined behaviour in the reference, Q4), and a file's tail may be that short.
+    void set_min_take(uint32_t n)
+    {
+        min_take_ = n;
+        for (auto& c : carry_) if (c.size() < 2 * ((size_t)n + granule_)) c.resize(2 * ((size_t)n + granule_), 0.0f);
+    }
+    bool looping() const { for (const auto& f : files_) if (f->loops()) return true; return false; }
     uint32_t streams() const { return (uint32_t)files_.size(); }
     uint32_t chunk() const { return chunk_; }
     const IqFile& file(uint32_t s) const { return *files_[s]; }
@@ -91,7 +100,8 @@ class IqFileBatch {
             if (got) ++alive;
             most = got > most ? got : most;
             const uint32_t total = c + (uint32_t)got;
-            const uint32_t rem = total % granule_;
+            uint32_t rem = total % granule_;
+            if (total - rem && total - rem < min_take_ && total < chunk_) rem = total;     // too short for the engine: wait for more
             n_out[s] = total - rem;
             if (rem) std::memcpy(carry_[s].data(), dst + 2 * (size_t)(total - rem), (size_t)rem * 8);
             carry_n_[s] = rem;
@@ -105,7 +115,7 @@ class IqFileBatch {
     std::vector<std::unique_ptr<IqFile>> files_;
     std::vector<std::vector<float>> carry_;
     std::vector<uint32_t> carry_n_;
-    uint32_t chunk_ = 0, granule_ = 1;
+    uint32_t chunk_ = 0, granule_ = 1, min_take_ = 0;
     double rate_ = 0.0;
 };
 

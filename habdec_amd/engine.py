@@ -144,12 +144,14 @@ class Engine:
 
     def symbol_backlog(self, s=0) -> int: return self.L.hd_stream_symbol_backlog(self.h, s)
 
+    def bits_total(self, s=0) -> int: return int(self.L.hd_stream_bits_total(self.h, s))
+
     def timing(self) -> dict:
         t = capi.hd_timing()
         check(self.L.hd_engine_timing(self.h, C.byref(t)))
         return {"ms_total": t.ms_total, "ms_front": t.ms_front, "front_bytes": t.front_bytes, "samples": t.samples,
                 "host_enqueue_us": t.host_enqueue_us, "host_wait_us": t.host_wait_us, "host_text_us": t.host_text_us,
-                "timed_calls": t.timed_calls}
+                "timed_calls": t.timed_calls, "path": t.path}
 
     def set_timing(self, every: int):
         """HIP-event timing on every `every`-th call (0 = off); see hd_engine_set_timing."""

@@ -87,11 +87,20 @@ public:
     }
     size_t setupDecimationStagesBW(const double max_rate)
     {
+        // reference Decoder.h:336-412: the smallest power-of-two division (2 .. 256) that brings the rate to max_rate or below; the
+        // reference would stack a SECOND such division when even /256 is not enough -- a plan of more than two stages, which the
+        // engine does not have: that request is refused (message, current plan kept).
         if (!input_rate_) return 0;
-        size_t f = 1;
         double r = input_rate_;
-        while (r > max_rate && f < 256) { r /= 2; f *= 2; }
-        return setupDecimationStagesFactor(f);
+        if (!(r > max_rate)) return setupDecimationStagesFactor(1);
+        int div = 2;
+        for (; div < 256; div *= 2)
+            if (r / div <= max_rate) break;
+        if (r / div > max_rate) {
+            std::cout << "Decoder::setupDecimationStagesBW more than /256 needed for " << max_rate << " Hz: unsupported, keeping /" << factor_ << std::endl;
+            return 0;
+        }
+        return setupDecimationStagesFactor((size_t)div);
     }
 
     // ---- results
@@ -149,32 +158,47 @@ public:
     void process()
     {
         if (!input_rate_) return;                            // nothing pushed yet
-        std::lock_guard<std::mutex> l(mtx_);
-        std::vector<TComplex> work;
+        std::vector<Event> fire;
+        std::string chars_now;
         {
-            std::lock_guard<std::mutex> q(queue_mtx_);
-            if ((int)queue_.size() < factor_) return;
-            const size_t take = queue_.size() - queue_.size() % (size_t)factor_;
-            work.assign(queue_.begin(), queue_.begin() + take);
-            queue_.erase(queue_.begin(), queue_.begin() + take);
-        }
-        if (!ensure_engine(work.size())) return;
-        size_t done = 0;
-        while (done < work.size()) {                         // one engine call per max_chunk (a single call in normal use)
-            const size_t n = std::min(work.size() - done, (size_t)max_chunk_);
-            if (hd_process_host(engine_, reinterpret_cast<const float*>(work.data() + done), n, nullptr, (uint32_t)n) != HD_OK) {
-                std::cout << "habdec_amd: " << hd_last_error() << std::endl;
-                return;
+            std::lock_guard<std::mutex> l(mtx_);
+            std::vector<TComplex> work;
+            {
+                std::lock_guard<std::mutex> q(queue_mtx_);
+                if ((int)queue_.size() < factor_) return;
+                const size_t take = queue_.size() - queue_.size() % (size_t)factor_;
+                // Inputs shorter than a decimation stage's history are undefined behaviour in the reference (Decimator.h:140-143) and
+                // refused by the engine: leave them queued until the next push has made them long enough.
+                if (take < (size_t)hd_min_chunk((uint32_t)factor_)) return;
+                work.assign(queue_.begin(), queue_.begin() + take);
+                queue_.erase(queue_.begin(), queue_.begin() + take);
             }
-            done += n;
+            if (!ensure_engine(work.size())) return;
+            events_ = &fire;
+            size_t done = 0;
+            while (done < work.size()) {                     // one engine call per max_chunk (a single call in normal use)
+                size_t n = std::min(work.size() - done, (size_t)max_chunk_);
+                const size_t left = work.size() - done - n;
+                if (left && left < (size_t)hd_min_chunk((uint32_t)factor_)) n -= (size_t)hd_min_chunk((uint32_t)factor_);   // never leave a too-short last call
+                if (hd_process_host(engine_, reinterpret_cast<const float*>(work.data() + done), n, nullptr, (uint32_t)n) != HD_OK) {
+                    std::cout << "habdec_amd: " << hd_last_error() << std::endl;
+                    break;
+                }
+                done += n;
+            }
+            events_ = nullptr;
+            // character_callback_: at most every 250 ms, like the reference (Decoder.h:617-629)
+            const auto now = std::chrono::steady_clock::now();
+            if (!pending_chars_.empty() && now - last_char_cb_ > std::chrono::milliseconds(250)) {
+                chars_now.swap(pending_chars_);
+                last_char_cb_ = now;
+            }
         }
-        // character_callback_: at most every 250 ms, like the reference (Decoder.h:617-629)
-        const auto now = std::chrono::steady_clock::now();
-        if (!pending_chars_.empty() && now - last_char_cb_ > std::chrono::milliseconds(250)) {
-            if (character_callback_) character_callback_(pending_chars_);
-            pending_chars_.clear();
-            last_char_cb_ = now;
-        }
+        // The callbacks run here, on the decoder thread and before process() returns (Decoder.h:604-606, 625-626), but with no lock
+        // held: they may call any getter of this decoder, as they can in the reference.
+        for (const Event& ev : fire)
+            if (sentence_callback_) sentence_callback_(ev.callsign, ev.data, ev.crc);
+        if (!chars_now.empty() && character_callback_) character_callback_(chars_now);
     }
     void operator()() { process(); }
 
@@ -191,11 +215,12 @@ public:
     std::function<void(std::string, int, std::vector<uint8_t>)> ssdv_callback_;
 
 private:
+    struct Event { std::string callsign, data, crc; };
     static void on_sentence(void* self, uint32_t, const char* call, const char* data, const char* crc)
     {
         auto* d = static_cast<Decoder*>(self);
         std::cout << call << "," << data << "*" << crc << std::endl;     // the reference prints every matched sentence
-        if (d->sentence_callback_) d->sentence_callback_(call, data, crc);
+        if (d->events_) d->events_->push_back(Event{call, data, crc});   // delivered by process() once its lock is released
     }
     static void on_chars(void* self, uint32_t, const char* chars, size_t n)
     {
@@ -214,7 +239,8 @@ private:
         const char* dev = std::getenv("HABDEC_AMD_DEVICE");
         c.device = dev ? std::atoi(dev) : 0;
         c.n_streams = 1;
-        max_chunk_ = (uint32_t)std::max<size_t>(1u << 20, ((take + factor_ - 1) / factor_) * factor_);
+        // room for the usual 65536-sample reads, or for this (larger) first take: the engine's rings and LDS images grow with max_chunk / factor
+        max_chunk_ = (uint32_t)std::max<size_t>((size_t)1 << 17, ((take + factor_ - 1) / factor_) * factor_);
         c.max_chunk = max_chunk_;
         c.sampling_rate = input_rate_;
         c.decimation = (uint32_t)factor_;
@@ -254,6 +280,7 @@ private:
     }
 
     hd_engine* engine_ = nullptr;
+    std::vector<Event>* events_ = nullptr;   // where the engine's sentence callback parks its events during process()
     mutable std::mutex mtx_;                 // process() vs. getters/setters from the server thread
     std::mutex queue_mtx_;
     std::vector<TComplex> queue_;            // iq_in_buffer_

@@ -78,6 +78,10 @@ void hd_engine_config_default(hd_engine_config* cfg);
 int  hd_engine_create(const hd_engine_config* cfg, hd_engine** out);
 void hd_engine_destroy(hd_engine* e);
 const char* hd_last_error(void);
+/* Smallest non-empty per-stream sample count hd_process_* accepts at a decimation factor (a multiple of the factor that covers every stage's
+ * history: shorter inputs are undefined behaviour in the reference's Decimator.h:140-143); 0 = unsupported factor.  A caller that drains a queue
+ * (Decoder::process, Decoder.h:426-436) leaves fewer samples queued until more arrive. */
+uint32_t hd_min_chunk(uint32_t decimation);
 uint32_t hd_engine_streams(const hd_engine* e);
 /* getDecimationFactor / getDecimatedSamplingRate (Decoder.h:716-735) */
 uint32_t hd_engine_decimation(const hd_engine* e);
@@ -149,11 +153,12 @@ size_t hd_stream_bits(hd_engine* e, uint32_t stream, uint8_t* bits, size_t cap);
 size_t hd_stream_flips(hd_engine* e, uint32_t stream, uint32_t* flips, size_t cap);        /* flip points of the last call */
 size_t hd_stream_fir_taps(hd_engine* e, uint32_t stream, float* taps, size_t cap);
 uint32_t hd_stream_symbol_backlog(hd_engine* e, uint32_t stream);                          /* samples held by the symbol extractor */
+uint64_t hd_stream_bits_total(hd_engine* e, uint32_t stream);                              /* symbols produced since the engine was created (delivered calls) */
 
 /* ---- measurement ---- */
 typedef struct hd_timing {
     double ms_total;        /* HIP-event time of the whole kernel sequence of the last hd_process_* call */
-    double ms_front;        /* of its first-stage decimation kernel (the only kernel that touches full-rate IQ) */
+    double ms_front;        /* of the kernel that touches full-rate IQ: the first-stage decimator, or the step kernel that contains it (see path) */
     uint64_t front_bytes;   /* algorithmic bytes of that launch: 8 B per input sample + 8 B per output sample */
     uint64_t samples;       /* input samples consumed by the last call over all streams */
     /* host side of the most recent hd_process_* call, microseconds */
@@ -161,6 +166,9 @@ typedef struct hd_timing {
     double host_wait_us;    /* blocked on the GPU for the results being delivered */
     double host_text_us;    /* AFC state machines, RTTY framing, sentence scan, callbacks */
     uint64_t timed_calls;   /* how many calls carried the HIP-event timing so far (ms_* are those of the latest one) */
+    uint32_t path;          /* how the most recent call was launched: 0 separate kernels, 1 fused back end (k_backend), 2 stream tail kernel
+                             * (k_tail), 3 step kernel (k_step: stage 1 + the previous call's stream tails in one launch; ms_front is ITS duration) */
+    uint32_t _pad;
 } hd_timing;
 int hd_engine_timing(hd_engine* e, hd_timing* out);
 /* Bracket the kernels with HIP events on every `every`-th call (default 8; 0 = never; 1 = every call).  Each event record is

@@ -9,6 +9,7 @@
  * Each function cites the reference lines it follows.  Quirk numbers (Qn) refer to SURVEY.md section 9.
  */
 #include "habdec_oracle.h"
+#include "orc_atan2f.h"
 
 #include <algorithm>
 #include <cmath>
@@ -387,7 +388,28 @@ static inline float orc_disc(cf32 x, cf32 prev)
     const float a = x.real(), b = x.imag(), c = prev.real(), d = -prev.imag();
     const float re = a * c - b * d;
     const float im = a * d + b * c;
-    return atan2f(im, re);
+    return orc_atan2f_fdlibm(im, re);      /* = glibc 2.35's atan2f bit for bit; see orc_atan2f.h and orc_atan2f_libm_mismatches() */
+}
+
+/* How many of n pseudo-random argument pairs (plus the special classes) the box's libm atan2f answers differently from the
+ * restatement the oracle uses.  0 on glibc 2.35; anything else means "this box has another libm", not "the oracle is wrong". */
+size_t orc_atan2f_libm_mismatches(uint64_t seed, size_t n)
+{
+    size_t bad = 0;
+    uint64_t st = seed * 6364136223846793005ull + 1442695040888963407ull;
+    auto next = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(st >> 32); };
+    const float specials[] = {0.0f, -0.0f, 1.0f, -1.0f, INFINITY, -INFINITY, NAN, 1e-45f, -1e-45f, 1e-38f, 3.4e38f, 33554432.0f, 9.3e-10f, 0.4375f, 0.6875f, 1.1875f, 2.4375f};
+    const size_t ns = sizeof(specials) / sizeof(specials[0]);
+    for (size_t i = 0; i < n + ns * ns; ++i) {
+        float y, x;
+        if (i < ns * ns) { y = specials[i / ns]; x = specials[i % ns]; }
+        else if (i & 1) { y = orc_bits_f32(next()); x = orc_bits_f32(next()); }              /* any bit pattern */
+        else { y = ((int32_t)next()) * 4.6566e-10f * 2.0f; x = ((int32_t)next()) * 4.6566e-10f * 2.0f; }   /* ordinary products */
+        const float want = atan2f(y, x), got = orc_atan2f_fdlibm(y, x);
+        if (want != want && got != got) continue;
+        if (orc_f32_bits(want) != orc_f32_bits(got)) ++bad;
+    }
+    return bad;
 }
 void orc_demod_run(orc_demod* s, const float* iq_f, size_t n, float* out)
 {
@@ -629,6 +651,7 @@ struct orc_decoder {
     orc_symex symex;
     orc_rtty rtty;
     std::string rtty_stream, last_sentence, sentence_log, match_log, chars_log;
+    uint64_t total_bits = 0;     /* symbols produced so far (bench self-check) */
     /* introspection of the last call */
     std::vector<cf32> last_decimated, last_filtered;
     std::vector<float> last_demod;
@@ -743,6 +766,7 @@ void orc_decoder_process(orc_decoder* d)                       /* Decoder.h:416-
 
     orc_symex_run(&d->symex);                                  /* :559-566 */
     d->last_bits = d->symex.bits;
+    d->total_bits += d->last_bits.size();
     d->symex.bits.clear();
     if (!d->last_bits.empty()) {
         orc_rtty_push(&d->rtty, d->last_bits.data(), d->last_bits.size());
@@ -813,7 +837,7 @@ double orc_bench_run(const orc_bench_cfg* cfg, const float* const* iq, const uin
                 orc_decoder_push(d, iq[i] + 2 * (size_t)chunk_idx[c] * chunk, chunk, cfg->sampling_rate);
                 orc_decoder_process(d);
             }
-            if (r == 0) logs[i] = d->sentence_log;
+            if (r == 0) logs[i] = d->sentence_log + '\x1f' + d->chars_log + '\x1f' + std::to_string(d->total_bits);
             orc_decoder_free(d);
         }
     };

@@ -149,6 +149,8 @@ typedef struct orc_bench_cfg {
     float stops, lowpass_bw, lowpass_trans;
     int mathh_context, ungated, with_fft;
 } orc_bench_cfg;
+/* libm cross-check of the discriminator restatement the oracle uses (orc_atan2f.h): number of differing results; report only */
+size_t orc_atan2f_libm_mismatches(uint64_t seed, size_t n);
 double orc_bench_run(const orc_bench_cfg* cfg, const float* const* iq_per_thread, const uint32_t* chunk_idx, size_t nchunks,
                      size_t chunk, int repeats, int nthreads, char* sentences, size_t cap);
 

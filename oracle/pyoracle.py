@@ -471,4 +471,25 @@ def bench_run(streams, chunk_idx, chunk, repeats, *, fs, factor, baud, bits, sto
     buf = C.create_string_buffer(cap)
     dt = fn(C.byref(cfg), ptrs, idx.ctypes.data, len(idx), chunk, repeats, len(keep), buf, cap)
     parts = buf.value.decode("latin-1").split("\x1e")[:len(keep)]
-    return dt, [[s for s in p.split("\n") if s] for p in parts]
+    out = []
+    for p in parts:
+        f = (p.split("\x1f") + ["", "0"])[:3]
+        out.append(BenchLog([x for x in f[0].split("\n") if x], f[1], int(f[2] or 0)))
+    return dt, out
+
+
+class BenchLog(list):
+    """One stream's first-pass results of bench_run: the list itself is the sentence list; .chars is every printable character the
+    decoder emitted, .bits the number of symbols it produced."""
+    def __init__(self, sentences, chars, bits):
+        super().__init__(sentences)
+        self.chars, self.bits = chars, bits
+
+
+def atan2f_libm_mismatches(n=200000, seed=1):
+    """How many of n argument pairs this box's libm atan2f answers differently from the oracle's fdlibm restatement (0 on glibc 2.35)."""
+    lib = _load(HERE / "liboracle.so")
+    fn = lib.orc_atan2f_libm_mismatches
+    fn.restype = _sz
+    fn.argtypes = [C.c_uint64, _sz]
+    return int(fn(seed, n))

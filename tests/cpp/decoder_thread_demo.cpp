@@ -28,10 +28,14 @@ int main(int argc, char** argv)
     DECODER.lowpass_bw(argc > 7 ? (float)std::atof(argv[7]) : 1500.0f);
     DECODER.lowpass_trans(0.025f);
     DECODER.setupDecimationStagesFactor(1u << std::atoi(argv[3]));
-    size_t n_sent = 0;
+    size_t n_sent = 0, reentered = 0;
     DECODER.sentence_callback_ = [&](std::string callsign, std::string data, std::string crc) {
         std::printf("SENTENCE %s,%s*%s\n", callsign.c_str(), data.c_str(), crc.c_str());
         ++n_sent;
+        // what a GUI does from this callback: ask the decoder for its text and its state (no lock is held here, as in the reference)
+        const std::string last = DECODER.getLastSentence();
+        if (last == callsign + "," + data + "*" + crc && !DECODER.getRTTY().empty() && DECODER.getDecimationFactor() > 0) ++reentered;
+        (void)DECODER.getFrequencyCorrection();
     };
     std::string chars;
     DECODER.character_callback_ = [&](std::string c) { chars += c; };
@@ -54,7 +58,9 @@ int main(int argc, char** argv)
     const auto info = DECODER.getSpectrumInfo();
     std::printf("RTTY %s\n", DECODER.getRTTY().c_str());
     std::printf("LAST %s\n", DECODER.getLastSentence().c_str());
-    std::printf("INFO dec=%d fsd=%.3f bins=%zu spectrum=%zu peak_l=%d peak_r=%d samples=%zu sentences=%zu\n", DECODER.getDecimationFactor(),
-                DECODER.getDecimatedSamplingRate(), DECODER.getBinsCount(), info.size(), info.peak_left_, info.peak_right_, total, n_sent);
+    std::printf("INFO dec=%d fsd=%.3f bins=%zu spectrum=%zu peak_l=%d peak_r=%d samples=%zu sentences=%zu reentered=%zu\n", DECODER.getDecimationFactor(),
+                DECODER.getDecimatedSamplingRate(), DECODER.getBinsCount(), info.size(), info.peak_left_, info.peak_right_, total, n_sent, reentered);
+    // setupDecimationStagesBW (Decoder.h:336-412): smallest power-of-two division that reaches the rate; more than /256 is refused
+    std::printf("BW %zu %zu %zu\n", DECODER.setupDecimationStagesBW(fs / 10.0), DECODER.setupDecimationStagesBW(fs * 2.0), DECODER.setupDecimationStagesBW(fs / 1000.0));
     return 0;
 }

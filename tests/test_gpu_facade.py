@@ -39,3 +39,26 @@ def test_decoder_facade_on_iq_file(tmp_path, fs, dec, baud, bits, stops, lowpass
     assert got_last == o.text("last_sentence")
     info = [l for l in lines if l.startswith("INFO ")][-1]
     assert f"dec={1 << dec} " in info and "bins=4096" in info and f"samples={len(iq)} " in info
+    # every sentence callback asked the decoder for getLastSentence()/getRTTY() from inside the callback (no deadlock, right answers)
+    assert f"reentered={len(got_sent)}" in info
+    # setupDecimationStagesBW: fs/10 -> /16, 2*fs -> /1, fs/1000 -> more than /256: refused (0)
+    bw = [l for l in lines if l.startswith("BW ")][-1].split()
+    assert bw[1:] == ["16", "1", "0"]
+
+
+def test_facade_keeps_short_pushes_queued(tmp_path):
+    """A push shorter than the first decimation stage's history (undefined behaviour in the reference, refused by the engine) must
+    stay queued until the next push makes it long enough -- not be dropped: feeding the same file in odd-sized reads gives the same text."""
+    from habdec_amd.build import build_facade_demo
+    exe = build_facade_demo()
+    fs, baud = 2.048e6, 300
+    text = synth.make_sentence("SHORT", "7,52.1,21.4,100") * 2
+    iq = synth.fsk_iq_for_text(text, fs, baud, 8, 2, sigma=0.08, seed=12, idle_before=8, idle_after=14)
+    C = 65536
+    iq = iq[: (len(iq) // C) * C + 128]              # the last read of the demo is 128 samples: 2 x 64, shorter than the 211-sample history
+    path = tmp_path / "iq.cf32"
+    path.write_bytes(synth.to_iqfile_bytes(iq))
+    out = subprocess.run([str(exe), str(path), str(fs), "6", str(baud), "8", "2", "1500.0"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "habdec_amd:" not in out.stdout          # no engine error surfaced
+    assert len([l for l in out.stdout.splitlines() if l.startswith("SENTENCE ")]) == 2
