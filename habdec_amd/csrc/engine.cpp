@@ -117,6 +117,7 @@ struct hd_engine {
     bool no_fuse = false;      // HD_NO_FUSE: never use the fused back end (kernels/backend.hip); A/B measurements
     bool no_tail = false;      // HD_NO_TAIL: never use the one-wave stream tail (kernels/tail_body.h); A/B measurements
     int tail_lanes = 0;        // HD_TAIL_LANES: 64 / 256 lanes per stream in the tail kernel (0 = by batch size)
+    uint32_t tail_max_n2 = 2048;   // HD_TAIL_MAX_N2: most decimated samples per call for which the stream tail is used
     int last_fuse = -1;
     // Step mode (batch decoding, kernels/decimate.hip k_step): the stream tails of call k ride in the stage-1 launch of call k+1.
     struct PendingTail { bool valid = false; hd::TailArgs ta{}; int slot = 0; bool any_fft = false; int r2 = 0, t2 = 0; } pend;
@@ -290,6 +291,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     e->no_step = getenv("HD_NO_STEP") != nullptr;
     if (const char* v = getenv("HD_STEP_WGS")) e->step_wgs = (uint32_t)atoi(v);
     if (const char* v = getenv("HD_TAIL_LANES")) e->tail_lanes = atoi(v);
+    if (const char* v = getenv("HD_TAIL_MAX_N2")) e->tail_max_n2 = (uint32_t)strtoul(v, nullptr, 0);
     {
         hipDeviceProp_t prop;
         HD_HIP(hipGetDeviceProperties(&prop, cfg->device));
@@ -300,7 +302,6 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         e->dec_wgs_per_cu = cfg->pipeline ? 6u : 0u;
         if (const char* v = getenv("HD_DEC_WGS_PER_CU")) e->dec_wgs_per_cu = (uint32_t)atoi(v);
     }
-    HD_HIP(hipStreamCreateWithFlags(&e->qh, hipStreamNonBlocking));
     for (hipEvent_t* ev : {&e->ev_copy[0], &e->ev_copy[1], &e->ev_staging_free[0], &e->ev_staging_free[1]}) HD_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     if (e->one_stream) e->qb = e->qc = e->qa;
     else {
@@ -754,7 +755,9 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     // call in pieces, so neither the call size nor the tap count has to fit an LDS image.
     hd::TailArgs ta{};
     const int tail_lanes = e->tail_lanes ? e->tail_lanes : (S >= 2 * e->n_cus ? 64 : 256);
-    const bool tail = nst == 2 && !any_dc && !e->no_tail &&
+    // One wave per stream is the right shape while a call is short: its time grows with the decimated samples per call, and beyond
+    // ~2048 of them (e.g. /16 with 65536-sample pushes: 4096) the many-workgroup kernels finish a batch sooner (measured: 156 vs 173 GS/s).
+    const bool tail = nst == 2 && !any_dc && !e->no_tail && max_n2 <= e->tail_max_n2 &&
                       hd::tail_layout(ta, tail_lanes, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, 64 * 1024);
     const bool fuse = tail || (nst == 2 && !any_dc && !e->no_fuse && ((R2 == 2 && T2 == 69) || (R2 == 4 && T2 == 139)) &&
                       hd::backend_lds_bytes((int)T2, max_n1, max_n2, max_taps) <= 64 * 1024);
@@ -762,7 +765,8 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     // call's stage 1 with the previous call's stream tails in front (kernels/decimate.hip k_step).
     hd::TailArgs ta_step{};
     const bool step = tail && e->cfg.pipeline && !e->no_step && !e->one_stream && min_in == max_in && max_in && (R1 == 32 || R1 == 64) &&
-                      hd::tail_layout(ta_step, 64, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, hd::kStepLdsBytes);
+                      hd::step_lds_bytes((int)R1, (int)T1) &&
+                      hd::tail_layout(ta_step, 64, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, hd::step_lds_bytes((int)R1, (int)T1));
     const int path = step ? 3 : tail ? 2 : fuse ? 1 : 0;
     if (e->last_fuse >= 0 && e->last_fuse != path) {   // path switch: drain (a pending tail first)
         if (const int r = run_pending_tail(e)) return r;
@@ -972,6 +976,9 @@ int hd_process_host(hd_engine* e, const float* iq, size_t stride, const uint32_t
     // validate the sizes before anything is queued (hd_process_device checks the rest and leaves every stream untouched on error)
     for (uint32_t s = 0; s < e->S; ++s)
         if ((n_per_stream ? n_per_stream[s] : n_uniform) > e->cfg.max_chunk) return fail(HD_ERR_CAPACITY, "more samples than max_chunk");
+    // The copy stream is created on first use, AFTER the engine's compute streams: HIP deals streams to a handful of hardware queues in
+    // creation order, and a copy stream created in between put the two compute streams on one queue (their kernels took turns).
+    if (!e->qh) HD_HIP(hipStreamCreateWithFlags(&e->qh, hipStreamNonBlocking));
     const int j = (int)(e->host_calls & 1u);
     if (j == 1 && !e->staging2.p) {
         HD_HIP(e->staging2.alloc((size_t)e->S * e->cfg.max_chunk));

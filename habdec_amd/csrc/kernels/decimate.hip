@@ -468,6 +468,15 @@ bool launch_decimate(hipStream_t st, int ratio, int ntaps, uint32_t n_streams, u
     return false;
 }
 
+uint32_t step_lds_bytes(int ratio, int ntaps)
+{
+    auto sz = [](int f4) { return (uint32_t)(f4 > (int)(kStepLdsBytes / 16) ? f4 : (int)(kStepLdsBytes / 16)) * 16u; };
+    if (ratio == 32 && ntaps == 212) return sz(dec_tile_f4<32, 212, 64>());
+    if (ratio == 32 && ntaps == 174) return sz(dec_tile_f4<32, 174, 64>());
+    if (ratio == 64 && ntaps == 348) return sz(dec_tile_f4<64, 348, 64>());
+    return 0;
+}
+
 bool launch_step(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, uint32_t n_streams, uint32_t n_out, const float2* in, size_t in_stride,
                  const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
                  StreamCall* call_copy, uint32_t stage1_wgs, const TailArgs& ta, uint32_t n_tail)

@@ -1,0 +1,184 @@
+"""GPU parity at the sizes and launch shapes bench.py actually runs (all against the CPU oracle, through the C ABI):
+
+  a. the headline workload -- 1024 streams, 50 baud 7N2, bench.py's carrier-offset distribution (1/8 of the streams far off-tune: the
+     busy path of the symbol extractor) -- in batch mode, i.e. through the STEP kernel (stage 1 + the previous call's stream tails in
+     one launch), 16+ sampled streams incl. far-off ones: decimated / discriminator output bit-equal, bits, backlog, AFC per call,
+     then a stretch of calls with nothing in between (two calls in flight) and the text compared at the end;
+  b. the linear-split grid and the step kernels of the other single-wave first stages (/128: <32,174,64>, /256: <64,348,64>), which
+     need 2^20-sample pushes to reach the tile count that switches them on;
+  c. the classic grids of the 256-lane first stages at 1024 streams (/16: <8,54,256>, /4: <4,139,256>);
+  d. two engines in one process, driven by two threads at once, against the same engines run one after the other.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+from habdec_amd import synth
+
+pytestmark = pytest.mark.gpu
+C = 65536
+
+
+def same_bits(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def test_headline_workload_through_the_step_kernel():
+    torch = pytest.importorskip("torch")
+    import bench
+    import habdec_amd
+    from oracle import pyoracle
+    w = dict(bench.WORKLOADS["cfg4"])
+    S, fs = w["S"], w["fs"]
+    dev = torch.device("cuda", 0)
+    ring, ring_chunks, _ = bench.generate_ring(torch, dev, w, S, 0, seed=77)
+    # 7/8 of the streams are within +-200 Hz, every 8th is far off: sample both kinds (and the first / last stream of XCD blocks)
+    check = [0, 1, 2, 127, 128, 500, 511, 512, 640, 1000, 1022, 7, 15, 263, 775, 1023]
+    assert sum(1 for s in check if s % 8 == 7) >= 4 and len(set(check)) >= 16
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"],
+                            lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], pipeline=True)
+    orcs = {s: pyoracle.Decoder("oracle", factor=w["D"], baud=w["baud"], bits=w["bits"], stops=w["stops"], lowpass_bw=w["lp_bw"]) for s in check}
+    host = {s: ring[:, s].cpu().numpy().view(np.complex64).reshape(ring_chunks, C) for s in check}
+    n_checked, n_free = 12, 36
+    obits = {s: 0 for s in check}
+    for k in range(n_checked):                               # per-call comparison (each getter waits for the call: the tails run as their own launch)
+        eng.process_device(ring[k % ring_chunks].data_ptr(), C, C)
+        for s, o in orcs.items():
+            o(host[s][k % ring_chunks], fs)
+            assert same_bits(eng.decimated(s), o.array("last_decimated")), ("decimated", k, s)
+            assert same_bits(eng.demodulated(s), o.array("last_demod")), ("demod", k, s)
+            assert np.array_equal(eng.bits(s), o.bits()), ("bits", k, s)
+            obits[s] += len(o.bits())
+            assert eng.symbol_backlog(s) == o.symex_held(), ("backlog", k, s)
+            ga, oa = eng.afc(s), o.afc()
+            assert (ga["peak_l"], ga["peak_r"]) == (oa["peak_l"], oa["peak_r"]), ("peaks", k, s)
+            assert ga["correction"] == pytest.approx(oa["correction"], rel=1e-9, abs=1e-9), ("afc", k, s)
+    assert eng.timing()["path"] == 3                         # the step kernel is what ran
+    for k in range(n_checked, n_checked + n_free):           # free running: two calls in flight, tails inside the next call's launch
+        eng.process_device(ring[k % ring_chunks].data_ptr(), C, C)
+        for s, o in orcs.items():
+            o(host[s][k % ring_chunks], fs)
+            obits[s] += len(o.bits())
+    eng.flush()
+    busy = 0
+    for s, o in orcs.items():
+        assert eng.take_chars(s) == o.text("chars_log"), ("chars", s)
+        assert eng.rtty(s) == o.text("rtty_stream"), ("rtty", s)
+        assert eng.bits_total(s) == obits[s], ("symbols produced", s)
+        assert eng.symbol_backlog(s) == o.symex_held(), ("backlog", s)
+        assert same_bits(eng.demodulated(s), o.array("last_demod")), ("demod at the end", s)
+        busy += int(s % 8 == 7)
+    assert busy >= 4
+    eng.close()
+
+
+@pytest.mark.parametrize("factor,S,force_tail", [(256, 24, True), (256, 24, False), (128, 12, True), (128, 12, False)])
+def test_linear_split_and_step_kernels_of_the_other_single_wave_stages(monkeypatch, factor, S, force_tail):
+    """/256 = <64,348,64> + <4,139>, /128 = <32,174,64> + <4,139>: with 2^20-sample pushes the batch reaches the 6144 tiles that switch
+    the linear split on.  force_tail lifts the engine's call-size limit for the stream tail, so batch mode runs k_step<64,348,4,139> /
+    k_step<32,174,4,139>; without it the split feeds the separate back-half kernels."""
+    torch = pytest.importorskip("torch")
+    import habdec_amd
+    from oracle import pyoracle
+    if force_tail:
+        monkeypatch.setenv("HD_TAIL_MAX_N2", "1000000")
+    fs, CH = 2.048e6, 1 << 20
+    text = synth.make_sentence("LIN", "1,52.1,21.4,100")
+    iq1 = synth.fsk_iq_for_text(text, fs, 300, 8, 2, sigma=0.08, seed=21, idle_before=8, idle_after=12, chunk=CH)
+    nch = max(2, min(3, len(iq1) // CH))
+    need = nch * CH + 4096
+    if len(iq1) < need:
+        iq1 = np.concatenate([iq1, synth.fsk_iq(np.ones(4, np.uint8), fs, 300, sigma=0.08, seed=22, n_samples=need - len(iq1))])
+    shifts = (np.arange(S) * 173) % 4096
+    base = torch.from_numpy(np.ascontiguousarray(iq1).view(np.float32).reshape(-1, 2)).cuda()
+    slab = torch.empty((nch, S, CH, 2), dtype=torch.float32, device="cuda")
+    for s in range(S):
+        slab[:, s] = base[int(shifts[s]):int(shifts[s]) + nch * CH].view(nch, CH, 2)
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=CH, sampling_rate=fs, decimation=factor, pipeline=True)
+    check = (0, 1, S // 2, S - 1)
+    orcs = {s: pyoracle.Decoder("oracle", factor=factor) for s in check}
+    for k in range(nch):
+        eng.process_device(slab[k].data_ptr(), CH, CH)
+        eng.flush()
+        for s, o in orcs.items():
+            o(iq1[int(shifts[s]) + k * CH: int(shifts[s]) + (k + 1) * CH], fs)
+            assert same_bits(eng.decimated(s), o.array("last_decimated")), (k, s)
+            assert same_bits(eng.demodulated(s), o.array("last_demod")), (k, s)
+            assert np.array_equal(eng.bits(s), o.bits()), (k, s)
+    # (/128's tail windows need a little more LDS than its step workgroup has: there the forced tail runs as its own kernel)
+    assert eng.timing()["path"] == ((3 if factor == 256 else 2) if force_tail else 0)
+    for s, o in orcs.items():
+        assert eng.take_chars(s) == o.text("chars_log")
+    eng.close()
+
+
+@pytest.mark.parametrize("factor,fs,ungated", [(16, 2.5e6, False), (4, 2.048e6, True)])
+def test_classic_grids_of_the_256_lane_first_stages_at_1024_streams(factor, fs, ungated):
+    """/16 (<8,54,256> + <2,69,256>) and /4 (<4,139,256>) at the batch size the bench uses: 1024 streams x 65536 samples per call, every
+    stream its own delayed copy of one signal, sampled streams against the oracle bit for bit."""
+    torch = pytest.importorskip("torch")
+    import habdec_amd
+    from oracle import pyoracle
+    S = 1024
+    text = synth.make_sentence("GRID", "1,52.1,21.4,100")
+    iq1 = synth.fsk_iq_for_text(text, fs, 300, 8, 2, sigma=0.08, seed=31, idle_before=8, idle_after=12)
+    nch = min(4, len(iq1) // C - 1)
+    shifts = (np.arange(S) * 37) % 4096
+    base = torch.from_numpy(np.ascontiguousarray(iq1).view(np.float32).reshape(-1, 2)).cuda()
+    slab = torch.empty((nch, S, C, 2), dtype=torch.float32, device="cuda")
+    for s in range(S):
+        slab[:, s] = base[int(shifts[s]):int(shifts[s]) + nch * C].view(nch, C, 2)
+    kw = dict(lowpass_bw_hz=3000.0) if factor == 16 else {}
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=factor, ungated=ungated, **kw)
+    check = (0, 3, 255, 256, 700, 1023)
+    orcs = {s: pyoracle.Decoder("oracle", factor=factor, ungated=ungated, lowpass_bw=(3000.0 if factor == 16 else None)) for s in check}
+    for k in range(nch):
+        eng.process_device(slab[k].data_ptr(), C, C)
+        for s, o in orcs.items():
+            o(iq1[int(shifts[s]) + k * C: int(shifts[s]) + (k + 1) * C], fs)
+            assert same_bits(eng.decimated(s), o.array("last_decimated")), (k, s)
+            assert same_bits(eng.demodulated(s), o.array("last_demod")), (k, s)
+            assert np.array_equal(eng.bits(s), o.bits()), (k, s)
+            assert eng.symbol_backlog(s) == o.symex_held(), (k, s)
+    eng.close()
+
+
+def test_two_engines_in_one_process_on_two_threads():
+    """"one engine + HIP stream + host thread per device".  Two engines (different plans) fed concurrently by two host
+    threads must give what the same engines give when run one after the other -- nothing in the library is shared between engines
+    except read-only tables (and the per-thread error string)."""
+    import habdec_amd
+    fs = 2.048e6
+    S = 8
+    jobs = []
+    for j, (factor, baud, bits) in enumerate([(64, 300, 8), (16, 300, 8)]):
+        texts = [synth.make_sentence(f"T{j}S{s}", f"{s},52.{s},21.{j}") * 2 for s in range(S)]
+        nchunks = int(np.ceil((max(len(t) for t in texts) * (1 + bits + 2) + 40) * fs / baud / C)) + 1
+        iq = np.zeros((S, nchunks * C), np.complex64)
+        for s in range(S):
+            iq[s] = synth.fsk_iq(synth.rtty_bits(texts[s], bits, 2, 6 + s, 10), fs, baud, sigma=0.08, seed=100 * j + s, n_samples=nchunks * C)
+        jobs.append((factor, baud, bits, iq))
+
+    def run(job, out, pipeline):
+        factor, baud, bits, iq = job
+        eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=factor, baud=baud, rtty_bits=bits, rtty_stops=2, pipeline=pipeline)
+        for k in range(iq.shape[1] // C):
+            eng.process_host(np.ascontiguousarray(iq[:, k * C:(k + 1) * C]))
+        eng.flush()
+        out.append([(eng.take_chars(s), eng.take_sentences(s), eng.rtty(s), eng.symbol_backlog(s), eng.demodulated(s).tobytes()) for s in range(S)])
+        eng.close()
+
+    for pipeline in (False, True):
+        serial = [[], []]
+        for j in range(2):
+            run(jobs[j], serial[j], pipeline)
+        threaded = [[], []]
+        th = [threading.Thread(target=run, args=(jobs[j], threaded[j], pipeline)) for j in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert threaded == serial
+        assert all(len(x[1]) >= 1 for x in serial[0][0])          # (sentences were decoded at all)
