@@ -383,10 +383,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (blockIdx.x < n_tail) {
         // the tails are latency chains with nobody to hide behind; the stage-1 waves beside them are waiting for HBM most of the
         // time and lose nothing when the arbiter prefers the tail
-        __builtin_amdgcn_s_setprio(3);
+#ifndef HD_STEP_PRIO
+#define HD_STEP_PRIO 3
+#endif
+        __builtin_amdgcn_s_setprio(HD_STEP_PRIO);
         tail_body<64, 4, D2, T2>(ta, blockIdx.x, reinterpret_cast<unsigned char*>(tile4));
         return;
     }
+#ifdef HD_STEP_S1_PRIO
+    __builtin_amdgcn_s_setprio(HD_STEP_S1_PRIO);
+#endif
     decimate_body<D, T, 64>(in, in_stride, hist_in, hist_out, taps, out, out_stride, call, 0, 0, 0u, 0u, nullptr, n_streams, lin_ntiles, call_copy,
                             blockIdx.x - n_tail, 0u, gridDim.x - n_tail, tile4);
 }
