@@ -110,6 +110,14 @@ HOST_API = {
     "hd_host_parse_sentence": (_int, [C.c_char_p, _vp]),
     "hd_host_timestamp_from_hms": (_sz, [C.c_int64, _int, _int, _f, C.c_char_p, _sz]),
     "hd_host_gps_distance": (None, [_dbl] * 6 + [C.POINTER(_dbl)]),
+    "hd_host_sondehub_new": (_vp, [C.c_char_p, C.c_char_p]),
+    "hd_host_sondehub_free": (None, [_vp]),
+    "hd_host_sondehub_push_sentence": (_int, [_vp, _u32, C.c_char_p, C.c_char_p, C.c_int64]),
+    "hd_host_sondehub_push": (_int, [_vp, C.c_char_p, C.c_char_p, C.c_char_p, _int, _f, _f, _f]),
+    "hd_host_sondehub_size": (_sz, [_vp]),
+    "hd_host_sondehub_take": (_sz, [_vp, C.c_int64, C.c_char_p, _sz, C.POINTER(_sz)]),
+    "hd_host_utc_iso": (_sz, [C.c_int64, C.c_char_p, _sz]),
+    "hd_host_json_number": (_sz, [_dbl, C.c_char_p, _sz]),
     "hd_host_iqfiles_open": (_vp, [C.POINTER(C.c_char_p), C.c_uint32, _int, C.c_uint32, C.c_uint32, _dbl]),
     "hd_host_iqfiles_close": (None, [_vp]),
     "hd_host_iqfiles_streams": (C.c_uint32, [_vp]),

@@ -9,6 +9,7 @@
 #include "host/fir_design.hpp"
 #include "host/gui_payload.hpp"
 #include "host/telemetry.hpp"
+#include "host/sondehub.hpp"
 #include "host/text_stage.hpp"
 #include "host/iq_file_batch.hpp"
 #include "kernels/exact_math.h"
@@ -174,6 +175,51 @@ void hd_host_gps_distance(double lat1, double lon1, double alt1, double lat2, do
 {
     const auto d = hd::telemetry::gps_distance(lat1, lon1, alt1, lat2, lon2, alt2);
     out[0] = d.line; out[1] = d.circle; out[2] = d.radians; out[3] = d.elevation_deg; out[4] = d.bearing_deg;
+}
+
+/* ---- sondehub upload batch (sondehub_uploader.cpp:14-69, main.cpp:286-306; see host/sondehub.hpp) ---- */
+struct hd_host_sondehub {
+    hd::SondehubBatch b;
+    std::string pending;      // a body that did not fit the caller's buffer: handed out again by the next take
+    size_t pending_n = 0;
+    hd_host_sondehub(const char* u, const char* v) : b(u ? u : "", v ? v : "") {}
+};
+hd_host_sondehub* hd_host_sondehub_new(const char* uploader_callsign, const char* software_version) { return new hd_host_sondehub(uploader_callsign, software_version); }
+void hd_host_sondehub_free(hd_host_sondehub* h) { delete h; }
+int hd_host_sondehub_push_sentence(hd_host_sondehub* h, uint32_t stream, const char* callsign, const char* data, int64_t now_unix_ns)
+{
+    if (!h || !callsign || !data) return -1;
+    return h->b.push_sentence(stream, callsign, data, now_unix_ns);
+}
+int hd_host_sondehub_push(hd_host_sondehub* h, const char* payload_callsign, const char* time_received, const char* datetime, int frame, float lat, float lon, float alt)
+{
+    if (!h || !payload_callsign || !time_received || !datetime) return -1;
+    hd::SondeRecord r;
+    r.payload_callsign = payload_callsign; r.time_received = time_received; r.datetime = datetime; r.frame = frame; r.lat = lat; r.lon = lon; r.alt = alt;
+    h->b.push(r);
+    return 1;
+}
+size_t hd_host_sondehub_size(const hd_host_sondehub* h) { return h ? h->b.size() : 0; }
+size_t hd_host_sondehub_take(hd_host_sondehub* h, int64_t now_unix_ns, char* out, size_t cap, size_t* n_records)
+{
+    if (!h) return 0;
+    if (h->pending.empty()) h->pending = h->b.take(now_unix_ns, &h->pending_n);
+    const size_t n = h->pending.size();
+    if (n_records) *n_records = h->pending_n;
+    if (out && cap > n) { std::memcpy(out, h->pending.data(), n); out[n] = 0; h->pending.clear(); h->pending_n = 0; }
+    return n;
+}
+size_t hd_host_utc_iso(int64_t unix_ns, char* buf, size_t cap)
+{
+    const std::string s = hd::utc_iso_ns(unix_ns);
+    if (buf && cap) { const size_t n = std::min(cap - 1, s.size()); std::memcpy(buf, s.data(), n); buf[n] = 0; }
+    return s.size();
+}
+size_t hd_host_json_number(double v, char* buf, size_t cap)
+{
+    const std::string s = hd::json_number(v);
+    if (buf && cap) { const size_t n = std::min(cap - 1, s.size()); std::memcpy(buf, s.data(), n); buf[n] = 0; }
+    return s.size();
 }
 
 /* ---- batched cf32 file ingest (IQSource_File.h:124-172 per file; see host/iq_file_batch.hpp) ---- */

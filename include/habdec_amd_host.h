@@ -84,6 +84,24 @@ size_t hd_host_timestamp_from_hms(int64_t now_unix, int hour, int minute, float 
 /* CalcGpsDistance (GpsDistance.cpp:21-84): out = {line distance m, great-circle distance m, angle rad, elevation deg, bearing deg} */
 void hd_host_gps_distance(double lat1, double lon1, double alt1, double lat2, double lon2, double alt2, double out[5]);
 
+/* ---- sondehub upload batch (last hop): the JSON body of SondeHubUploader::upload (sondehub_uploader.cpp:31-69) ----
+ * Any number of threads push (one record per CRC-valid sentence: what SentenceCallback does, websocketServer/main.cpp:286-306 --
+ * habdec::parse_sentence, time_received = utc_now_iso()); one thread takes the batch: a JSON array with the reference's eleven fields per
+ * record, serialised byte for byte like its nlohmann::json (keys sorted, compact, Grisu2 shortest floats, alt as int).  The HTTP PUT
+ * itself is the application's.  Clocks are passed in (nanoseconds since the epoch, UTC), so results are reproducible. */
+typedef struct hd_host_sondehub hd_host_sondehub;
+hd_host_sondehub* hd_host_sondehub_new(const char* uploader_callsign, const char* software_version /* first 7 characters are used */);
+void hd_host_sondehub_free(hd_host_sondehub*);
+/* 1 = queued; 0 = dropped like the reference does (fewer than six fields, no GPS fix, bad time); -1 = the reference would throw (stoi / stof) */
+int hd_host_sondehub_push_sentence(hd_host_sondehub*, uint32_t stream, const char* callsign, const char* data, int64_t now_unix_ns);
+int hd_host_sondehub_push(hd_host_sondehub*, const char* payload_callsign, const char* time_received, const char* datetime, int frame,
+                          float lat, float lon, float alt);                                   /* SondeHubUploader::push of a ready MinTelemetry */
+size_t hd_host_sondehub_size(const hd_host_sondehub*);
+/* Body size in bytes (0 = queue empty); written NUL-terminated to out when cap > size, and only then is the batch consumed. */
+size_t hd_host_sondehub_take(hd_host_sondehub*, int64_t now_unix_ns, char* out, size_t cap, size_t* n_records);
+size_t hd_host_utc_iso(int64_t unix_ns, char* buf, size_t cap);                              /* utc_now_iso() (common/utc_now_iso.cpp:7-22) at a given instant */
+size_t hd_host_json_number(double v, char* buf, size_t cap);                                 /* how the body prints a float field */
+
 /* ---- batched cf32 file ingest: S IQ files -> one push slab per round ----
  * Each file is an IQSource_File<float> (IQSource_File.h:124-172): raw interleaved float32 I,Q, no header; a read returns
  * what is left, the end of file is noticed by the read that runs into it, and the NEXT read rewinds when `loop` (else

@@ -53,7 +53,7 @@ def main():
         wr = statistics.median(write.get(k, [0.0])) * KB
         table[k] = {"launches": len(fetch.get(k, [])), "fetch_bytes": round(fr), "write_bytes": round(wr), "hbm_bytes": round(fr + wr)}
     (dst / f"{rnd}_pmc_traffic.json").write_text(json.dumps(table, indent=1) + "\n")
-    front = max((k for k in table if k.startswith("k_decimate")), key=lambda k: table[k]["hbm_bytes"])
+    front = max((k for k in table if k.startswith("k_decimate") or k.startswith("k_step")), key=lambda k: table[k]["hbm_bytes"])
     tf = dst / "traffic.json"
     cur = json.loads(tf.read_text()) if tf.exists() else {}
     cur[workload] = {"front_kernel": front, "front_kernel_hbm_bytes_per_launch": table[front]["hbm_bytes"],

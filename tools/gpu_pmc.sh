@@ -1,12 +1,12 @@
 #!/bin/bash
-# Run ON the GPU box: one PMC pass of a bench invocation; prints per-kernel averages of the requested counters.
+# Run ON the GPU box: one PMC pass of a bench invocation; prints per-kernel medians of the requested counters for the hd:: kernels.
 # Usage: tools/gpu_pmc.sh <tag> "<counters>" [bench args...]
 tag=$1; ctr=$2; shift; shift
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/pmc_$tag
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-timeout 300 rocprofv3 --pmc $ctr --output-format csv -d $out -o pmc -- python3 $root/bench.py --no-cpu-baseline "$@" > $out/bench.json 2> $out/err.log
+timeout 300 rocprofv3 --pmc $ctr --output-format csv -d $out -o pmc -- python3 $root/bench.py --no-cpu-baseline --no-also "$@" > $out/bench.json 2> $out/err.log
 python3 - <<P
 import csv,glob,re,collections
 f=glob.glob('$out/**/*counter_collection.csv',recursive=True)
@@ -17,6 +17,8 @@ for r in csv.DictReader(open(f[0])):
     if not m: continue
     acc[m.group(1)+(m.group(2) or '')][r['Counter_Name']].append(float(r['Counter_Value']))
 for k,v in acc.items():
-    if not (k.startswith('k_tail') or k.startswith('k_step') or k.startswith('k_decimate<32')): continue
-    print(k, {c: round(sorted(x)[len(x)//2]) for c,x in v.items()}, 'launches', len(next(iter(v.values()))))
+    n=len(next(iter(v.values())))
+    if n < 5: continue
+    print(k, {c: round(sorted(x)[len(x)//2]) for c,x in v.items()}, 'launches', n)
 P
+rm -rf $out/*/*counter_collection.csv $out/*counter_collection.csv 2>/dev/null
