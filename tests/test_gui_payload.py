@@ -102,3 +102,15 @@ def test_payloads_from_a_live_engine():
     d = eng.demodulated(0)
     got, sent = ours_demod(L, d, 256, 2)
     assert sent == 256 and len(got) == 20 + 512
+    # the 8- and 16-bit modes of CompressedVector (CompressedVector.cpp:75-118) on live data: what the web client decodes from the bytes
+    # (min + q / (2^bits - 1) * (max - min), the header carries min and max) is the thinned getter values to within one quantisation step
+    for ts in (1, 2):
+        got, sent = ours_spectrum(L, p, a["peak_l"], a["peak_r"], 0.5, 512, ts)
+        assert sent == 512 and len(got) == 52 + 512 * ts
+        thin = mid[(np.arange(512, dtype=np.float32) / np.float32(512) * np.float32(mid.size)).astype(np.int64)]
+        q = np.frombuffer(got[52:], np.uint8 if ts == 1 else np.uint16).astype(np.float64)
+        lo, hi = float(thin.min()), float(thin.max())
+        back = lo + q / (2 ** (8 * ts) - 1) * (hi - lo)
+        assert np.max(np.abs(back - thin)) <= (hi - lo) / (2 ** (8 * ts) - 1) * 1.01
+        got, sent = ours_demod(L, d, 256, ts)
+        assert sent == 256 and len(got) == 20 + 256 * ts

@@ -120,3 +120,61 @@ def test_ingest_run_decodes_like_direct_feeding(tmp_path, pipeline):
     assert eng.ingest(src) == total
     assert [eng.take_sentences(s) for s in range(S)] == want
     assert eng.rtty(0) == ref.rtty(0)
+
+
+@pytest.mark.gpu
+def test_ingest_sentences_equal_the_oracle_fed_like_the_reference_feeds_its_decoder(tmp_path):
+    """The batched ingest against the ORACLE (not against the same engine fed by hand): every file read in 65536-sample requests like
+    IQSource_File::get, pushed and processed per round like DECODER_THREAD does (main.cpp:234-245); the engine's sentences, characters
+    and text must equal the oracle's stream by stream.  One file ends in a tail shorter than the first stage's history (the engine
+    holds that back instead of failing the batch; the tail is idle carrier, so the text is unaffected)."""
+    import habdec_amd
+    from habdec_amd import synth
+    from oracle import pyoracle
+    fs, D, C, S = 2.048e6, 64, 65536, 5
+    iq, paths = [], []
+    for s in range(S):
+        text = synth.make_sentence(f"ING{s}", f"{s},52.{s},21.{s}") * 2
+        x = synth.fsk_iq(synth.rtty_bits(text, 8, 2, 4 + s, 6), fs, 300, seed=40 + s, sigma=0.06).astype(np.complex64)
+        x = x[:(len(x) // C) * C + (100 if s == 1 else 3000 * s + 5000)]      # file 1 ends with a 100-sample read
+        iq.append(x)
+        p = tmp_path / f"g{s}.cf32"
+        x.tofile(p); paths.append(p)
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=D, pipeline=True)
+    done = eng.ingest(habdec_amd.IqFiles(paths, chunk=C, granule=D))
+    assert done > 0
+    for s in range(S):
+        o = pyoracle.Decoder("oracle", factor=D)
+        f = RefFile(iq[s], False)
+        while True:
+            got = f.get(C)
+            if not len(got):
+                break
+            if len(got) >= 2176:                                    # (pushes shorter than the stage histories are undefined behaviour in the
+                o(got, fs)                                          #  reference: the engine holds them back, the oracle is not given them)
+        assert eng.take_sentences(s) == o.sentences(), s
+        assert len(o.sentences()) == 2
+        assert eng.take_chars(s) == o.text("chars_log"), s
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_ingest_keeps_looping_files_going_and_resumes_after_max_rounds(tmp_path):
+    """Looping files of equal length, a whole number of chunks long: the reference's source returns one empty read before every rewind
+    (IQSource_File.h:141-155), so every stream is empty in the same round -- that must not end a looping ingest; and a run bounded
+    by max_rounds must leave the files where a second run continues seamlessly (nothing read ahead and dropped)."""
+    import habdec_amd
+    from habdec_amd import synth
+    fs, D, C, S = 2.048e6, 64, 65536, 3
+    paths, n_chunks = [], 3
+    for s in range(S):
+        x = synth.fsk_iq(np.ones(8, np.uint8), fs, 300, seed=70 + s, sigma=0.05, n_samples=n_chunks * C).astype(np.complex64)
+        p = tmp_path / f"l{s}.cf32"
+        x.tofile(p); paths.append(p)
+    src = habdec_amd.IqFiles(paths, chunk=C, granule=D, loop=True)
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=D, pipeline=True)
+    # rounds 0-2 deliver the file, round 3 is the empty read, rounds 4-6 the file again, round 7 empty, ...
+    assert eng.ingest(src, max_rounds=5) == S * C * 4
+    assert eng.ingest(src, max_rounds=6) == S * C * 5                # chunks 1, 2, the empty read, chunks 0, 1, 2: nothing was read ahead and dropped in between
+    assert all(src.rewinds(s) == 2 for s in range(S))
+    eng.close()

@@ -115,3 +115,42 @@ def test_number_formatting_against_the_reference_library_directly(L):
         L.hd_host_json_number(float(v), b, 64)
         bad += a.value != b.value
     assert bad == 0
+
+
+@pytest.mark.gpu
+def test_decoded_sentences_of_a_batch_become_one_upload_body(L):
+    """End of the path: GPU engine -> sentence callback -> sondehub batch.  The records of the body are exactly the CRC-valid sentences
+    the CPU oracle decodes from the same streams (callsign, frame, position, altitude), in delivery order per stream."""
+    import habdec_amd
+    from habdec_amd import synth
+    from oracle import pyoracle
+    fs, S, Cn = 2.048e6, 8, 65536
+    texts = [synth.make_sentence(f"SONDE{s}", f"{10 + s},12:{s:02d}:30,52.{1000 + s},21.{4000 + s},{1500 + 10 * s}") * 2 for s in range(S)]
+    n = int(np.ceil((max(len(t) for t in texts) * 11 + 40) * fs / 300 / Cn)) + 1
+    iq = np.stack([synth.fsk_iq(synth.rtty_bits(texts[s], 8, 2, 6 + s, 10), fs, 300, sigma=0.07, seed=300 + s, n_samples=n * Cn) for s in range(S)])
+    h = L.hd_host_sondehub_new(b"GPUBOX", b"0123456789")
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=Cn, sampling_rate=fs, decimation=64, pipeline=True)
+    now = 1614861296 * 10 ** 9
+    eng.on_sentence(lambda s, call, data, crc: L.hd_host_sondehub_push_sentence(h, s, call.encode(), data.encode(), now))
+    for k in range(n):
+        eng.process_host(np.ascontiguousarray(iq[:, k * Cn:(k + 1) * Cn]))
+    eng.flush()
+    want = []
+    for s in range(S):
+        o = pyoracle.Decoder("oracle", factor=64)
+        for k in range(n):
+            o(iq[s, k * Cn:(k + 1) * Cn], fs)
+        want += [x for x in o.sentences()]
+    assert len(want) == 2 * S
+    cnt = C.c_size_t(0)
+    need = L.hd_host_sondehub_take(h, now + 1, None, 0, C.byref(cnt))
+    buf = C.create_string_buffer(need + 1)
+    L.hd_host_sondehub_take(h, now + 1, buf, len(buf), C.byref(cnt))
+    recs = json.loads(buf.value.decode())
+    assert len(recs) == len(want)
+    got = sorted(f'{r["payload_callsign"]},{r["frame"]},{r["alt"]}' for r in recs)
+    exp = sorted(f'{x.split(",")[0]},{x.split(",")[1]},{x.split(",")[5].split("*")[0]}' for x in want)
+    assert got == exp
+    assert all(r["datetime"].startswith("2021-03-04T12:0") and abs(r["lat"] - 52.1) < 0.1 for r in recs)
+    L.hd_host_sondehub_free(h)
+    eng.close()
