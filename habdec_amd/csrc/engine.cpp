@@ -682,7 +682,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
 
     // ---- host mirror of the reference's size bookkeeping -> one StreamCall per stream
     uint32_t max_in = 0, min_in = 0xFFFFFFFFu, max_n1 = 0, max_n2 = 0, max_m = 0, max_taps = 0, max_new = 0, max_pend = 0;
-    bool any_fft = false, any_dc = false;
+    bool any_fft = false, any_dc = false, any_zero1 = false;
     uint64_t total_in = 0;
     for (uint32_t s = 0; s < S; ++s) {
         StreamHost& st = e->st[s];
@@ -739,6 +739,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         sl.h_call.p[s] = c;
         max_in = std::max(max_in, n); min_in = std::min(min_in, n); max_n1 = std::max(max_n1, c.n1); max_n2 = std::max(max_n2, c.n2);
         any_dc |= c.dc_remove != 0;
+        any_zero1 |= c.zero_hist1 != 0;
         total_in += n;
     }
     sl.total_in = total_in;
@@ -842,7 +843,8 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
         const uint32_t wgs = e->step_wgs ? e->step_wgs : 32u * e->n_cus;   // short runs of tiles: the dispatcher evens out the tail of the launch
         if (!hd::launch_step(qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, max_n1, iq, stride, e->hist1[hin].p,
-                             e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, wgs, prev.ta, prev.valid ? S : 0u))
+                             e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, wgs, prev.ta, prev.valid ? S : 0u,
+                             any_zero1 ? 0u : max_in))
             return fail(HD_ERR_INVALID, "no step kernel for this decimation plan");
         if (sl.timed) HD_HIP(hipEventRecord(sl.t2, qa));
         if (ps) {

@@ -68,7 +68,9 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
                                               const StreamCall* __restrict__ call, int stage, int final_stage,
                                               uint32_t fir_hist_cap, uint32_t tiles_per_wg, float2* __restrict__ fft_in,
                                               uint32_t n_streams, uint32_t lin_ntiles, StreamCall* __restrict__ call_copy,
-                                              const uint32_t bx, const uint32_t by, const uint32_t gdx, float4* __restrict__ tile4)
+                                              const uint32_t bx, const uint32_t by, const uint32_t gdx, float4* __restrict__ tile4,
+                                              const uint32_t uniform_n = 0 /* != 0: every stream brings this many samples and none restarts its history:
+                                                                             the per-stream parameter block need not be read (it may sit across PCIe) */)
 {
     constexpr int OPL = dec_opl<D>();              // outputs per lane
     constexpr int TOUT = TO * OPL;                 // outputs per tile
@@ -101,7 +103,9 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
     } else {
         s = by; first = bx * tiles_per_wg; count = tiles_per_wg;
     }
-    CallHead c = *reinterpret_cast<const CallHead*>(call + s);
+    CallHead c{};
+    if (uniform_n) { c.n_in = c.n1 = uniform_n; }            // (a workgroup's first tile is requested without waiting for a parameter fetch)
+    else c = *reinterpret_cast<const CallHead*>(call + s);
     const uint32_t n = stage == 0 ? c.n_in : c.n1;          // (linear: the same for every stream)
     const uint32_t nout = n / D;
     const uint32_t ntiles = (nout + TOUT - 1) / TOUT;
@@ -178,8 +182,14 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
     uint32_t tile_i = first;                                // tile of stream s being computed; pf_* run one tile ahead
     // The call's parameters live in mapped host memory; whoever owns a stream's first tile leaves a device copy for the kernels
     // that read them later (the stream tail of this call runs inside the NEXT call's launch).
+    // (The read crosses PCIe: it is requested here and stored a tile later, so nothing waits for it.)
+    uint4 cpy = make_uint4(0, 0, 0, 0);
+    uint32_t cpy_s = 0xFFFFFFFFu;
     auto leave_copy = [&](uint32_t sc) {
-        if (call_copy && threadIdx.x < 4) reinterpret_cast<uint4*>(call_copy + sc)[threadIdx.x] = reinterpret_cast<const uint4*>(call + sc)[threadIdx.x];
+        if (call_copy) { cpy_s = sc; if (threadIdx.x < 4) cpy = reinterpret_cast<const uint4*>(call + sc)[threadIdx.x]; }
+    };
+    auto flush_copy = [&]() {
+        if (cpy_s != 0xFFFFFFFFu) { if (threadIdx.x < 4) reinterpret_cast<uint4*>(call_copy + cpy_s)[threadIdx.x] = cpy; cpy_s = 0xFFFFFFFFu; }
     };
     if (first == 0) leave_copy(s);
     for (uint32_t done = 0; done < count; ++done) {
@@ -195,11 +205,12 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
         __syncthreads();
         DSTAMP(1);
         store_prev();
+        if (done) flush_copy();
         if (done + 1 < count) {                             // the next tile's loads stay in flight while this tile is computed
             uint32_t pf_tile = tile_i + 1;
             if (linear && pf_tile == ntiles) {              // ... across the seam into the next stream
                 pf_tile = 0; ++pf_s;
-                c_next = *reinterpret_cast<const CallHead*>(call + pf_s);
+                if (!uniform_n) c_next = *reinterpret_cast<const CallHead*>(call + pf_s);
                 pf_zero_hist = (stage == 0 ? c_next.zero_hist1 : c_next.zero_hist2) != 0;
             }
             load_tile(pf_tile);
@@ -348,6 +359,7 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
         }
     }
     store_prev();
+    flush_copy();
     DSTAMP_WRITE();
 }
 
@@ -376,7 +388,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                    const float* __restrict__ taps,
                                                    float2* __restrict__ out, size_t out_stride,
                                                    const StreamCall* __restrict__ call, uint32_t n_streams, uint32_t lin_ntiles,
-                                                   StreamCall* __restrict__ call_copy, const TailArgs ta, const uint32_t n_tail)
+                                                   StreamCall* __restrict__ call_copy, const TailArgs ta, const uint32_t n_tail,
+                                                   const uint32_t uniform_n)
 {
     constexpr int kF4 = dec_tile_f4<D, T, 64>() > (int)(kStepLdsBytes / 16) ? dec_tile_f4<D, T, 64>() : (int)(kStepLdsBytes / 16);
     __shared__ float4 tile4[kF4];
@@ -394,7 +407,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     __builtin_amdgcn_s_setprio(HD_STEP_S1_PRIO);
 #endif
     decimate_body<D, T, 64>(in, in_stride, hist_in, hist_out, taps, out, out_stride, call, 0, 0, 0u, 0u, nullptr, n_streams, lin_ntiles, call_copy,
-                            blockIdx.x - n_tail, 0u, gridDim.x - n_tail, tile4);
+                            blockIdx.x - n_tail, 0u, gridDim.x - n_tail, tile4, uniform_n);
 }
 
 __global__ void k_passthrough(const float2* __restrict__ in, size_t in_stride, float2* __restrict__ out, size_t out_stride,
@@ -485,13 +498,13 @@ uint32_t step_lds_bytes(int ratio, int ntaps)
 
 bool launch_step(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, uint32_t n_streams, uint32_t n_out, const float2* in, size_t in_stride,
                  const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
-                 StreamCall* call_copy, uint32_t stage1_wgs, const TailArgs& ta, uint32_t n_tail)
+                 StreamCall* call_copy, uint32_t stage1_wgs, const TailArgs& ta, uint32_t n_tail, uint32_t uniform_n)
 {
 #define HD_STEP_CASE(D, T, D2, T2)                                                                                                    \
     if (ratio == D && ntaps == T && ratio2 == D2 && ntaps2 == T2) {                                                                   \
         const uint32_t ntiles = (n_out + 63) / 64;                                                                                    \
         hipLaunchKernelGGL((k_step<D, T, D2, T2>), dim3(n_tail + stage1_wgs), dim3(64), 0, st, in, in_stride, hist_in, hist_out, taps, out, \
-                           out_stride, call, n_streams, ntiles, call_copy, ta, n_tail);                                               \
+                           out_stride, call, n_streams, ntiles, call_copy, ta, n_tail, uniform_n);                                    \
         return true;                                                                                                                  \
     }
     HD_STEP_CASE(32, 212, 2, 69) HD_STEP_CASE(32, 174, 4, 139) HD_STEP_CASE(64, 348, 4, 139)
