@@ -181,7 +181,7 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"],
                             rtty_stops=w["stops"], lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"],
                             device=local_rank, pipeline=not sync)
-    eng.set_timing(4)
+    eng.set_timing(8)          # HIP-event brackets on every 8th call: each record is a barrier packet worth microseconds of queue time
     base = ring.data_ptr()
 
     def step(i):
@@ -202,7 +202,7 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     for i in range(W, W + K):
         step(i)
         t = eng.timing()
-        if t["timed_calls"] != seen:          # the engine brackets every 4th call with HIP events (each record costs queue time)
+        if t["timed_calls"] != seen:          # (a call that carried the HIP-event brackets)
             seen = t["timed_calls"]
             front_ms.append(t["ms_front"])
             total_ms.append(t["ms_total"])
