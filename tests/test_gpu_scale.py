@@ -182,3 +182,43 @@ def test_two_engines_in_one_process_on_two_threads():
             t.join()
         assert threaded == serial
         assert all(len(x[1]) >= 1 for x in serial[0][0])          # (sentences were decoded at all)
+
+
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_long_idle_backlog_vent_and_parameter_change(pipeline):
+    """What a stream does between transmissions: an idle carrier produces no flip points, the symbol extractor's backlog grows call by call
+    until the reference's vent drops it (more than 30000 samples held, SymbolExtractor.h:116-120); a baud change in that state makes
+    every cached window sum stale (the whole backlog is recomputed in one call).  Bits and backlog per call against the oracle, through
+    the stream-tail kernel (synchronous) and through the step kernel (batch mode)."""
+    import habdec_amd
+    from oracle import pyoracle
+    fs, S = 2.048e6, 3
+    ncalls = 64
+    text = synth.make_sentence("V", "1") * 2                         # 22 characters: 0.8 s at 300 baud
+    frame = synth.rtty_bits(text, 8, 2, 4, 4)
+    iq = np.zeros((S, ncalls * C), np.complex64)
+    idle_bits = int(36 * C * 300 / fs)
+    iq[0] = synth.fsk_iq(np.concatenate([np.ones(idle_bits, np.uint8), frame]), fs, 300, sigma=0.02, seed=1, n_samples=ncalls * C)   # idle, then a sentence
+    iq[1] = synth.fsk_iq(frame, fs, 300, sigma=0.02, seed=2, n_samples=ncalls * C)                                                  # a sentence, then idle for good
+    iq[2] = synth.fsk_iq(np.ones(8, np.uint8), fs, 300, sigma=0.02, seed=3, n_samples=ncalls * C)                                   # idle throughout, baud changed on the way
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=64, pipeline=pipeline)
+    orcs = [pyoracle.Decoder("oracle", factor=64) for _ in range(S)]
+    peak = 0
+    for k in range(ncalls):
+        if k in (20, 31):
+            b = 50.0 if k == 20 else 300.0
+            eng.set_baud(2, b); orcs[2].set_baud(b)
+        eng.process_host(np.ascontiguousarray(iq[:, k * C:(k + 1) * C]))
+        eng.flush()
+        for s in range(S):
+            orcs[s](iq[s, k * C:(k + 1) * C], fs)
+            assert np.array_equal(eng.bits(s), orcs[s].bits()), ("bits", k, s)
+            assert eng.symbol_backlog(s) == orcs[s].symex_held(), ("backlog", k, s)
+            assert same_bits(eng.demodulated(s), orcs[s].array("last_demod")), ("demod", k, s)
+        peak = max(peak, eng.symbol_backlog(0))
+    assert peak > 30000                                             # stream 0's backlog did reach the vent
+    assert eng.take_sentences(0) == orcs[0].sentences() and len(orcs[0].sentences()) >= 1       # decoded after the vent
+    assert eng.take_sentences(1) == orcs[1].sentences() and len(orcs[1].sentences()) >= 1
+    for s in range(S):
+        assert eng.take_chars(s) == orcs[s].text("chars_log")
+    eng.close()
