@@ -8,6 +8,13 @@ ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
+# PyTorch ships its own copy of the HIP runtime; libhabdec_amd.so links the system one.  Whichever is loaded first serves the whole process, and
+# torch finds no GPU when the system copy came first -- so where both are used (the GPU tests stage inputs with torch), torch is imported first.
+try:
+    import torch  # noqa: F401
+except Exception:      # the CPU-only suite does not need it
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
