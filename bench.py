@@ -176,11 +176,13 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     w = dict(WORKLOADS[name])
     S = S or w["S"]
     C = w["C"]
-    ring, ring_chunks, texts = generate_ring(torch, dev, w, S, rank, seed=1234 + rank)
-    K = K or ring_chunks
+    # (the engine first -- allocations, rocFFT plan, code objects: host-side work during which the GPU idles -- then the synthetic ring, whose
+    # generation keeps the GPU busy right up to the warm-up steps)
     eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"],
                             rtty_stops=w["stops"], lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"],
                             device=local_rank, pipeline=not sync)
+    ring, ring_chunks, texts = generate_ring(torch, dev, w, S, rank, seed=1234 + rank)
+    K = K or ring_chunks
     eng.set_timing(8)          # HIP-event brackets on every 8th call: each record is a barrier packet worth microseconds of queue time
     base = ring.data_ptr()
 
@@ -207,9 +209,11 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
             front_ms.append(t["ms_front"])
             total_ms.append(t["ms_total"])
         host_us.append((t["host_enqueue_us"], t["host_wait_us"], t["host_text_us"]))
+    t_loop = time.perf_counter()
     eng.flush()          # the last step's text is delivered inside the timed region
     barrier()
     dt = time.perf_counter() - t0
+    drain_ms = (time.perf_counter() - t_loop) * 1e3
     dt = job_time(dist, dt, dev)
     tm = eng.timing()
     front_bytes, path = tm["front_bytes"], tm.get("path", 0)
@@ -251,6 +255,7 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
                      "launch_path": PATHS.get(path, str(path)),
                      "call_latency_ms": round(float(np.mean(total_ms)), 4),
                      "sentences_ok_rank0": int(sentences_ok),
+                     "drain_ms": round(drain_ms, 3),
                      "host_us_enqueue_p50_p90_max": [round(float(np.percentile([h[0] for h in host_us], q)), 1) for q in (50, 90, 100)],
                      "host_us_per_step": {"enqueue": round(float(np.mean([h[0] for h in host_us])), 1),
                                           "wait_gpu": round(float(np.mean([h[1] for h in host_us])), 1),

@@ -122,6 +122,7 @@ struct hd_engine {
     // Step mode (batch decoding, kernels/decimate.hip k_step): the stream tails of call k ride in the stage-1 launch of call k+1.
     struct PendingTail { bool valid = false; hd::TailArgs ta{}; int slot = 0; bool any_fft = false; int r2 = 0, t2 = 0; } pend;
     bool no_step = false;      // HD_NO_STEP: keep stage 1 and the tails in separate launches
+    uint32_t qa_cus = 0;       // HD_CU_SPLIT experiment: CUs the stage-1 queue may use (0 = all)
     uint32_t step_wgs = 0;     // HD_STEP_WGS: stage-1 workgroups of a step launch (default 8 per CU)
     uint32_t pend_max_taps = 0;
     uint32_t n_cus = 0, dec_wgs_per_cu = 0;   // stage-1 linear split: workgroups per CU (0 = classic grid), see kernels/decimate.hip        // path of the previous call (the two paths use the stage-2 buffers on different queues)
@@ -282,7 +283,15 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         const char* pv = getenv("HD_QA_PRIORITY");
         if (pv && atoi(pv) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
             HD_HIP(hipStreamCreateWithPriority(&e->qa, hipStreamNonBlocking, atoi(pv) > 0 ? hi : lo));
-        else
+        else if (getenv("HD_CU_SPLIT")) {
+            // experiment: stage 1 on the first a of every XCD's 32 CUs, the back half on the rest (mask bits [8j, 8j+8) select CU j of each XCD)
+            const int a = atoi(getenv("HD_CU_SPLIT"));
+            uint32_t ma[8] = {0}, mb[8] = {0};
+            for (int j = 0; j < 32; ++j) (j < a ? ma : mb)[j / 4] |= 0xffu << (8 * (j % 4));
+            HD_HIP(hipExtStreamCreateWithCUMask(&e->qa, 8, ma));
+            HD_HIP(hipExtStreamCreateWithCUMask(&e->qb, 8, mb));
+            e->qa_cus = 8u * (uint32_t)a;
+        } else
             HD_HIP(hipStreamCreateWithFlags(&e->qa, hipStreamNonBlocking));
     }
     e->one_stream = getenv("HD_ONE_STREAM") != nullptr;
@@ -306,7 +315,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     for (hipEvent_t* ev : {&e->ev_copy[0], &e->ev_copy[1], &e->ev_staging_free[0], &e->ev_staging_free[1]}) HD_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     if (e->one_stream) e->qb = e->qc = e->qa;
     else {
-        HD_HIP(hipStreamCreateWithFlags(&e->qb, hipStreamNonBlocking));
+        if (!e->qb) HD_HIP(hipStreamCreateWithFlags(&e->qb, hipStreamNonBlocking));
         HD_HIP(hipStreamCreateWithFlags(&e->qc, hipStreamNonBlocking));   // parameter fetches: tiny kernels that need not queue behind stage 1
     }
     for (auto& sl : e->slot) {
@@ -630,6 +639,8 @@ int collect(hd_engine* e, hd_engine::CallSlot& sl)
 int flush_locked(hd_engine* e)
 {
     int rc = HD_OK;
+    // step mode: the newest call's tails have not been launched yet -- start them before the host spends time on the older call's text
+    if (e->delivered < e->calls) { if (const int r = run_pending_tail(e)) return r; }
     while (e->delivered < e->calls) {           // oldest first
         const int r = collect(e, e->slot[e->delivered % hd_engine::kSlots]);
         if (r) rc = r;
@@ -880,7 +891,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         const size_t out1_stride = single ? e->fbuf_stride : e->n1_cap;
         if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
         if (!hd::launch_decimate(qa, R1, T1, S, max_n1, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
-                                 lean ? sl.h_call.dev : dcall, 0, single ? 1 : 0, e->fir_hist_cap, single ? feed : nullptr, (min_in == max_in && max_in) ? e->dec_wgs_per_cu * e->n_cus : 0u))
+                                 lean ? sl.h_call.dev : dcall, 0, single ? 1 : 0, e->fir_hist_cap, single ? feed : nullptr, (min_in == max_in && max_in) ? e->dec_wgs_per_cu * (e->qa_cus ? e->qa_cus : e->n_cus) : 0u))
             return fail(HD_ERR_INVALID, "no kernel for this decimation stage");
         if (sl.timed) HD_HIP(hipEventRecord(sl.t2, qa));
         if (!single && !fuse) {

@@ -26,6 +26,10 @@
 #include "launch.h"
 #include "tail_body.h"
 
+#ifndef HD_DEC_LA
+#define HD_DEC_LA 4        // products this many taps ahead of the sum in the single-wave first stages
+#endif
+
 namespace hd {
 
 #ifdef HD_STAMP_DEC   // diagnostic build only (tools/micro/dec_stamps.py): phase clocks of the D = 32 kernel, per workgroup
@@ -57,6 +61,29 @@ constexpr int dec_tile_f4()                        // float4 slots of a workgrou
     constexpr int NJJ = (TOUT - 1) * D + T + JS, NL = NJJ + 2 * (NJJ / RD) + 4;
     return (NL + 1) / 2 + TOUT / 2 + 1;
 }
+
+// Taps [J0, J1) of a 16-slot chunk for ONE accumulator (a lane's only output), products LA taps ahead of the sum: the T-term sum is a
+// serial chain of adds by definition (ascending tap order, one accumulator), but the products are independent -- written as
+// "acc = acc + x * k" the compiler multiplies into one temporary right in front of each add and the wave waits out the multiplier
+// AND the adder on every tap.  With the products a few taps ahead, an independent multiply sits between consecutive adds.
+template <int J0, int J1, int LA>
+__device__ __forceinline__ void dec_chunk_mac(f32x2& acc, const f32x4 (&x)[8], const float (&k)[16])
+{
+    auto smp = [&](int j) -> f32x2 { return (j & 1) ? x[j >> 1].zw : x[j >> 1].xy; };
+    f32x2 pr[LA];
+#pragma unroll
+    for (int j = J0; j < J0 + LA; ++j)
+        if (j < J1) pr[(j - J0) % LA] = smp(j) * k[j];
+#pragma unroll
+    for (int j = J0; j < J1; ++j) {
+        acc = acc + pr[(j - J0) % LA];
+        if (j + LA < J1) pr[(j - J0) % LA] = smp(j + LA) * k[j + LA];
+    }
+}
+
+#ifdef HD_STAMP_TAIL  // diagnostic build only: the phase clocks of the tails that ran inside step launches (this translation unit's copy)
+extern "C" void hd_debug_step_tail_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tail_stamps), n * 8); }
+#endif
 
 // The stage body.  (bx, by, gdx) are the workgroup's coordinates in the stage's own grid -- blockIdx / gridDim when the stage is a
 // launch of its own (k_decimate), shifted when stream tails ride in front of it in the same launch (k_step).
@@ -221,6 +248,51 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
         // together, then 2*B packed multiply/add) inside a rolled loop: that keeps ~B taps live in SGPRs instead
         // of all T (which spilled SGPRs through v_writelane) and puts B/2 LDS reads in flight per wave.
         float2 yq[OPL];
+#ifndef HD_DEC_OLDLOOP
+        if constexpr (OPL == 1 && D >= 32 && (D % 16) == 0) {
+            // Single-wave first stages (/32, /64): 16-slot chunks (never across a row pad), the next chunk's LDS reads and taps requested
+            // before the current chunk is summed (two register images, rolled loop over chunk pairs), products ahead of the adds.
+            constexpr int CH = 16, LA = HD_DEC_LA;
+            constexpr int NS = T + JS;                          // slots [JS, NS) carry taps [0, T)
+            constexpr int NCH = NS / CH;                        // full chunks; chunk 0 starts at slot JS
+            static_assert(NCH >= 3, "filter shorter than three chunks");
+            static_assert((TO - 1) * (RD + 2) + (NCH * CH + CH - 1) + 2 * ((NCH * CH + CH - 1) / D) < 2 * dec_tile_f4<D, T, TO>(),
+                          "the look-ahead read of the last chunk must stay inside the workgroup's LDS");
+            f32x2 acc = {0.f, 0.f};
+            f32x4 xa[8], xb[8];
+            float ka[16], kb[16];                               // the chunk's taps (wave-uniform: scalar registers), requested with its samples
+            auto rd = [&](f32x4 (&x)[8], float (&k)[16], const int c, auto j0, auto j1) {
+                const float2* pc = p + c * CH + 2 * ((c * CH) / D);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x[q] = *reinterpret_cast<const f32x4*>(pc + 2 * q);
+                const float* tb = taps + (c * CH - JS);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) k[j] = (j >= decltype(j0)::value && j < decltype(j1)::value) ? tb[j] : 0.f;
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I16 = std::integral_constant<int, 16>;
+            rd(xa, ka, 0, std::integral_constant<int, JS>{}, I16{});
+            rd(xb, kb, 1, I0{}, I16{});
+            dec_chunk_mac<JS, CH, LA>(acc, xa, ka);
+            int c = 1;
+#pragma unroll 1
+            for (; c + 1 < NCH; c += 2) {                       // chunk c is in xb
+                rd(xa, ka, c + 1, I0{}, I16{});
+                dec_chunk_mac<0, CH, LA>(acc, xb, kb);
+                if (c + 2 < NCH) rd(xb, kb, c + 2, I0{}, I16{});
+                else rd(xb, kb, NCH, I0{}, std::integral_constant<int, NS % CH>{});    // the partial chunk behind the last pair (or nothing)
+                dec_chunk_mac<0, CH, LA>(acc, xa, ka);
+            }
+            if constexpr ((NCH - 1) % 2) {                      // one full chunk left over (in xb)
+                rd(xa, ka, NCH, I0{}, std::integral_constant<int, NS % CH>{});
+                dec_chunk_mac<0, CH, LA>(acc, xb, kb);
+                if constexpr (NS % CH) dec_chunk_mac<0, NS % CH, LA>(acc, xa, ka);
+            } else {
+                if constexpr (NS % CH) dec_chunk_mac<0, NS % CH, LA>(acc, xb, kb);
+            }
+            yq[0] = make_float2(acc.x, acc.y);
+        } else
+#endif
         if constexpr (OPL == 1) {
             float ar = 0.f, ai = 0.f;
             auto mac = [&](float xr, float xi, float k) { ar = ar + xr * k; ai = ai + xi * k; };

@@ -5,12 +5,13 @@ import torch, bench, habdec_amd
 w = dict(bench.WORKLOADS["cfg4"]); S = 1024; C = w["C"]
 dev = torch.device("cuda", 0)
 ring, rc, _ = bench.generate_ring(torch, dev, w, S, 0, 1234)
-eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"])
-L = habdec_amd.lib(); f = L.hd_debug_tail_stamps; f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"], pipeline=bool(int(__import__("os").environ.get("PIPE", "0"))))
+L = habdec_amd.lib(); f = L.hd_debug_step_tail_stamps if int(__import__('os').environ.get('PIPE', '0')) else L.hd_debug_tail_stamps; f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 acc = np.zeros(20); mx = np.zeros(20); n = 0; spans = []
 for i in range(40):
     eng.process_device(ring.data_ptr() + (i % rc) * S * C * 8, C, C)
     if i >= 10:
+        if int(__import__('os').environ.get('PIPE', '0')): torch.cuda.synchronize()
         st = np.zeros(S * 24, np.uint64); f(st.ctypes.data, S * 24); st = st.reshape(S, 24).astype(np.int64)
         d = st[:, :20].astype(np.float64)
         acc += d.mean(axis=0); mx = np.maximum(mx, d.max(axis=0)); n += 1
