@@ -122,6 +122,10 @@ struct hd_engine {
     // Step mode (batch decoding, kernels/decimate.hip k_step): the stream tails of call k ride in the stage-1 launch of call k+1.
     struct PendingTail { bool valid = false; hd::TailArgs ta{}; int slot = 0; bool any_fft = false; int r2 = 0, t2 = 0; } pend;
     bool no_step = false;      // HD_NO_STEP: keep stage 1 and the tails in separate launches
+    bool no_claim = false;     // HD_NO_CLAIM: step launches with fixed shares of tiles (A/B measurements)
+    uint32_t step_run = 0;     // HD_STEP_RUN: tiles per drawn run (default 2, the minimum)
+    uint64_t step_launches = 0;
+    DevBuf<unsigned int> step_ctr;         // two sets of per-XCD run counters ([2][16][32] u32), alternating per step launch
     uint32_t qa_cus = 0;       // HD_CU_SPLIT experiment: CUs the stage-1 queue may use (0 = all)
     uint32_t step_wgs = 0;     // HD_STEP_WGS: stage-1 workgroups of a step launch (default 8 per CU)
     uint32_t pend_max_taps = 0;
@@ -298,6 +302,8 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     e->no_fuse = getenv("HD_NO_FUSE") != nullptr;
     e->no_tail = getenv("HD_NO_TAIL") != nullptr;
     e->no_step = getenv("HD_NO_STEP") != nullptr;
+    e->no_claim = getenv("HD_NO_CLAIM") != nullptr;
+    if (const char* v = getenv("HD_STEP_RUN")) e->step_run = (uint32_t)atoi(v);
     if (const char* v = getenv("HD_STEP_WGS")) e->step_wgs = (uint32_t)atoi(v);
     if (const char* v = getenv("HD_TAIL_LANES")) e->tail_lanes = atoi(v);
     if (const char* v = getenv("HD_TAIL_MAX_N2")) e->tail_max_n2 = (uint32_t)strtoul(v, nullptr, 0);
@@ -359,6 +365,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     // device memory
     HD_HIP(e->staging.alloc((size_t)S * cfg->max_chunk));
     if (e->stages.size() == 2) for (auto* b : {&e->dec1, &e->dec1b, &e->dec1c}) HD_HIP(b->alloc((size_t)S * e->n1_cap));
+    HD_HIP(e->step_ctr.alloc(2 * 16 * 32));
     if (e->stages.size() >= 1) {
         for (auto& h : e->hist1) HD_HIP(h.alloc((size_t)S * (e->stages[0].taps.size() - 1)));
         HD_HIP(e->stage_taps[0].alloc(e->stages[0].taps.size()));
@@ -853,10 +860,24 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         hd_engine::PendingTail prev = e->pend;
         hd_engine::CallSlot* ps = prev.valid ? &e->slot[prev.slot] : nullptr;
         if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
-        const uint32_t wgs = e->step_wgs ? e->step_wgs : 32u * e->n_cus;   // short runs of tiles: the dispatcher evens out the tail of the launch
+        uint32_t wgs = e->step_wgs ? e->step_wgs : 32u * e->n_cus;   // short runs of tiles: the dispatcher evens out the tail of the launch
+        // Better still when every stream brings the same whole number of runs: eight resident workgroups per CU draw runs of two tiles
+        // from per-XCD counters (kernels/decimate.hip) -- no cold start per run, no fixed shares.
+        hd::StepClaim claim{};
+        {
+            const uint32_t ntiles = (max_n1 + 63) / 64, n_xcd = e->n_cus / 32u, run_len = e->step_run >= 2 ? e->step_run : 2u;   // (a run must hold the tile in front of which the next draw is issued: at least two)
+            const uint64_t runs = (uint64_t)S * ntiles / run_len;
+            if (!e->no_claim && !any_zero1 && n_xcd && e->n_cus % 32u == 0 && n_xcd <= 16 && ntiles % run_len == 0 && runs % n_xcd == 0 && max_n1 % 64 == 0) {
+                claim.ctr = e->step_ctr.p + (size_t)(e->step_launches & 1u) * 16 * 32;
+                claim.ctr_next = e->step_ctr.p + (size_t)((e->step_launches & 1u) ^ 1u) * 16 * 32;
+                claim.n_xcd = n_xcd; claim.runs_per_xcd = (uint32_t)(runs / n_xcd); claim.run_len = run_len;
+                if (!e->step_wgs) wgs = 8u * e->n_cus;
+                ++e->step_launches;
+            }
+        }
         if (!hd::launch_step(qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, max_n1, iq, stride, e->hist1[hin].p,
                              e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, wgs, prev.ta, prev.valid ? S : 0u,
-                             any_zero1 ? 0u : max_in))
+                             any_zero1 ? 0u : max_in, claim))
             return fail(HD_ERR_INVALID, "no step kernel for this decimation plan");
         if (sl.timed) HD_HIP(hipEventRecord(sl.t2, qa));
         if (ps) {

@@ -97,7 +97,8 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
                                               uint32_t n_streams, uint32_t lin_ntiles, StreamCall* __restrict__ call_copy,
                                               const uint32_t bx, const uint32_t by, const uint32_t gdx, float4* __restrict__ tile4,
                                               const uint32_t uniform_n = 0 /* != 0: every stream brings this many samples and none restarts its history:
-                                                                             the per-stream parameter block need not be read (it may sit across PCIe) */)
+                                                                             the per-stream parameter block need not be read (it may sit across PCIe) */,
+                                              const StepClaim claim = StepClaim{} /* runs of tiles handed out by per-XCD counters instead of a fixed share */)
 {
     constexpr int OPL = dec_opl<D>();              // outputs per lane
     constexpr int TOUT = TO * OPL;                 // outputs per tile
@@ -121,7 +122,36 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
     static_assert(sizeof(CallHead) == 32, "CallHead mirrors the head of StreamCall");
     const bool linear = lin_ntiles != 0;
     uint32_t s, first, count;                               // current stream, first tile in it, tiles this workgroup walks in total
-    if (linear) {
+    // Claimed runs (step launches): the slab's tiles are cut into runs of claim.run_len consecutive tiles of one stream; XCD x owns the
+    // runs [x * runs_per_xcd, (x + 1) * runs_per_xcd) and its workgroups draw them from the XCD's counter until none is left.  The draw
+    // for the NEXT run is issued one tile before it is needed, in front of that tile's prefetch loads (returns are in order: by the
+    // time the prefetched tile has arrived, so has the ticket), and the next run's first tile is prefetched like any other tile -- a
+    // workgroup never sits through a cold start again, however unevenly the launch's slots free up.
+    const bool claimed = claim.ctr != nullptr && claim.run_len >= 2;
+    unsigned int* my_ctr = nullptr;
+    unsigned int* next_ctr = nullptr;
+    // A counter is only ever touched by its own XCD, with atomics (they execute in that XCD's L2): the workgroup that draws the first
+    // ticket past the end -- exactly one per XCD and launch -- resets the XCD's counter of the other set for the next step launch.
+    // (A plain store from whichever XCD runs workgroup 0 would leave this XCD's L2 with its stale copy.)
+    auto retire = [&]() { if (threadIdx.x == 0) (void)__hip_atomic_exchange(next_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // one draw per WAVE: lane 0 adds, everybody reads its answer (the value is only looked at a tile later -- the wait sits there)
+    auto draw = [&]() -> unsigned int { unsigned int t = 0; if (threadIdx.x == 0) t = __hip_atomic_fetch_add(my_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return t; };
+    auto drawn = [&](unsigned int t) -> unsigned int { return (unsigned int)__builtin_amdgcn_readfirstlane((int)t); };
+    uint32_t xcd = 0;
+    unsigned int ticket = 0;                                // the draw in flight (lane 0's register)
+    bool jump = false; uint32_t jump_s = 0, jump_first = 0;
+    if (claimed) {
+        xcd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;       // XCC_ID
+        if (xcd >= claim.n_xcd) xcd = claim.n_xcd - 1;
+        my_ctr = claim.ctr + (size_t)xcd * 32;                                  // one counter per 128-byte line
+        next_ctr = claim.ctr_next + (size_t)xcd * 32;
+        const unsigned int r = drawn(draw());
+        if (r >= claim.runs_per_xcd) { if (r == claim.runs_per_xcd) retire(); return; }
+        const uint64_t g0 = ((uint64_t)xcd * claim.runs_per_xcd + r) * claim.run_len;
+        s = (uint32_t)(g0 / lin_ntiles);
+        first = (uint32_t)(g0 - (uint64_t)s * lin_ntiles);
+        count = claim.run_len;
+    } else if (linear) {
         const uint64_t total = (uint64_t)n_streams * lin_ntiles;
         const uint64_t g0 = (uint64_t)bx * total / gdx, g1 = (uint64_t)(bx + 1) * total / gdx;
         s = (uint32_t)(g0 / lin_ntiles);
@@ -188,6 +218,13 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
         }
     };
 
+#ifdef HD_DEC_STAGGER   // experiment: start a CU's eight waves an eighth of a tile period apart (HW_ID: wave slot [3:0], SIMD [5:4])
+    {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+        const unsigned slot8 = ((hw >> 4) & 3u) * 2u + (hw & 1u);
+        for (unsigned i = 0; i < slot8; ++i) __builtin_amdgcn_s_sleep(HD_DEC_STAGGER);
+    }
+#endif
     DSTAMP_DECL;
     load_tile(first);
     const float2* p = tile + threadIdx.x * (RD + 2);
@@ -233,6 +270,20 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
         DSTAMP(1);
         store_prev();
         if (done) flush_copy();
+        if (claimed && done + 2 == count)                   // one tile before the run ends: draw the next run (in front of the prefetch loads)
+            ticket = draw();
+        if (claimed && done + 1 == count) {                 // the run's last tile: prefetch the first tile of the run just drawn, if there is one
+            const unsigned int tk = drawn(ticket);
+            if (tk == claim.runs_per_xcd) retire();
+            if (tk < claim.runs_per_xcd) {
+                const uint64_t g0 = ((uint64_t)xcd * claim.runs_per_xcd + tk) * claim.run_len;
+                pf_s = (uint32_t)(g0 / lin_ntiles);
+                const uint32_t pf_tile = (uint32_t)(g0 - (uint64_t)pf_s * lin_ntiles);
+                load_tile(pf_tile);
+                count += claim.run_len;
+                jump = true; jump_s = pf_s; jump_first = pf_tile;
+            }
+        } else
         if (done + 1 < count) {                             // the next tile's loads stay in flight while this tile is computed
             uint32_t pf_tile = tile_i + 1;
             if (linear && pf_tile == ntiles) {              // ... across the seam into the next stream
@@ -411,7 +462,9 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
         fdst_prev = fft_in ? fft_in + (size_t)s * kFftBins + c.fft_fill + o : nullptr;
         __syncthreads();                                    // everyone is done with this tile's LDS image
         DSTAMP(3);
-        if (++tile_i == ntiles) {
+        ++tile_i;
+        const bool seam = tile_i == ntiles;
+        if (seam) {
             // History carry for the next call (Decimator.h:140-143).  Q4: the reference decimates in place
             // (Decoder.h:443-444), so history positions that fall inside the first n/D samples hold OUTPUTS; that can only
             // happen for inputs so short that all outputs are in this (single) tile.
@@ -423,11 +476,16 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
                     hout[j] = idx < nout ? ytile[idx] : in_s[idx];
                 }
             }
-            if (done + 1 < count) {                         // linear split: walk on into the next stream (its first tile is in flight)
+            if (!jump && done + 1 < count) {                // linear split: walk on into the next stream (its first tile is in flight)
                 __syncthreads();                            // ytile is rewritten by the next tile
                 ++s; tile_i = 0; c = c_next;
                 leave_copy(s);
             }
+        }
+        if (jump) {                                         // claimed runs: on to the run drawn a tile ago (its first tile is in flight)
+            __syncthreads();
+            s = jump_s; tile_i = jump_first; jump = false;
+            if (!tile_i) leave_copy(s);
         }
     }
     store_prev();
@@ -461,7 +519,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                    float2* __restrict__ out, size_t out_stride,
                                                    const StreamCall* __restrict__ call, uint32_t n_streams, uint32_t lin_ntiles,
                                                    StreamCall* __restrict__ call_copy, const TailArgs ta, const uint32_t n_tail,
-                                                   const uint32_t uniform_n)
+                                                   const uint32_t uniform_n, const StepClaim claim)
 {
     constexpr int kF4 = dec_tile_f4<D, T, 64>() > (int)(kStepLdsBytes / 16) ? dec_tile_f4<D, T, 64>() : (int)(kStepLdsBytes / 16);
     __shared__ float4 tile4[kF4];
@@ -479,7 +537,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     __builtin_amdgcn_s_setprio(HD_STEP_S1_PRIO);
 #endif
     decimate_body<D, T, 64>(in, in_stride, hist_in, hist_out, taps, out, out_stride, call, 0, 0, 0u, 0u, nullptr, n_streams, lin_ntiles, call_copy,
-                            blockIdx.x - n_tail, 0u, gridDim.x - n_tail, tile4, uniform_n);
+                            blockIdx.x - n_tail, 0u, gridDim.x - n_tail, tile4, uniform_n, claim);
 }
 
 __global__ void k_passthrough(const float2* __restrict__ in, size_t in_stride, float2* __restrict__ out, size_t out_stride,
@@ -570,13 +628,13 @@ uint32_t step_lds_bytes(int ratio, int ntaps)
 
 bool launch_step(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, uint32_t n_streams, uint32_t n_out, const float2* in, size_t in_stride,
                  const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
-                 StreamCall* call_copy, uint32_t stage1_wgs, const TailArgs& ta, uint32_t n_tail, uint32_t uniform_n)
+                 StreamCall* call_copy, uint32_t stage1_wgs, const TailArgs& ta, uint32_t n_tail, uint32_t uniform_n, const StepClaim& claim)
 {
 #define HD_STEP_CASE(D, T, D2, T2)                                                                                                    \
     if (ratio == D && ntaps == T && ratio2 == D2 && ntaps2 == T2) {                                                                   \
         const uint32_t ntiles = (n_out + 63) / 64;                                                                                    \
         hipLaunchKernelGGL((k_step<D, T, D2, T2>), dim3(n_tail + stage1_wgs), dim3(64), 0, st, in, in_stride, hist_in, hist_out, taps, out, \
-                           out_stride, call, n_streams, ntiles, call_copy, ta, n_tail, uniform_n);                                    \
+                           out_stride, call, n_streams, ntiles, call_copy, ta, n_tail, uniform_n, claim);                             \
         return true;                                                                                                                  \
     }
     HD_STEP_CASE(32, 212, 2, 69) HD_STEP_CASE(32, 174, 4, 139) HD_STEP_CASE(64, 348, 4, 139)

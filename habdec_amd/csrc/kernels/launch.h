@@ -83,10 +83,18 @@ bool launch_tail(hipStream_t st, int lanes, int ratio2, int ntaps2, uint32_t n_s
 // Batch mode, two-stage plans whose first stage is a single-wave design: ONE launch per step -- the stream tails of the previous call
 // (workgroups [0, n_tail), arguments `ta`) in front of this call's stage 1 as a linear split over stage1_wgs workgroups; every stream
 // has n_out stage-1 outputs.  Returns false when there is no instantiation for the plan.
+// How a step launch's stage-1 workgroups get their tiles when they draw them (ctr != nullptr): per-XCD counters, one per 128-byte line
+// (32 u32 apart), zero when the launch starts; every XCD resets its counter in ctr_next, the set the NEXT step launch uses.
+struct StepClaim {
+    unsigned int* ctr = nullptr;             // this launch's counters, [n_xcd][32]
+    unsigned int* ctr_next = nullptr;        // the other set
+    uint32_t n_xcd = 0, runs_per_xcd = 0, run_len = 0;
+};
 bool launch_step(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, uint32_t n_streams, uint32_t n_out, const float2* in, size_t in_stride,
                  const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
                  StreamCall* call_copy, uint32_t stage1_wgs, const TailArgs& ta, uint32_t n_tail,
-                 uint32_t uniform_n /* != 0: the streams' common sample count, and no stream restarts its stage-1 history this call */);
+                 uint32_t uniform_n /* != 0: the streams' common sample count, and no stream restarts its stage-1 history this call */,
+                 const StepClaim& claim = StepClaim{});
 uint32_t step_lds_bytes(int ratio, int ntaps);   // LDS of a step-launch workgroup for that first stage (its tile, at least kStepLdsBytes); 0 = no step kernel
 constexpr uint32_t kStepLdsBytes = 20480;   // LDS of a stage-1 workgroup slot (eight per CU): what a tail riding in the stage-1 launch may use
 
