@@ -853,6 +853,21 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         t.sp = e->d_sym.p; t.slots = sl.h_slots.dev; t.slot_words = e->slot_words;
         t.flips_dbg = e->flips_cap ? e->flips_dbg.p : nullptr; t.flips_cap = e->flips_cap;
     };
+    // Equally sized pushes through a single-wave first stage of a two-stage plan: the stage-1 workgroups (eight resident per CU) draw
+    // runs of tiles from per-XCD counters (kernels/decimate.hip) -- no cold start per run, no fixed shares that end ragged.
+    auto make_claim = [&](uint32_t lin_wgs /* stage 1 as a launch of its own: the workgroup count of its linear split (which needs four tiles per workgroup); 0 = step launch */) {
+        hd::StepClaim claim{};
+        const uint32_t ntiles = (max_n1 + 63) / 64, n_xcd = e->n_cus / 32u, run_len = e->step_run >= 2 ? e->step_run : 2u;   // (a run must hold the tile in front of which the next draw is issued: at least two)
+        const uint64_t runs = (uint64_t)S * ntiles / run_len;
+        if (!e->no_claim && nst == 2 && (R1 == 32 || R1 == 64) && min_in == max_in && max_in && !any_zero1 && n_xcd && e->n_cus % 32u == 0 && n_xcd <= 16 &&
+            ntiles % run_len == 0 && runs % n_xcd == 0 && max_n1 % 64 == 0 && !e->qa_cus && (uint64_t)ntiles * S >= 4ull * lin_wgs) {   // (the two counter sets alternate: a launch that takes one must really run that way)
+            claim.ctr = e->step_ctr.p + (size_t)(e->step_launches & 1u) * 16 * 32;
+            claim.ctr_next = e->step_ctr.p + (size_t)((e->step_launches & 1u) ^ 1u) * 16 * 32;
+            claim.n_xcd = n_xcd; claim.runs_per_xcd = (uint32_t)(runs / n_xcd); claim.run_len = run_len;
+            ++e->step_launches;
+        }
+        return claim;
+    };
     if (step) {
         // One launch: [tails of the previous call | this call's stage 1].  Stage 1 reads its parameters from the mapped host block and
         // leaves the device copy the tails (next launch) and the spectrum commit read.
@@ -861,20 +876,8 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         hd_engine::CallSlot* ps = prev.valid ? &e->slot[prev.slot] : nullptr;
         if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
         uint32_t wgs = e->step_wgs ? e->step_wgs : 32u * e->n_cus;   // short runs of tiles: the dispatcher evens out the tail of the launch
-        // Better still when every stream brings the same whole number of runs: eight resident workgroups per CU draw runs of two tiles
-        // from per-XCD counters (kernels/decimate.hip) -- no cold start per run, no fixed shares.
-        hd::StepClaim claim{};
-        {
-            const uint32_t ntiles = (max_n1 + 63) / 64, n_xcd = e->n_cus / 32u, run_len = e->step_run >= 2 ? e->step_run : 2u;   // (a run must hold the tile in front of which the next draw is issued: at least two)
-            const uint64_t runs = (uint64_t)S * ntiles / run_len;
-            if (!e->no_claim && !any_zero1 && n_xcd && e->n_cus % 32u == 0 && n_xcd <= 16 && ntiles % run_len == 0 && runs % n_xcd == 0 && max_n1 % 64 == 0) {
-                claim.ctr = e->step_ctr.p + (size_t)(e->step_launches & 1u) * 16 * 32;
-                claim.ctr_next = e->step_ctr.p + (size_t)((e->step_launches & 1u) ^ 1u) * 16 * 32;
-                claim.n_xcd = n_xcd; claim.runs_per_xcd = (uint32_t)(runs / n_xcd); claim.run_len = run_len;
-                if (!e->step_wgs) wgs = 8u * e->n_cus;
-                ++e->step_launches;
-            }
-        }
+        const hd::StepClaim claim = make_claim(0);
+        if (claim.ctr && !e->step_wgs) wgs = 8u * e->n_cus;
         if (!hd::launch_step(qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, max_n1, iq, stride, e->hist1[hin].p,
                              e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, wgs, prev.ta, prev.valid ? S : 0u,
                              any_zero1 ? 0u : max_in, claim))
@@ -910,9 +913,12 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         const bool single = nst == 1;
         float2* out1 = single ? fcur : d1;
         const size_t out1_stride = single ? e->fbuf_stride : e->n1_cap;
+        const uint32_t lin1 = (min_in == max_in && max_in) ? e->dec_wgs_per_cu * (e->qa_cus ? e->qa_cus : e->n_cus) : 0u;
+        const hd::StepClaim claim1 = (single || !lin1) ? hd::StepClaim{} : make_claim(lin1);
         if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
         if (!hd::launch_decimate(qa, R1, T1, S, max_n1, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
-                                 lean ? sl.h_call.dev : dcall, 0, single ? 1 : 0, e->fir_hist_cap, single ? feed : nullptr, (min_in == max_in && max_in) ? e->dec_wgs_per_cu * (e->qa_cus ? e->qa_cus : e->n_cus) : 0u))
+                                 lean ? sl.h_call.dev : dcall, 0, single ? 1 : 0, e->fir_hist_cap, single ? feed : nullptr, lin1,
+                                 nullptr, claim1.ctr ? max_in : 0u, claim1))
             return fail(HD_ERR_INVALID, "no kernel for this decimation stage");
         if (sl.timed) HD_HIP(hipEventRecord(sl.t2, qa));
         if (!single && !fuse) {

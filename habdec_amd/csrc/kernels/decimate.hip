@@ -500,11 +500,13 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                    float2* __restrict__ out, size_t out_stride,
                                                    const StreamCall* __restrict__ call, int stage, int final_stage,
                                                    uint32_t fir_hist_cap, uint32_t tiles_per_wg, float2* __restrict__ fft_in,
-                                                   uint32_t n_streams, uint32_t lin_ntiles, StreamCall* __restrict__ call_copy)
+                                                   uint32_t n_streams, uint32_t lin_ntiles, StreamCall* __restrict__ call_copy,
+                                                   const uint32_t uniform_n, const StepClaim claim)
 {
     __shared__ float4 tile4[dec_tile_f4<D, T, TO>()];
     decimate_body<D, T, TO>(in, in_stride, hist_in, hist_out, taps, out, out_stride, call, stage, final_stage, fir_hist_cap, tiles_per_wg, fft_in,
-                            n_streams, lin_ntiles, call_copy, blockIdx.x, blockIdx.y, gridDim.x, tile4);
+                            n_streams, lin_ntiles, call_copy, blockIdx.x, blockIdx.y, gridDim.x, tile4, TO == 64 ? uniform_n : 0u,
+                            TO == 64 ? claim : StepClaim{});
 }
 
 // One launch per step in batch mode: workgroups [0, n_tail) are the stream tails of the PREVIOUS call (tail_body.h: stage 2, low-pass,
@@ -583,7 +585,8 @@ __global__ __launch_bounds__(64) void k_dc_remove(float2* __restrict__ fbuf, siz
 template <int D, int T, int TO>
 static void launch_one(hipStream_t st, uint32_t n_streams, uint32_t max_out, const float2* in, size_t in_stride,
                        const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride,
-                       const StreamCall* call, int stage, int final_stage, uint32_t fir_hist_cap, float2* fft_in, uint32_t lin_wgs, StreamCall* call_copy)
+                       const StreamCall* call, int stage, int final_stage, uint32_t fir_hist_cap, float2* fft_in, uint32_t lin_wgs, StreamCall* call_copy,
+                       uint32_t uniform_n, const StepClaim& claim)
 {
     constexpr uint32_t TOUT = TO * dec_opl<D>();
     const uint32_t ntiles = (max_out + TOUT - 1) / TOUT;
@@ -592,7 +595,8 @@ static void launch_one(hipStream_t st, uint32_t n_streams, uint32_t max_out, con
     // eight 19.5 KB LDS slots this kernel takes -- the rest stays free for the back-half kernels of the previous call.
     if (TO == 64 && lin_wgs && (uint64_t)ntiles * n_streams >= 4ull * lin_wgs) {
         hipLaunchKernelGGL((k_decimate<D, T, TO>), dim3(lin_wgs), dim3(TO), 0, st, in, in_stride, hist_in, hist_out, taps, out, out_stride, call,
-                           stage, final_stage, fir_hist_cap, 0u, fft_in, n_streams, ntiles, call_copy);
+                           stage, final_stage, fir_hist_cap, 0u, fft_in, n_streams, ntiles, call_copy, final_stage ? 0u : uniform_n,
+                           (final_stage || !uniform_n) ? StepClaim{} : claim);
         return;
     }
     // Walk several tiles per workgroup (prefetch pipelining) once there are enough workgroups to fill the chip:
@@ -601,16 +605,17 @@ static void launch_one(hipStream_t st, uint32_t n_streams, uint32_t max_out, con
     while (per < 16 && (uint64_t)((ntiles + 2 * per - 1) / (2 * per)) * n_streams >= 2048) per *= 2;
     dim3 grid((ntiles + per - 1) / per, n_streams);
     hipLaunchKernelGGL((k_decimate<D, T, TO>), grid, dim3(TO), 0, st, in, in_stride, hist_in, hist_out, taps, out, out_stride, call,
-                       stage, final_stage, fir_hist_cap, per, fft_in, n_streams, 0u, (StreamCall*)nullptr);
+                       stage, final_stage, fir_hist_cap, per, fft_in, n_streams, 0u, (StreamCall*)nullptr, 0u, StepClaim{});
 }
 
 bool launch_decimate(hipStream_t st, int ratio, int ntaps, uint32_t n_streams, uint32_t max_out, const float2* in, size_t in_stride,
                      const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
-                     int stage, int final_stage, uint32_t fir_hist_cap, float2* fft_in, uint32_t lin_wgs, StreamCall* call_copy)
+                     int stage, int final_stage, uint32_t fir_hist_cap, float2* fft_in, uint32_t lin_wgs, StreamCall* call_copy,
+                     uint32_t uniform_n, const StepClaim& claim)
 {
     if (!max_out) return true;
 #define HD_CASE(D, T, TO) \
-    if (ratio == D && ntaps == T) { launch_one<D, T, TO>(st, n_streams, max_out, in, in_stride, hist_in, hist_out, taps, out, out_stride, call, stage, final_stage, fir_hist_cap, fft_in, lin_wgs, call_copy); return true; }
+    if (ratio == D && ntaps == T) { launch_one<D, T, TO>(st, n_streams, max_out, in, in_stride, hist_in, hist_out, taps, out, out_stride, call, stage, final_stage, fir_hist_cap, fft_in, lin_wgs, call_copy, uniform_n, claim); return true; }
     HD_CASE(2, 69, 256) HD_CASE(4, 139, 256) HD_CASE(8, 280, 256) HD_CASE(8, 54, 256)
     HD_CASE(16, 107, 128) HD_CASE(32, 212, 64) HD_CASE(32, 174, 64) HD_CASE(64, 348, 64)
 #undef HD_CASE

@@ -14,6 +14,14 @@ struct DemodCarry {        // per-stream discriminator carry (previous filtered 
     uint32_t _pad;
 };
 
+// How the single-wave stage-1 workgroups of a launch (step launches, and stage 1 alone over equally sized pushes) get their tiles when they
+// draw them (ctr != nullptr): per-XCD counters, one per 128-byte line
+// (32 u32 apart), zero when the launch starts; every XCD resets its counter in ctr_next, the set the NEXT step launch uses.
+struct StepClaim {
+    unsigned int* ctr = nullptr;             // this launch's counters, [n_xcd][32]
+    unsigned int* ctr_next = nullptr;        // the other set
+    uint32_t n_xcd = 0, runs_per_xcd = 0, run_len = 0;
+};
 // One FIR-decimate stage for all streams.  `final_stage`: output lands behind the FIR history in the
 // low-pass input buffer (offset fir_hist_cap + pend_before), else at offset 0 of `out`.
 // Returns false when (ratio, ntaps) is not one of the eight reference designs.  The kernel also carries each
@@ -24,7 +32,9 @@ bool launch_decimate(hipStream_t st, int ratio, int ntaps, uint32_t n_streams, u
                      float2* out, size_t out_stride, const StreamCall* call, int stage, int final_stage,
                      uint32_t fir_hist_cap, float2* fft_in /* final stage: spectrum input buffer [S][4096], or null */,
                      uint32_t lin_wgs = 0 /* != 0: every stream has the same size; use exactly this many workgroups (single-wave kernels) */,
-                     StreamCall* call_copy = nullptr /* linear split only: leave a device copy of each stream's parameters here */);
+                     StreamCall* call_copy = nullptr /* linear split only: leave a device copy of each stream's parameters here */,
+                     uint32_t uniform_n = 0 /* linear split, not the final stage: the streams' common sample count, no stream restarts its history */,
+                     const StepClaim& claim = StepClaim{} /* with uniform_n: the lin_wgs workgroups draw their tiles */);
 // copy `bytes` (multiple of 16) from mapped pinned host memory into device memory with a kernel
 void launch_fetch_params(hipStream_t st, const void* host_mapped, void* dst, size_t bytes);
 // factor 1: copy the chunk behind the FIR history.
@@ -83,13 +93,6 @@ bool launch_tail(hipStream_t st, int lanes, int ratio2, int ntaps2, uint32_t n_s
 // Batch mode, two-stage plans whose first stage is a single-wave design: ONE launch per step -- the stream tails of the previous call
 // (workgroups [0, n_tail), arguments `ta`) in front of this call's stage 1 as a linear split over stage1_wgs workgroups; every stream
 // has n_out stage-1 outputs.  Returns false when there is no instantiation for the plan.
-// How a step launch's stage-1 workgroups get their tiles when they draw them (ctr != nullptr): per-XCD counters, one per 128-byte line
-// (32 u32 apart), zero when the launch starts; every XCD resets its counter in ctr_next, the set the NEXT step launch uses.
-struct StepClaim {
-    unsigned int* ctr = nullptr;             // this launch's counters, [n_xcd][32]
-    unsigned int* ctr_next = nullptr;        // the other set
-    uint32_t n_xcd = 0, runs_per_xcd = 0, run_len = 0;
-};
 bool launch_step(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, uint32_t n_streams, uint32_t n_out, const float2* in, size_t in_stride,
                  const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
                  StreamCall* call_copy, uint32_t stage1_wgs, const TailArgs& ta, uint32_t n_tail,

@@ -25,15 +25,29 @@ def same_bits(a, b):
     return a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
 
 
-def test_headline_workload_through_the_step_kernel():
+@pytest.fixture(scope="module")
+def headline_ring():
     torch = pytest.importorskip("torch")
     import bench
+    w = dict(bench.WORKLOADS["cfg4"])
+    ring, ring_chunks, _ = bench.generate_ring(torch, torch.device("cuda", 0), w, w["S"], 0, seed=77)
+    yield w, ring, ring_chunks
+    del ring
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("shares", ["drawn", "drawn4", "fixed"])
+def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, shares):
+    """shares: how the step launch's stage-1 workgroups get their tiles -- runs of two drawn from per-XCD counters (the default), runs of
+    four, or the fixed shares of HD_NO_CLAIM (the first call of a stream, which restarts its history, always takes fixed shares)."""
     import habdec_amd
     from oracle import pyoracle
-    w = dict(bench.WORKLOADS["cfg4"])
+    if shares == "drawn4":
+        monkeypatch.setenv("HD_STEP_RUN", "4")
+    if shares == "fixed":
+        monkeypatch.setenv("HD_NO_CLAIM", "1")
+    w, ring, ring_chunks = headline_ring
     S, fs = w["S"], w["fs"]
-    dev = torch.device("cuda", 0)
-    ring, ring_chunks, _ = bench.generate_ring(torch, dev, w, S, 0, seed=77)
     # 7/8 of the streams are within +-200 Hz, every 8th is far off: sample both kinds (and the first / last stream of XCD blocks)
     check = [0, 1, 2, 127, 128, 500, 511, 512, 640, 1000, 1022, 7, 15, 263, 775, 1023]
     assert sum(1 for s in check if s % 8 == 7) >= 4 and len(set(check)) >= 16

@@ -13,7 +13,7 @@ IFS='|' read -ra VS <<< "${VARIANTS:-|}"
 for flags in "${VS[@]}"; do
   echo "=== build [$flags]"
   HD_EXTRA_FLAGS="$flags" python3 -m habdec_amd.build --force 2>&1 | grep -E "error|spill" | head
-  for i in 1 2; do $B 2>/dev/null | show; done
+  for i in 1 2; do timeout 200 $B 2>/dev/null | show; done
   [ -n "$SYNC" ] && { echo "  sync:"; $B --sync 2>/dev/null | show; }
   [ -n "$PARITY" ] && python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -2
 done
