@@ -122,8 +122,9 @@ struct hd_engine {
     // Step mode (batch decoding, kernels/decimate.hip k_step): the stream tails of call k ride in the stage-1 launch of call k+1.
     struct PendingTail { bool valid = false; hd::TailArgs ta{}; int slot = 0; bool any_fft = false; int r2 = 0, t2 = 0; } pend;
     bool no_step = false;      // HD_NO_STEP: keep stage 1 and the tails in separate launches
+    bool claim_alone = false;  // HD_CLAIM_ALONE: stage 1 as a launch of its own draws its tiles too (measured slower: off)
     bool no_claim = false;     // HD_NO_CLAIM: step launches with fixed shares of tiles (A/B measurements)
-    uint32_t step_run = 0;     // HD_STEP_RUN: tiles per drawn run (default 2, the minimum)
+    uint32_t step_run = 0;     // HD_STEP_RUN: tiles per drawn run (default 4, minimum 2)
     uint64_t step_launches = 0;
     DevBuf<unsigned int> step_ctr;         // two sets of per-XCD run counters ([2][16][32] u32), alternating per step launch
     uint32_t qa_cus = 0;       // HD_CU_SPLIT experiment: CUs the stage-1 queue may use (0 = all)
@@ -303,6 +304,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     e->no_tail = getenv("HD_NO_TAIL") != nullptr;
     e->no_step = getenv("HD_NO_STEP") != nullptr;
     e->no_claim = getenv("HD_NO_CLAIM") != nullptr;
+    e->claim_alone = getenv("HD_CLAIM_ALONE") != nullptr;
     if (const char* v = getenv("HD_STEP_RUN")) e->step_run = (uint32_t)atoi(v);
     if (const char* v = getenv("HD_STEP_WGS")) e->step_wgs = (uint32_t)atoi(v);
     if (const char* v = getenv("HD_TAIL_LANES")) e->tail_lanes = atoi(v);
@@ -857,7 +859,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     // runs of tiles from per-XCD counters (kernels/decimate.hip) -- no cold start per run, no fixed shares that end ragged.
     auto make_claim = [&](uint32_t lin_wgs /* stage 1 as a launch of its own: the workgroup count of its linear split (which needs four tiles per workgroup); 0 = step launch */) {
         hd::StepClaim claim{};
-        const uint32_t ntiles = (max_n1 + 63) / 64, n_xcd = e->n_cus / 32u, run_len = e->step_run >= 2 ? e->step_run : 2u;   // (a run must hold the tile in front of which the next draw is issued: at least two)
+        const uint32_t ntiles = (max_n1 + 63) / 64, n_xcd = e->n_cus / 32u, run_len = e->step_run >= 2 ? e->step_run : 4u;   // (a run must hold the tile in front of which the next draw is issued: at least two; four re-read fewer halos than two)
         const uint64_t runs = (uint64_t)S * ntiles / run_len;
         if (!e->no_claim && nst == 2 && (R1 == 32 || R1 == 64) && min_in == max_in && max_in && !any_zero1 && n_xcd && e->n_cus % 32u == 0 && n_xcd <= 16 &&
             ntiles % run_len == 0 && runs % n_xcd == 0 && max_n1 % 64 == 0 && !e->qa_cus && (uint64_t)ntiles * S >= 4ull * lin_wgs) {   // (the two counter sets alternate: a launch that takes one must really run that way)
@@ -914,7 +916,9 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         float2* out1 = single ? fcur : d1;
         const size_t out1_stride = single ? e->fbuf_stride : e->n1_cap;
         const uint32_t lin1 = (min_in == max_in && max_in) ? e->dec_wgs_per_cu * (e->qa_cus ? e->qa_cus : e->n_cus) : 0u;
-        const hd::StepClaim claim1 = (single || !lin1) ? hd::StepClaim{} : make_claim(lin1);
+        // (Stage 1 alone is HBM-bound: drawing runs costs it ~3 % -- more halo re-reads, 588 vs 576 MB per launch -- where the step launch gains
+        // 4 %; measured on one box, alternating.  HD_CLAIM_ALONE=1 turns it on for experiments.)
+        const hd::StepClaim claim1 = (single || !lin1 || !e->claim_alone) ? hd::StepClaim{} : make_claim(lin1);
         if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
         if (!hd::launch_decimate(qa, R1, T1, S, max_n1, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
                                  lean ? sl.h_call.dev : dcall, 0, single ? 1 : 0, e->fir_hist_cap, single ? feed : nullptr, lin1,

@@ -36,14 +36,14 @@ def headline_ring():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("shares", ["drawn", "drawn4", "fixed"])
+@pytest.mark.parametrize("shares", ["drawn", "drawn2", "fixed"])
 def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, shares):
-    """shares: how the step launch's stage-1 workgroups get their tiles -- runs of two drawn from per-XCD counters (the default), runs of
-    four, or the fixed shares of HD_NO_CLAIM (the first call of a stream, which restarts its history, always takes fixed shares)."""
+    """shares: how the step launch's stage-1 workgroups get their tiles -- runs of four drawn from per-XCD counters (the default), runs of
+    two, or the fixed shares of HD_NO_CLAIM (the first call of a stream, which restarts its history, always takes fixed shares)."""
     import habdec_amd
     from oracle import pyoracle
-    if shares == "drawn4":
-        monkeypatch.setenv("HD_STEP_RUN", "4")
+    if shares == "drawn2":
+        monkeypatch.setenv("HD_STEP_RUN", "2")
     if shares == "fixed":
         monkeypatch.setenv("HD_NO_CLAIM", "1")
     w, ring, ring_chunks = headline_ring
@@ -85,6 +85,28 @@ def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, s
         assert same_bits(eng.demodulated(s), o.array("last_demod")), ("demod at the end", s)
         busy += int(s % 8 == 7)
     assert busy >= 4
+    eng.close()
+
+
+def test_stage1_alone_drawing_its_tiles(monkeypatch, headline_ring):
+    """HD_CLAIM_ALONE=1: synchronous calls, stage 1 as a launch of its own with the per-XCD run counters (off by default: measured slower
+    than the fixed shares; the code path stays covered)."""
+    import habdec_amd
+    from oracle import pyoracle
+    monkeypatch.setenv("HD_CLAIM_ALONE", "1")
+    w, ring, ring_chunks = headline_ring
+    S, fs = w["S"], w["fs"]
+    check = [0, 127, 128, 511, 512, 775, 1023]
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"],
+                            lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"])
+    orcs = {s: pyoracle.Decoder("oracle", factor=w["D"], baud=w["baud"], bits=w["bits"], stops=w["stops"], lowpass_bw=w["lp_bw"]) for s in check}
+    for k in range(7):
+        eng.process_device(ring[k].data_ptr(), C, C)
+        for s, o in orcs.items():
+            o(ring[k, s].cpu().numpy().view(np.complex64).reshape(-1), fs)
+            assert same_bits(eng.decimated(s), o.array("last_decimated")), ("decimated", k, s)
+            assert same_bits(eng.demodulated(s), o.array("last_demod")), ("demod", k, s)
+            assert np.array_equal(eng.bits(s), o.bits()), ("bits", k, s)
     eng.close()
 
 
