@@ -45,6 +45,16 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, float seed, in
                 asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %2\n v_add_f32 %0, %0, %3\n v_add_f32 %0, %0, %4\n"
                              "v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %2\n v_add_f32 %0, %0, %3\n v_add_f32 %0, %0, %4"
                              : "+v"(a0.x) : "v"(x0.x), "v"(x1.x), "v"(x2.x), "v"(x3.x));
+            } else if (MODE == 6) {   // packed dependent chain of adds only
+                asm volatile("v_pk_add_f32 %0, %0, %1\n v_pk_add_f32 %0, %0, %2\n v_pk_add_f32 %0, %0, %3\n v_pk_add_f32 %0, %0, %4\n"
+                             "v_pk_add_f32 %0, %0, %1\n v_pk_add_f32 %0, %0, %2\n v_pk_add_f32 %0, %0, %3\n v_pk_add_f32 %0, %0, %4"
+                             : "+v"(a0) : "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+            } else if (MODE == 7) {   // one packed chain, products two taps ahead: mul(i+2) between add(i) and add(i+1)
+                f32x2 p0, p1;
+                asm volatile("v_pk_mul_f32 %0, %2, %4\n v_pk_mul_f32 %1, %3, %4" : "=&v"(p0), "=&v"(p1) : "v"(x0), "v"(x1), "v"(k));
+                asm volatile("v_pk_add_f32 %0, %0, %1\n v_pk_mul_f32 %1, %3, %5\n v_pk_add_f32 %0, %0, %2\n v_pk_mul_f32 %2, %4, %5\n"
+                             "v_pk_add_f32 %0, %0, %1\n v_pk_add_f32 %0, %0, %2"
+                             : "+v"(a0), "+v"(p0), "+v"(p1) : "v"(x2), "v"(x3), "v"(k));
             } else if (MODE == 4) {   // packed fma, independent
                 asm volatile("v_pk_fma_f32 %0, %4, %8, %0\n v_pk_fma_f32 %1, %5, %8, %1\n v_pk_fma_f32 %2, %6, %8, %2\n v_pk_fma_f32 %3, %7, %8, %3\n"
                              "v_pk_fma_f32 %0, %5, %8, %0\n v_pk_fma_f32 %1, %6, %8, %1\n v_pk_fma_f32 %2, %7, %8, %2\n v_pk_fma_f32 %3, %4, %8, %3"
@@ -81,6 +91,8 @@ int main()
     run<1>("v_mul_f32 + v_add_f32, 8 chains", 16);
     run<2>("v_pk_mul -> v_pk_add, one dependent chain", 8);
     run<3>("v_add_f32 dependent chain", 8);
+    run<6>("v_pk_add_f32 dependent chain", 8);
+    run<7>("one pk chain, products 2 ahead (4 taps: 8 instr)", 8);
     run<4>("v_pk_fma_f32 independent", 8);
     run<5>("v_fma_f32 independent", 8);
     return 0;
