@@ -7,8 +7,8 @@
 A "step" is one pushSamples()+operator()() round for every stream of the batch (reference
 code/websocketServer/main.cpp:240-245): S streams x C IQ samples already resident in HBM go through the whole
 chain (decimation -> [DC] -> spectrum/AFC -> low-pass FIR -> FSK discriminator -> symbol extractor on the GPU;
-RTTY framing, sentence extraction, CRC on the host).  By default the engine runs its batch (pipelined) mode: up to two
-calls are in flight and each call's text is delivered, in order, while the next calls run; everything is delivered
+RTTY framing, sentence extraction, CRC on the host).  By default the engine runs its batch (pipelined) mode: up to three
+calls are undelivered and each call's text is delivered, in order, while the next calls run; everything is delivered
 inside the timed region (hd_flush before the closing barrier).  --sync delivers every step's text before the next step
 starts, like Decoder::operator().  Metric: input complex samples consumed per second over all GPUs (IQ Msamples/s).
 
@@ -180,7 +180,7 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     # generation keeps the GPU busy right up to the warm-up steps)
     eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"],
                             rtty_stops=w["stops"], lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"],
-                            device=local_rank, pipeline=not sync)
+                            device=local_rank, pipeline=0 if sync else int(os.environ.get("HD_BENCH_PIPELINE", "2")))
     ring, ring_chunks, texts = generate_ring(torch, dev, w, S, rank, seed=1234 + rank)
     K = K or ring_chunks
     eng.set_timing(8)          # HIP-event brackets on every 8th call: each record is a barrier packet worth microseconds of queue time
@@ -260,7 +260,7 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
                      "host_us_per_step": {"enqueue": round(float(np.mean([h[0] for h in host_us])), 1),
                                           "wait_gpu": round(float(np.mean([h[1] for h in host_us])), 1),
                                           "text_stage": round(float(np.mean([h[2] for h in host_us])), 1)},
-                     "mode": "sync" if sync else "batch (calls pipelined)"},
+                     "mode": "sync" if sync else "batch (calls pipelined; up to three undelivered)"},
     }
     if valu:
         res["roofline"] = {"bound": "valu", "kernel": "FIR chain: " + kernel + " + k_fir_demod (exact mode: separately rounded multiply and add)",

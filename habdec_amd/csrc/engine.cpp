@@ -158,6 +158,7 @@ struct hd_engine {
     PinBuf<hd::SymbolParams> h_sym;
     // Everything a call in flight owns, double-buffered so call k+1 can be enqueued (and its front half can run)
     // while call k's back half is still executing and its results have not been read yet.
+    static constexpr int kSlots = 4;   // calls whose host-visible blocks (parameters, result slots, spectrum statistics) may be in use at once: in flight + being delivered
     struct CallSlot {
         DevBuf<hd::StreamCall> d_call;
         PinBuf<hd::StreamCall> h_call;
@@ -169,8 +170,7 @@ struct hd_engine {
         uint64_t total_in = 0;
         uint32_t r1 = 1;
         ~CallSlot() { for (hipEvent_t ev : {ev_front, ev_done, ev_params, t0, t1, t2, t3}) if (ev) (void)hipEventDestroy(ev); }
-    } slot[3];
-    static constexpr int kSlots = 3;
+    } slot[kSlots];
     uint64_t calls = 0;
     uint64_t delivered = 0;   // calls whose results have been delivered; calls - delivered <= 2 (pipelined mode)
     int cur = 0;          // which fbuf receives this call's chunk
@@ -696,7 +696,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     if (tables_dirty) { if (int rc = flush_locked(e)) return rc; }
 
     hd_engine::CallSlot& sl = e->slot[e->calls % hd_engine::kSlots];
-    while (sl.busy) {                            // cannot happen with depth <= 2, but never reuse a slot in flight
+    while (sl.busy) {                            // cannot happen with depth <= 3, but never reuse a slot in flight
         if (int rc = collect(e, e->slot[e->delivered % hd_engine::kSlots])) return rc;
         ++e->delivered;
     }
@@ -899,8 +899,12 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         e->hist_cur ^= 1;
         ++e->calls;
         e->last_timing.host_enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
+        // Step launches run strictly in order on one queue, so how far the host lags behind with the results is only a matter of the
+        // host-visible slots: pipeline = 2 keeps three calls undelivered instead of two -- results one call later still, and a host that
+        // is held up for a whole launch (a descheduled thread, a burst of sentences) no longer leaves the queue empty.
+        const uint64_t depth = e->cfg.pipeline >= 2 ? 3u : 2u;
         int rc = HD_OK;
-        while (e->calls - e->delivered > 2) {
+        while (e->calls - e->delivered > depth) {
             const int r = collect(e, e->slot[e->delivered % hd_engine::kSlots]);
             if (r) rc = r;
             ++e->delivered;

@@ -26,7 +26,7 @@ class EngineConfig:
     enable_spectrum: bool = True
     ungated: bool = False
     keep_filtered: bool = False
-    pipeline: bool = False
+    pipeline: int = 0        # 0 synchronous, 1 batch mode (results one call later), 2 batch mode with one more call in flight
     device: int = 0
 
 

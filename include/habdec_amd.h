@@ -67,7 +67,10 @@ typedef struct hd_engine_config {
     int32_t  keep_filtered;     /* 1 = also store the FIR output so hd_stream_filtered() works (parity tests) */
     /* 0 = hd_process_* returns after THIS call's text has been delivered (what Decoder::operator() does).
      * 1 = pipelined batch mode: a call enqueues its GPU work and delivers the PREVIOUS call's text, so the host
-     *     text stage and the next call's decimation overlap the current call's symbol kernels; hd_flush() drains. */
+     *     text stage and the next call's decimation overlap the current call's symbol kernels; hd_flush() drains.
+     * 2 = the same with one more call in flight where the launches of consecutive calls are strictly ordered on one queue (equally
+     *     sized pushes through the step kernel): text arrives two calls late, and a host thread that is held up for the length of a
+     *     launch does not leave the GPU idle.  Elsewhere 2 behaves like 1. */
     int32_t  pipeline;
 } hd_engine_config;
 

@@ -36,10 +36,11 @@ def headline_ring():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("shares", ["drawn", "drawn2", "fixed"])
+@pytest.mark.parametrize("shares", ["drawn", "drawn2", "fixed", "deep"])
 def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, shares):
     """shares: how the step launch's stage-1 workgroups get their tiles -- runs of four drawn from per-XCD counters (the default), runs of
-    two, or the fixed shares of HD_NO_CLAIM (the first call of a stream, which restarts its history, always takes fixed shares)."""
+    two, or the fixed shares of HD_NO_CLAIM (the first call of a stream, which restarts its history, always takes fixed shares); "deep" = pipeline 2,
+    three calls undelivered in the free-running stretch."""
     import habdec_amd
     from oracle import pyoracle
     if shares == "drawn2":
@@ -52,7 +53,7 @@ def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, s
     check = [0, 1, 2, 127, 128, 500, 511, 512, 640, 1000, 1022, 7, 15, 263, 775, 1023]
     assert sum(1 for s in check if s % 8 == 7) >= 4 and len(set(check)) >= 16
     eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"],
-                            lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], pipeline=True)
+                            lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], pipeline=2 if shares == "deep" else 1)
     orcs = {s: pyoracle.Decoder("oracle", factor=w["D"], baud=w["baud"], bits=w["bits"], stops=w["stops"], lowpass_bw=w["lp_bw"]) for s in check}
     host = {s: ring[:, s].cpu().numpy().view(np.complex64).reshape(ring_chunks, C) for s in check}
     n_checked, n_free = 12, 36
