@@ -261,7 +261,12 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
             const bool any = KP * tid < cnt;
             float wp[KP];
             if (any) {
+#if defined(HD_TB_EXP) && (HD_TB_EXP & 16)   // ablation: what the window sums cost (results wrong)
+#pragma unroll
+                for (int j = 0; j < (int)KP; ++j) wp[j] = V[off + KP * tid + j];
+#else
                 window_sums8(V + off + KP * tid, R, wp);
+#endif
                 TSTAMP(19);
 #pragma unroll
                 for (int j = 0; j < (int)KP; ++j) WS[off + R + KP * tid + j] = wp[j];
@@ -727,6 +732,9 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     constexpr int NX = kTailStrip / 64;
     auto chain = [&](float acc, uint32_t a0, uint32_t b) -> float {     // acc + v[a0] + ... + v[b-1] (backlog indices)
         if (a0 >= b) return acc;
+#if defined(HD_TB_EXP) && (HD_TB_EXP & 8)   // ablation: what the run sums cost (results wrong)
+        return acc + (float)(b - a0);
+#endif
         if (a0 >= carried_to && b - carried_to <= vc_n) {               // the samples are in LDS already (wave-uniform addresses: broadcast reads)
             const float* v0 = vc + (a0 - carried_to);
             uint32_t n = b - a0, i = 0;
