@@ -183,7 +183,8 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
                             device=local_rank, pipeline=0 if sync else int(os.environ.get("HD_BENCH_PIPELINE", "2")))
     ring, ring_chunks, texts = generate_ring(torch, dev, w, S, rank, seed=1234 + rank)
     K = K or ring_chunks
-    eng.set_timing(8)          # HIP-event brackets on every 8th call: each record is a barrier packet worth microseconds of queue time
+    eng.set_timing(7)          # HIP-event brackets on every 7th call (each record is a barrier packet worth microseconds of queue time; 7, not 8: every 4th
+                               # launch carries the streams' spectra, and the sample must see light and heavy launches in their true proportion)
     base = ring.data_ptr()
 
     def step(i):

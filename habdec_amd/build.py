@@ -16,7 +16,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "libhabdec_amd.so"
-SOURCES = ["engine.cpp", "host_api.cpp", "kernels/decimate.hip", "kernels/fir_demod.hip", "kernels/backend.hip", "kernels/spectrum.hip", "kernels/symbols.hip", "kernels/tail.hip"]
+SOURCES = ["engine.cpp", "host_api.cpp", "kernels/decimate.hip", "kernels/fir_demod.hip", "kernels/backend.hip", "kernels/spectrum.hip", "kernels/spectrum_wave.hip", "kernels/symbols.hip", "kernels/tail.hip"]
 ARCH = "gfx950"
 
 

@@ -122,6 +122,9 @@ struct hd_engine {
     // Step mode (batch decoding, kernels/decimate.hip k_step): the stream tails of call k ride in the stage-1 launch of call k+1.
     struct PendingTail { bool valid = false; hd::TailArgs ta{}; int slot = 0; bool any_fft = false; int r2 = 0, t2 = 0; } pend;
     bool no_step = false;      // HD_NO_STEP: keep stage 1 and the tails in separate launches
+    bool own_fft = false;      // HD_OWN_FFT: the spectrum as one launch of single-wave workgroups instead of rocFFT + commit where no tail does it (measured: no faster)
+    bool tail_fft = true;      // a stream tail transforms its stream's completed spectrum buffer itself (kernels/spectrum_wave.h); HD_ROCFFT=1: separate launches
+    DevBuf<float2> fft_tw;     // (cos, -sin)(2 pi m / 4096), rounded once from double
     bool claim_alone = false;  // HD_CLAIM_ALONE: stage 1 as a launch of its own draws its tiles too (measured slower: off)
     bool no_claim = false;     // HD_NO_CLAIM: step launches with fixed shares of tiles (A/B measurements)
     uint32_t step_run = 0;     // HD_STEP_RUN: tiles per drawn run (default 4, minimum 2)
@@ -404,6 +407,17 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         HD_HIP(e->spec.alloc((size_t)S * hd::kFftBins));
         HD_HIP(e->power.alloc((size_t)S * hd::kFftBins));
         for (auto& sl : e->slot) HD_HIP(sl.h_stats.alloc(S));
+        {
+            std::vector<float2> tw(hd::kFftBins);
+            for (size_t m = 0; m < hd::kFftBins; ++m) {
+                const double a = 2.0 * 3.14159265358979323846264338327950288 * (double)m / (double)hd::kFftBins;
+                tw[m] = make_float2((float)std::cos(a), (float)-std::sin(a));
+            }
+            HD_HIP(e->fft_tw.alloc(hd::kFftBins));
+            HD_HIP(hipMemcpy(e->fft_tw.p, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+            e->own_fft = getenv("HD_OWN_FFT") != nullptr;
+            e->tail_fft = getenv("HD_ROCFFT") == nullptr;
+        }
         std::call_once(g_rocfft_once, [] { rocfft_setup(); });
         const size_t len = hd::kFftBins;
         if (rocfft_plan_create(&e->fft_plan, rocfft_placement_notinplace, rocfft_transform_type_complex_forward,
@@ -559,15 +573,24 @@ int hd_stream_reset_frequency_correction(hd_engine* e, uint32_t s, double c)
 namespace {
 
 // rocFFT + commit for the streams whose 4096-sample buffer completed in the call that owns `sl` (Decoder.h:475-489)
-int run_spectrum(hd_engine* e, hipStream_t q, hd_engine::CallSlot& sl, bool any_fft)
+int transform_and_commit(hd_engine* e, hipStream_t q, hd::SpectrumStatsDev* stats_dev, const hd::StreamCall* dcall)
 {
-    if (!e->cfg.enable_spectrum || !any_fft) return HD_OK;
+    if (e->own_fft) {   // one launch, one wave per stream (kernels/spectrum_wave.hip)
+        hd::launch_spectrum_wave(q, e->S, e->fft_in.p, e->fft_tw.p, e->spec.p, e->power.p, stats_dev, dcall, e->fsd, e->bins_sep);
+        return HD_OK;
+    }
     void* in[1] = {e->fft_in.p};
     void* outb[1] = {e->fft_raw.p};
     rocfft_execution_info_set_stream(e->fft_info, q);
     if (rocfft_execute(e->fft_plan, in, outb, e->fft_info) != rocfft_status_success) return fail(HD_ERR_DEVICE, "rocfft_execute failed");
-    hd::launch_spectrum_commit(q, e->S, e->fft_raw.p, e->spec.p, e->power.p, sl.h_stats.dev, sl.d_call.p, e->fsd, e->bins_sep);
+    hd::launch_spectrum_commit(q, e->S, e->fft_raw.p, e->spec.p, e->power.p, stats_dev, dcall, e->fsd, e->bins_sep);
     return HD_OK;
+}
+
+int run_spectrum(hd_engine* e, hipStream_t q, hd_engine::CallSlot& sl, bool any_fft)
+{
+    if (!e->cfg.enable_spectrum || !any_fft) return HD_OK;
+    return transform_and_commit(e, q, sl.h_stats.dev, sl.d_call.p);
 }
 
 // Step mode: the tails of the newest call have not been launched yet (they wait for the next call's launch).  Run them now, as a
@@ -585,7 +608,7 @@ int run_pending_tail(hd_engine* e)
         if (!hd::tail_layout(lay, lanes, e->pend.r2, e->pend.t2, e->pend_max_taps, e->max_R, e->min_R, e->tail_cap, e->pend.ta.pend_max, 64 * 1024)) return fail(HD_ERR_INVALID, "stream tail layout");
     }
     if (!hd::launch_tail(e->qa, lanes, e->pend.r2, e->pend.t2, e->S, lay)) return fail(HD_ERR_INVALID, "stream tail refused a shape it was selected for");
-    if (const int r = run_spectrum(e, e->qa, ps, e->pend.any_fft)) return r;
+    if (!ta.fft_tw) { if (const int r = run_spectrum(e, e->qa, ps, e->pend.any_fft)) return r; }
     HD_HIP(hipEventRecord(ps.ev_done, e->qa));
     HD_HIP(hipGetLastError());
     return HD_OK;
@@ -854,6 +877,8 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         t.ring = e->tail.p; t.ring_cap = e->tail_cap; t.sym = e->d_symstate.p; t.flipmask = e->flipmask.p; t.wsum = e->weight.p;
         t.sp = e->d_sym.p; t.slots = sl.h_slots.dev; t.slot_words = e->slot_words;
         t.flips_dbg = e->flips_cap ? e->flips_dbg.p : nullptr; t.flips_cap = e->flips_cap;
+        const bool in_tail = e->tail_fft && e->cfg.enable_spectrum && feed;  // the tail transforms a completed buffer itself
+        t.fft_tw = in_tail ? e->fft_tw.p : nullptr; t.spec = e->spec.p; t.power = e->power.p; t.stats = sl.h_stats.dev; t.rate = e->fsd; t.bins_sep = e->bins_sep;
     };
     // Equally sized pushes through a single-wave first stage of a two-stage plan: the stage-1 workgroups (eight resident per CU) draw
     // runs of tiles from per-XCD counters (kernels/decimate.hip) -- no cold start per run, no fixed shares that end ragged.
@@ -886,7 +911,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             return fail(HD_ERR_INVALID, "no step kernel for this decimation plan");
         if (sl.timed) HD_HIP(hipEventRecord(sl.t2, qa));
         if (ps) {
-            if (const int r = run_spectrum(e, qa, *ps, prev.any_fft)) return r;
+            if (!prev.ta.fft_tw) { if (const int r = run_spectrum(e, qa, *ps, prev.any_fft)) return r; }
             HD_HIP(hipEventRecord(ps->ev_done, qa));
         }
         if (sl.timed) HD_HIP(hipEventRecord(sl.t3, qa));
@@ -940,11 +965,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         if (!(e->cfg.enable_spectrum && max_n2)) return HD_OK;
         if (!fuse && (any_dc || nst == 0)) hd::launch_fft_feed(q, S, fcur, e->fbuf_stride, e->fft_in.p, dcall, e->fir_hist_cap);
         if (any_fft) {   // only when some stream's 4096-sample buffer completed (every call at >= 4096 decimated samples per push)
-            void* in[1] = {e->fft_in.p};
-            void* outb[1] = {e->fft_raw.p};
-            rocfft_execution_info_set_stream(e->fft_info, q);
-            if (rocfft_execute(e->fft_plan, in, outb, e->fft_info) != rocfft_status_success) return fail(HD_ERR_DEVICE, "rocfft_execute failed");
-            hd::launch_spectrum_commit(q, S, e->fft_raw.p, e->spec.p, e->power.p, sl.h_stats.dev, dcall, e->fsd, e->bins_sep);
+            if (const int r = transform_and_commit(e, q, sl.h_stats.dev, dcall)) return r;
         }
         return HD_OK;
     };
@@ -964,7 +985,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         if (lean) hd::launch_fetch_params(qb, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
         fill_tail(ta);
         if (!hd::launch_tail(qb, tail_lanes, (int)R2, (int)T2, S, ta)) return fail(HD_ERR_INVALID, "stream tail refused a shape it was selected for");
-        if (const int r = spectrum(qb)) return r;
+        if (!ta.fft_tw) { if (const int r = spectrum(qb)) return r; }
     } else if (fuse) {
         if (lean) hd::launch_fetch_params(qb, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
         if (!hd::launch_backend(qb, (int)R2, (int)T2, S, max_n1, max_n2, max_taps, d1, e->n1_cap, e->hist2[hin].p, e->hist2[hout].p,

@@ -45,6 +45,9 @@ void launch_fft_feed(hipStream_t st, uint32_t n_streams, const float2* fbuf, siz
                      const StreamCall* call, uint32_t fir_hist_cap);
 void launch_spectrum_commit(hipStream_t st, uint32_t n_streams, const float2* raw, float2* spec, float* power,
                             SpectrumStatsDev* stats, const StreamCall* call, double rate, int bins_sep);
+// The transform and the commit in one launch, one wave per stream (kernels/spectrum_wave.hip); tw4096[m] = (cos, -sin)(2 pi m / 4096).
+void launch_spectrum_wave(hipStream_t st, uint32_t n_streams, const float2* fft_in, const float2* tw4096, float2* spec, float* power,
+                          SpectrumStatsDev* stats, const StreamCall* call, double rate, int bins_sep);
 void launch_fir_demod(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_taps, const float2* fbuf, size_t stride,
                       const float* taps, uint32_t taps_stride, float* demod, size_t demod_stride, float2* filtered /*or null*/,
                       const DemodCarry* carry_in, DemodCarry* carry_out, const StreamCall* call, uint32_t fir_hist_cap,
@@ -81,6 +84,8 @@ struct TailArgs {
     // symbol extractor (same rings and state as launch_symbols)
     float* ring; uint32_t ring_cap; SymState* sym; unsigned long long* flipmask; float* wsum; const SymbolParams* sp;
     uint32_t* slots; uint32_t slot_words; uint32_t* flips_dbg; uint32_t flips_cap;
+    // spectrum of a stream whose 4096-sample buffer completes in this call, done by the tail itself when fft_tw != nullptr (spectrum_wave.h)
+    const float2* fft_tw; float2* spec; float* power; SpectrumStatsDev* stats; double rate; int bins_sep;
     // LDS carve in bytes from the base of the workgroup's scratch (tail_layout)
     uint32_t pend_max, f_off, v_off, ws_off, words_off, tp_off, h2_off, lmask_off, flips_off, fl_cap, strips_off, wc_off, wc_cap, vc_off, vc_cap, lds_bytes;
 };

@@ -49,7 +49,8 @@ bool tail_layout(TailArgs& a, int lanes, int ratio2, int ntaps2, uint32_t max_ta
     a.flips_off = off; off += fl_cap * 8;
     a.strips_off = off; off += (NT / 64) * kTailStrip * 4;
     a.wc_off = off;
-    const uint32_t need = stream_phase > off + 6144 ? stream_phase : off + 6144;   // at least 1024 cached window sums + 512 cached samples
+    uint32_t need = stream_phase > off + 6144 ? stream_phase : off + 6144;   // at least 1024 cached window sums + 512 cached samples
+    if (need < kTailHdrBytes + kSpecWaveLds) need = kTailHdrBytes + kSpecWaveLds;   // the spectrum's transpose plane (spectrum_wave.h) reuses the scratch at the end
     if (need > lds_limit) return false;
     uint32_t want = off + 4 * (2560 + 1536);                             // window sums of ~four symbols of backlog at 50 baud, samples of one call and a half
     if (want < need) want = need;

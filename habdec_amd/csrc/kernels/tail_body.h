@@ -23,6 +23,7 @@
 #include "exact_math.h"
 #include "launch.h"
 #include "sym_common.h"
+#include "spectrum_wave.h"
 
 namespace hd {
 
@@ -644,7 +645,9 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     if (!run && tid == 0) a.carry_out[s] = kin;
     TSTAMP(7);
 
-    // ---- symbol extractor, second half: edge search, run means, bits (SymbolExtractor.h:129-158)
+    // ---- symbol extractor, second half: edge search, run means, bits (SymbolExtractor.h:129-158).  (A lambda, so that its early exits
+    // all lead to the one place behind it where a completed spectrum buffer is transformed.)
+    auto second_half = [&]() {
     uint32_t* outw = slot + sizeof(BitsHeader) / 4;
     const uint32_t cap_bits = (a.slot_words - sizeof(BitsHeader) / 4) * 32;
     if (!m) {
@@ -841,6 +844,17 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         hdr->nbits = nbits; hdr->held_after = st.held; hdr->nflips = nfl; hdr->overflow = overflow; hdr->uncached = end - st.cached;
     }
     TSTAMP(11);
+    };
+    second_half();
+    // ---- the stream's spectrum, when its 4096-sample buffer completed in this call (Decoder.h:475-489): transform, half swap, power and
+    // AFC statistics by this same wave (spectrum_wave.h) -- no launches of their own, no fft_raw round trip.  The buffer's last samples
+    // were stored by this workgroup a moment ago.
+    if (a.fft_tw && c.fft_run) {
+        __threadfence_block();
+        tb_sync<NT>();                                                  // every wave is done with the LDS images
+        if (wave == 0)
+            spectrum_wave_body(a.fft_in, a.fft_tw, a.spec, a.power, a.stats, s, a.rate, a.bins_sep, reinterpret_cast<float*>(lds + kTailHdrBytes));
+    }
     TSTAMP_WRITE();
 }
 

@@ -147,9 +147,16 @@ def test_chain_identical_to_oracle(hd, name):
     assert eng.sentences_ok() == sum(len(o.sentences()) for o in orcs)
 
 
-def test_cfg4_50baud_7N2_with_offsets_and_afc(hd):
-    """configs[3] shape on few streams: /64, 50 baud 7N2, per-stream carrier offsets; AFC outputs every call."""
+@pytest.mark.parametrize("spectrum_by", ["tail", "rocfft", "wave_launch"])
+def test_cfg4_50baud_7N2_with_offsets_and_afc(hd, monkeypatch, spectrum_by):
+    """configs[3] shape on few streams: /64, 50 baud 7N2, per-stream carrier offsets; AFC outputs every call.  The spectrum of a completed
+    buffer comes from the stream tail itself (default), from rocFFT + the commit kernel (HD_ROCFFT=1), or from the single-wave kernel as a
+    launch of its own (HD_ROCFFT=1 HD_OWN_FFT=1): the same tolerances against the exact DFT for all three."""
     from oracle import pyoracle
+    if spectrum_by != "tail":
+        monkeypatch.setenv("HD_ROCFFT", "1")
+    if spectrum_by == "wave_launch":
+        monkeypatch.setenv("HD_OWN_FFT", "1")
     S, fs = 4, 2.048e6
     texts = [synth.make_sentence("A", str(s)) * 3 for s in range(S)]
     iq, _ = make_streams(S, fs, 50, 7, 2, f0=[0.0, 120.0, -200.0, 1500.0], seed0=7, texts=texts)

@@ -36,7 +36,7 @@ def headline_ring():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("shares", ["drawn", "drawn2", "fixed", "deep"])
+@pytest.mark.parametrize("shares", ["drawn", "drawn2", "fixed", "deep", "rocfft"])
 def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, shares):
     """shares: how the step launch's stage-1 workgroups get their tiles -- runs of four drawn from per-XCD counters (the default), runs of
     two, or the fixed shares of HD_NO_CLAIM (the first call of a stream, which restarts its history, always takes fixed shares); "deep" = pipeline 2,
@@ -47,6 +47,8 @@ def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, s
         monkeypatch.setenv("HD_STEP_RUN", "2")
     if shares == "fixed":
         monkeypatch.setenv("HD_NO_CLAIM", "1")
+    if shares == "rocfft":                                   # the spectra as launches of their own (rocFFT + commit) instead of inside the tails
+        monkeypatch.setenv("HD_ROCFFT", "1")
     w, ring, ring_chunks = headline_ring
     S, fs = w["S"], w["fs"]
     # 7/8 of the streams are within +-200 Hz, every 8th is far off: sample both kinds (and the first / last stream of XCD blocks)
