@@ -8,7 +8,7 @@
 // over n1 in registers; the result is multiplied by W4096^(n2 k1) (table in HBM/L2, computed in double on the host); an LDS transpose
 // (one float plane at a time, 65-float pitch: conflict-free both ways) hands lane k1 the 64 values of all n2; pass 2 is the same
 // 64-point transform over n2, after which lane k1 holds X[k1 + 64 k2], k2 = 0..63 -- bins that are 64 apart, so the stores of the
-// swapped spectrum and of the power are wave-wide contiguous again.  The 64-point transform is six radix-2 stages on a register
+// swapped spectrum and of the power are wave-wide contiguous again.  The 64-point transform is 8 x 8 eight-point transforms on a register
 // array with compile-time indices and twiddles.
 //
 // Parity: like rocFFT's, this transform is compared norm-wise with the exact DFT (FFTW itself is not available to pin against,
@@ -27,42 +27,75 @@ __device__ static constexpr float kW64[2][32] = {
 #include "fft64_tw.inc"
 };
 
-constexpr int brev6(int v) { return ((v & 1) << 5) | ((v & 2) << 3) | ((v & 4) << 1) | ((v & 8) >> 1) | ((v & 16) >> 3) | ((v & 32) >> 5); }
+// Where bin k of a 64-point transform sits in the register array after fft64 (8 x 8 decomposition, second-level output k2 left in its
+// row): X[k1 + 8 k2] = a[8 k1 + k2].
+constexpr int xpos(int k) { return 8 * (k & 7) + (k >> 3); }
 
-// One radix-2 stage of span M (decimation in time, input in bit-reversed order): a[k+j], a[k+j+M/2] <- u + W t, u - W t, W = W_M^j
-template <int M>
-__device__ __forceinline__ void fft64_stage(f32x2 (&a)[64])
+// 8-point transform of v[0..7] in place, natural order in and out: three radix-2 stages (decimation in time) with W8 = (1 - i)/sqrt(2).
+__device__ __forceinline__ void fft8(f32x2 (&v)[8])
 {
-    constexpr int H = M / 2, STEP = 64 / M;
-#pragma unroll
-    for (int k = 0; k < 64; k += M) {
-#pragma unroll
-        for (int j = 0; j < H; ++j) {
-            const int m = j * STEP;                                  // W_64^m = cos - i sin, m in [0, 32)
-            const f32x2 u = a[k + j], v = a[k + j + H];
-            f32x2 t;
-            if (m == 0) t = v;
-            else if (m == 16) t = (f32x2){v.y, -v.x};
-            else {
-                const float c = kW64[0][m], s = kW64[1][m];
-                t.x = v.x * c + v.y * s;
-                t.y = v.y * c - v.x * s;
-            }
-            a[k + j] = u + t;
-            a[k + j + H] = u - t;
-        }
-    }
+    constexpr float r = 0.70710678118654752440f;
+    // stage 1 on the bit-reversed pairs (0,4) (2,6) (1,5) (3,7)
+    const f32x2 a0 = v[0] + v[4], a1 = v[0] - v[4], a2 = v[2] + v[6], a3 = v[2] - v[6];
+    const f32x2 a4 = v[1] + v[5], a5 = v[1] - v[5], a6 = v[3] + v[7], a7 = v[3] - v[7];
+    // stage 2: twiddles 1, -i
+    const f32x2 a3r = (f32x2){a3.y, -a3.x}, a7r = (f32x2){a7.y, -a7.x};
+    const f32x2 b0 = a0 + a2, b2 = a0 - a2, b1 = a1 + a3r, b3 = a1 - a3r;
+    const f32x2 b4 = a4 + a6, b6 = a4 - a6, b5 = a5 + a7r, b7 = a5 - a7r;
+    // stage 3: twiddles 1, W8, -i, W8^3
+    const f32x2 t5 = (f32x2){(b5.x + b5.y) * r, (b5.y - b5.x) * r};          // b5 * (1 - i)/sqrt(2)
+    const f32x2 t6 = (f32x2){b6.y, -b6.x};                                    // b6 * (-i)
+    const f32x2 t7 = (f32x2){(b7.y - b7.x) * r, (-b7.x - b7.y) * r};         // b7 * (-1 - i)/sqrt(2)
+    v[0] = b0 + b4; v[4] = b0 - b4;
+    v[1] = b1 + t5; v[5] = b1 - t5;
+    v[2] = b2 + t6; v[6] = b2 - t6;
+    v[3] = b3 + t7; v[7] = b3 - t7;
 }
 
-__device__ __forceinline__ void fft64(f32x2 (&a)[64])               // a[brev6(n)] = x[n] in, a[k] = X[k] out
+// 64-point transform on the register array: a[n] = x[n] in (natural order), X[k] = a[xpos(k)] out.  64 = 8 x 8 with n = 8 n1 + n2,
+// k = k1 + 8 k2: eight 8-point transforms over n1 (one per n2) with the twiddle W64^(n2 k1) folded in, then eight over n2 (one per k1).
+// One small transform at a time (the scheduling barriers keep the compiler from interleaving all eight: the array alone takes half of
+// the register file, and a spill inside a step launch queues behind stage 1's tile loads).
+__device__ __forceinline__ void fft64(f32x2 (&a)[64])
 {
-    // (a barrier for the instruction scheduler between the stages: interleaving them breadth-first keeps two stages' worth of values alive)
-    fft64_stage<2>(a); __builtin_amdgcn_sched_barrier(0);
-    fft64_stage<4>(a); __builtin_amdgcn_sched_barrier(0);
-    fft64_stage<8>(a); __builtin_amdgcn_sched_barrier(0);
-    fft64_stage<16>(a); __builtin_amdgcn_sched_barrier(0);
-    fft64_stage<32>(a); __builtin_amdgcn_sched_barrier(0);
-    fft64_stage<64>(a); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) {
+        __builtin_amdgcn_sched_barrier(0);
+        f32x2 v[8];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) v[n1] = a[8 * n1 + n2];
+        fft8(v);
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) {
+            const int m = n2 * k1;                                  // W64^m, m in [0, 49]
+            f32x2 w = v[k1];
+            if (m != 0) {
+                const float c = m < 32 ? kW64[0][m] : -kW64[0][m - 32], sn = m < 32 ? kW64[1][m] : -kW64[1][m - 32];
+                w = (f32x2){w.x * c + w.y * sn, w.y * c - w.x * sn};
+            }
+            a[8 * k1 + n2] = w;
+        }
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) {
+        __builtin_amdgcn_sched_barrier(0);
+        f32x2 v[8];
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) v[n2] = a[8 * k1 + n2];
+        fft8(v);
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) a[8 * k1 + k2] = v[k2];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// All 64 values become opaque at this point of the program: nothing computed from them can be moved in front of it and nothing they are
+// computed from behind it.  (The instruction-scheduler barriers do not bind the optimiser: it started the power computation of the first
+// bins in the middle of the second pass, and the extra live values spilled -- a spill inside a step launch queues behind stage 1's loads.)
+__device__ __forceinline__ void pin64(f32x2 (&a)[64])
+{
+#pragma unroll
+    for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(a[i]));
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -101,7 +134,7 @@ __device__ __forceinline__ void spectrum_wave_body(const float2* __restrict__ ff
         const float2* xg = x + 64 * g;
         asm volatile("" : "+s"(xg));
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const float2 v = xg[64 * u + l]; a[specwave::brev6(g + u)] = (f32x2){v.x, v.y}; }
+        for (int u = 0; u < 8; ++u) { const float2 v = xg[64 * u + l]; a[g + u] = (f32x2){v.x, v.y}; }
     }
     specwave::fft64(a);
     // ---- twiddle W4096^(n2 k1), then the transpose (lane n2, register k1) -> (lane k1, register n2), one plane at a time
@@ -111,7 +144,7 @@ __device__ __forceinline__ void spectrum_wave_body(const float2* __restrict__ ff
         __builtin_amdgcn_sched_barrier(0);
         float2 w[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) w[u] = tw4096[(l * (uint32_t)(g + u)) & (kFftBins - 1)];   // (cos, -sin)
+        for (int u = 0; u < 16; ++u) w[u] = tw4096[(l * (uint32_t)specwave::xpos(g + u)) & (kFftBins - 1)];   // (cos, -sin); register i holds k1 = xpos(i)
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const f32x2 v = a[g + u];
@@ -120,28 +153,31 @@ __device__ __forceinline__ void spectrum_wave_body(const float2* __restrict__ ff
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k1 = 0; k1 < 64; ++k1) plane[k1 * 65 + l] = a[k1].x;
+    for (int k1 = 0; k1 < 64; ++k1) plane[k1 * 65 + l] = a[specwave::xpos(k1)].x;
     __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0): the plane is wave-private
     __builtin_amdgcn_wave_barrier();
     // (the two components move independently: .x of every register is replaced while .y still sits at its pass-1 index)
 #pragma unroll
-    for (int n2 = 0; n2 < 64; ++n2) a[specwave::brev6(n2)].x = plane[l * 65 + n2];
+    for (int n2 = 0; n2 < 64; ++n2) a[n2].x = plane[l * 65 + n2];
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k1 = 0; k1 < 64; ++k1) plane[k1 * 65 + l] = a[k1].y;
+    for (int k1 = 0; k1 < 64; ++k1) plane[k1 * 65 + l] = a[specwave::xpos(k1)].y;
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int n2 = 0; n2 < 64; ++n2) a[specwave::brev6(n2)].y = plane[l * 65 + n2];
-    // ---- pass 2: transform over n2; a[k2] = X[l + 64 k2]
+    for (int n2 = 0; n2 < 64; ++n2) a[n2].y = plane[l * 65 + n2];
+    // ---- pass 2: transform over n2; a[xpos(k2)] = X[l + 64 k2]
+    specwave::pin64(a);
     specwave::fft64(a);
+    specwave::pin64(a);
     // ---- half swap, dB power, statistics.  Bin k = l + 64 k2 lands at i = (k + 2048) & 4095 = l + 64 j, j = (k2 + 32) & 63.
     float2* so = spec + (size_t)s * kFftBins;
     float* po = power + (size_t)s * kFftBins;
     int mybad = 0;
     double lsum = 0.0;
-    float p[64];                                                    // p[j] = P[l + 64 j]
+    // P[l + 64 j] replaces the real part of the bin it was computed from (register xpos((j + 32) & 63)): no second array beside a[]
+#define HD_SW_P(j_) a[specwave::xpos(((j_) + 32) & 63)].x
     float2* sg = so;
     float* pg = po;
 #pragma unroll
@@ -152,14 +188,14 @@ __device__ __forceinline__ void spectrum_wave_body(const float2* __restrict__ ff
             asm volatile("" : "+s"(sg), "+s"(pg));
         }
         const int k2 = (j + 32) & 63;
-        const f32x2 v = a[k2];
+        const f32x2 v = a[specwave::xpos(k2)];
         sg[l + 64 * (j & 7)] = make_float2(v.x, v.y);
         float q = (v.x * v.x + v.y * v.y) / (float)kFftBins;
         q = q * q;
         q = (float)((double)q / rate);
         q = 10.0f * log10f(q);
         if (v.x != v.x || v.y != v.y || isinf(v.x) || isinf(v.y) || q != q || isinf(q)) mybad = 1;
-        p[j] = q;
+        HD_SW_P(j) = q;
         pg[l + 64 * (j & 7)] = q;
         lsum += (double)q;
     }
@@ -170,22 +206,24 @@ __device__ __forceinline__ void spectrum_wave_body(const float2* __restrict__ ff
     int bi = kFftBins;
 #pragma unroll
     for (int j = 0; j < 64; ++j) {                                  // ascending index inside the lane
-        const double d = (double)p[j] - mean;
+        const float pj = HD_SW_P(j);
+        const double d = (double)pj - mean;
         lvar += d * d;
-        if (p[j] > bv) { bv = p[j]; bi = (int)l + 64 * j; }
+        if (pj > bv) { bv = pj; bi = (int)l + 64 * j; }
     }
     const double sigma = sqrt(specwave::wave_sum(lvar) / (double)kFftBins);
     specwave::wave_argmax(bv, bi);
     const int p1 = bi;
     const float p1v = bv;
     const int lo = max(p1 - 2 * bins_sep, 0), hi = min(p1 + 2 * bins_sep, (int)kFftBins);
-    const float floor0 = __shfl(p[0], 0, 64);                       // P[0]
+    const float floor0 = __shfl(HD_SW_P(0), 0, 64);                 // P[0]
     float cv = -__builtin_huge_valf();
     int ci = kFftBins;
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
         const int i = (int)l + 64 * j;
-        if (i >= lo && i < hi && p[j] > floor0 && abs(i - p1) > bins_sep / 2 && p[j] > cv) { cv = p[j]; ci = i; }
+        const float pj = HD_SW_P(j);
+        if (i >= lo && i < hi && pj > floor0 && abs(i - p1) > bins_sep / 2 && pj > cv) { cv = pj; ci = i; }
     }
     specwave::wave_argmax(cv, ci);
     if (l == 0) {
@@ -199,6 +237,7 @@ __device__ __forceinline__ void spectrum_wave_body(const float2* __restrict__ ff
         o.mean = mean; o.sigma = sigma;
         stats[s] = o;
     }
+#undef HD_SW_P
 }
 
 }  // namespace hd
