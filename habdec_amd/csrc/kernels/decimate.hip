@@ -182,7 +182,7 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
     // Edge tiles (the history tile of every stream): branch-free address selection so the loads still issue
     // back to back -- out-of-range samples read a safe address and are zeroed afterwards.
     float4 r[ITER];
-    auto load_tile = [&](uint32_t tile_i) {                 // tile tile_i of stream pf_s
+    auto load_tile = [&](uint32_t tile_i, const bool fast) {   // tile tile_i of stream pf_s; fast: try the plain path for interior tiles
         const float2* in_s = in + (size_t)pf_s * in_stride;
         const float2* hist_s = hist_in + (size_t)pf_s * (T - 1);
         const bool zero_hist = pf_zero_hist;
@@ -196,6 +196,20 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
         };
         const long xe = (long)tile_i * TOUT * D - (T - 1) - JS;    // stream sample of LDS slot 0; even
         const float4* src = reinterpret_cast<const float4*>(in_s + xe);
+#ifndef HD_DEC_NO_FASTLOAD
+        // A tile that lies wholly inside this call's input -- all but a stream's first and (sometimes) last: one scalar test, then ITER
+        // plain loads off one scalar base with immediate offsets.  (Tested per sweep, the compiler kept the bounds in vector registers
+        // and put ten instructions between consecutive loads.)
+        if (fast && __builtin_amdgcn_readfirstlane((int)(xe >= 0 && xe + 2L * ITER * TO <= (long)n))) {
+            const uint64_t b64 = reinterpret_cast<uint64_t>(src);
+            const char* base = reinterpret_cast<const char*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b64 >> 32)) << 32) |
+                                                             (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64));
+            const uint32_t lane_off = threadIdx.x * 16u;
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) r[it] = *reinterpret_cast<const float4*>(base + (lane_off + (uint32_t)it * (TO * 16u)));
+            return;
+        }
+#endif
         // Per sweep of TO pairs: plain aligned 16-byte loads when the whole sweep lies inside this call's input (wave-uniform
         // test); only the sweeps that touch the history in front of the stream (first tile: the first ceil((T-1)/2/TO) sweeps)
         // or the end of the input take the address-selecting path.
@@ -226,7 +240,7 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
     }
 #endif
     DSTAMP_DECL;
-    load_tile(first);
+    load_tile(first, false);                                // (a workgroup's first tile: once, through the general path only)
     const float2* p = tile + threadIdx.x * (RD + 2);
     // A tile's outputs are stored one iteration late, just BEFORE the next prefetch is issued: loads and stores retire
     // through one in-order counter, so a store issued after the prefetch would make the wait for the prefetched tile also
@@ -270,6 +284,7 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
         DSTAMP(1);
         store_prev();
         if (done) flush_copy();
+        bool pf_do = false; uint32_t pf_which = 0;
         if (claimed && done + 2 == count)                   // one tile before the run ends: draw the next run (in front of the prefetch loads)
             ticket = draw();
         if (claimed && done + 1 == count) {                 // the run's last tile: prefetch the first tile of the run just drawn, if there is one
@@ -279,7 +294,7 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
                 const uint64_t g0 = ((uint64_t)xcd * claim.runs_per_xcd + tk) * claim.run_len;
                 pf_s = (uint32_t)(g0 / lin_ntiles);
                 const uint32_t pf_tile = (uint32_t)(g0 - (uint64_t)pf_s * lin_ntiles);
-                load_tile(pf_tile);
+                pf_do = true; pf_which = pf_tile;
                 count += claim.run_len;
                 jump = true; jump_s = pf_s; jump_first = pf_tile;
             }
@@ -291,8 +306,9 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
                 if (!uniform_n) c_next = *reinterpret_cast<const CallHead*>(call + pf_s);
                 pf_zero_hist = (stage == 0 ? c_next.zero_hist1 : c_next.zero_hist2) != 0;
             }
-            load_tile(pf_tile);
+            pf_do = true; pf_which = pf_tile;
         }
+        if (pf_do) load_tile(pf_which, true);               // (one call site for the loop: the loader is big, and inlined)
         DSTAMP(2);
 
         // The T-term sum, in tap order.  Taps are consumed in blocks of B LDS slots (B/2 ds_read_b128 issued
