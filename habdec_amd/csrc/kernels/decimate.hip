@@ -147,9 +147,9 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
         next_ctr = claim.ctr_next + (size_t)xcd * 32;
         const unsigned int r = drawn(draw());
         if (r >= claim.runs_per_xcd) { if (r == claim.runs_per_xcd) retire(); return; }
-        const uint64_t g0 = ((uint64_t)xcd * claim.runs_per_xcd + r) * claim.run_len;
-        s = (uint32_t)(g0 / lin_ntiles);
-        first = (uint32_t)(g0 - (uint64_t)s * lin_ntiles);
+        const uint32_t g0 = (xcd * claim.runs_per_xcd + r) * claim.run_len;    // (the slab's tile count fits 32 bits: the host checks)
+        s = g0 / lin_ntiles;
+        first = g0 - s * lin_ntiles;
         count = claim.run_len;
     } else if (linear) {
         const uint64_t total = (uint64_t)n_streams * lin_ntiles;
@@ -275,7 +275,7 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int k = threadIdx.x + it * TO;
-            if (k < NP) {
+            if ((it + 1) * TO <= NP || k < NP) {                // (only the last sweep is partial: no per-sweep lane masks for the others)
                 const int jj = 2 * k;
                 *reinterpret_cast<float4*>(tile + jj + 2 * (jj / RD)) = r[it];
             }
@@ -291,9 +291,9 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
             const unsigned int tk = drawn(ticket);
             if (tk == claim.runs_per_xcd) retire();
             if (tk < claim.runs_per_xcd) {
-                const uint64_t g0 = ((uint64_t)xcd * claim.runs_per_xcd + tk) * claim.run_len;
-                pf_s = (uint32_t)(g0 / lin_ntiles);
-                const uint32_t pf_tile = (uint32_t)(g0 - (uint64_t)pf_s * lin_ntiles);
+                const uint32_t g0 = (xcd * claim.runs_per_xcd + tk) * claim.run_len;
+                pf_s = g0 / lin_ntiles;
+                const uint32_t pf_tile = g0 - pf_s * lin_ntiles;
                 pf_do = true; pf_which = pf_tile;
                 count += claim.run_len;
                 jump = true; jump_s = pf_s; jump_first = pf_tile;
