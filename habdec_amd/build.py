@@ -43,7 +43,10 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     build_dir = HERE / "build"
     build_dir.mkdir(exist_ok=True)
     extra = os.environ.get("HD_EXTRA_FLAGS", "").split()
-    common = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", *extra,
+    common = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+              # (the atomic optimiser rewrites lane 0's ticket draw in the step kernel into a form that needs the old value at once: the wave
+              # would wait for the round trip it issues a tile early precisely not to wait for)
+              "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", *extra,
               "-Wall", "-Wno-unused-function", "-I", str(HERE.parent / "include"), "-I", str(CSRC)]
     procs = []
     for src in SOURCES:

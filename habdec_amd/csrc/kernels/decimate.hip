@@ -295,7 +295,7 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
                 pf_s = g0 / lin_ntiles;
                 const uint32_t pf_tile = g0 - pf_s * lin_ntiles;
                 pf_do = true; pf_which = pf_tile;
-                count += claim.run_len;
+                count = (uint32_t)__builtin_amdgcn_readfirstlane((int)(count + claim.run_len));   // (stays a scalar: the loop bound)
                 jump = true; jump_s = pf_s; jump_first = pf_tile;
             }
         } else
