@@ -1,8 +1,8 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for flags in "-DHD_STAMP_DEC" "-DHD_STAMP_DEC -DHD_DEC_OLDLOOP"; do
+for flags in "-DHD_STAMP_DEC"; do
 echo "=== [$flags]"
 HD_EXTRA_FLAGS="$flags" python3 -m habdec_amd.build --force 2>&1 | grep -E "error" | head
-for w in ${WGS:-8192}; do echo "--- HD_STEP_WGS=$w"; HD_STEP_WGS=$w python3 tools/micro/step_stamps.py 2>&1 | tail -8; done
-echo "--- stage 1 alone (synchronous)"; python3 tools/micro/dec_stamps.py 2>&1 | tail -8
+echo "--- step launch (drawn runs)"; HD_STEP_WGS=2048 timeout 120 python3 tools/micro/step_stamps.py 2>&1 | tail -8
+echo "--- stage 1 alone (synchronous)"; timeout 120 python3 tools/micro/dec_stamps.py 2>&1 | tail -8
 done
