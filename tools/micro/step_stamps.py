@@ -15,6 +15,7 @@ for i in range(30):
 eng.flush()
 st = np.zeros(4096 * 8, np.uint64); f(st.ctypes.data, 4096 * 8); st = st.reshape(4096, 8).astype(np.float64)
 st = st[st[:, 7] > 0]
+st = st[st[:, 0] >= st[:, 0].max() - 100000]      # the last launch only (100 MHz ticks: 1 ms): with drawn runs a workgroup that finds no run writes nothing
 t0 = st[:, 0].min()
 start, end = (st[:, 0] - t0) / 100.0, (st[:, 2] - t0) / 100.0
 print("stage-1 workgroups:", len(st), "tiles per WG:", st[0, 7], " step kernel ms:", eng.timing()["ms_front"])
