@@ -1,6 +1,6 @@
 # PCIe-inclusive rate of the boundary's host entry point (hd_process_host): the slab is copied H2D inside every call.
 import sys, time, ctypes, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import torch, bench, habdec_amd
 w = dict(bench.WORKLOADS["cfg4"]); S = 1024; C = w["C"]
 eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"])

@@ -1,7 +1,7 @@
 """Stage-1 workgroups inside the step kernel (diagnostic build: HD_EXTRA_FLAGS=-DHD_STAMP_DEC): when they run and what a tile costs them,
 early in the launch (beside the stream tails) and late (alone)."""
 import sys, ctypes, os, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 os.environ.setdefault("HD_STEP_WGS", "4096")
 import torch, bench, habdec_amd
 w = dict(bench.WORKLOADS["cfg4"]); S = 1024; C = w["C"]

@@ -1,5 +1,5 @@
 import sys, ctypes, numpy as np, json, subprocess
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import torch, bench, habdec_amd
 w = dict(bench.WORKLOADS["cfg4"]); S = 1024; C = w["C"]
 dev = torch.device("cuda", 0)

@@ -1,6 +1,6 @@
 """How a stream tail's duration moves along the benchmark ring (diagnostic build: -DHD_STAMP_TAIL), on-tune vs far-off streams."""
 import sys, ctypes, os, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import torch, bench, habdec_amd
 w = dict(bench.WORKLOADS["cfg4"]); S = 1024; C = w["C"]
 dev = torch.device("cuda", 0)

@@ -1,6 +1,6 @@
 """Phase clocks of the stream tail (diagnostic build: HD_EXTRA_FLAGS=-DHD_STAMP_TAIL python -m habdec_amd.build --force)."""
 import sys, ctypes, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import torch, bench, habdec_amd
 w = dict(bench.WORKLOADS["cfg4"]); S = 1024; C = w["C"]
 dev = torch.device("cuda", 0)
