@@ -1,0 +1,4 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+HD_EXTRA_FLAGS="-DHD_STAMP_RING" python3 -m habdec_amd.build --force 2>&1 | grep -E "error" | head
+NCALLS=2 timeout 300 python3 tools/micro/ring_stamps.py 2>&1 | tail -7

@@ -128,6 +128,9 @@ struct hd_engine {
     bool claim_alone = false;  // HD_CLAIM_ALONE: stage 1 as a launch of its own draws its tiles too (measured slower: off)
     bool no_claim = false;     // HD_NO_CLAIM: step launches with fixed shares of tiles (A/B measurements)
     uint32_t step_run = 0;     // HD_STEP_RUN: tiles per drawn run (default 4, minimum 2)
+    bool no_cu_step = false;   // HD_NO_CU_STEP: step launches as single-wave workgroups (k_step) instead of one workgroup per CU (k_step_cu)
+    uint32_t ring_run = 0;     // HD_RING_RUN: tiles per drawn run of k_step_cu's loader (default 8)
+    PinBuf<unsigned int> ring_gave_up;     // mapped host word the waves of k_step_cu bump when a bounded wait runs out (never in a correct run)
     uint64_t step_launches = 0;
     DevBuf<unsigned int> step_ctr;         // two sets of per-XCD run counters ([2][16][32] u32), alternating per step launch
     uint32_t qa_cus = 0;       // HD_CU_SPLIT experiment: CUs the stage-1 queue may use (0 = all)
@@ -309,6 +312,8 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     e->no_claim = getenv("HD_NO_CLAIM") != nullptr;
     e->claim_alone = getenv("HD_CLAIM_ALONE") != nullptr;
     if (const char* v = getenv("HD_STEP_RUN")) e->step_run = (uint32_t)atoi(v);
+    e->no_cu_step = getenv("HD_NO_CU_STEP") != nullptr;
+    if (const char* v = getenv("HD_RING_RUN")) e->ring_run = (uint32_t)atoi(v);
     if (const char* v = getenv("HD_STEP_WGS")) e->step_wgs = (uint32_t)atoi(v);
     if (const char* v = getenv("HD_TAIL_LANES")) e->tail_lanes = atoi(v);
     if (const char* v = getenv("HD_TAIL_MAX_N2")) e->tail_max_n2 = (uint32_t)strtoul(v, nullptr, 0);
@@ -370,7 +375,18 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     // device memory
     HD_HIP(e->staging.alloc((size_t)S * cfg->max_chunk));
     if (e->stages.size() == 2) for (auto* b : {&e->dec1, &e->dec1b, &e->dec1c}) HD_HIP(b->alloc((size_t)S * e->n1_cap));
-    HD_HIP(e->step_ctr.alloc(2 * 16 * 32));
+    HD_HIP(e->step_ctr.alloc(2 * 16 * 32 + 32));
+    HD_HIP(e->ring_gave_up.alloc(4));
+    e->ring_gave_up.p[0] = 0;
+    if (!e->no_claim && e->n_cus % 32u == 0) {
+        // The drawn runs of the step launches are split by the hardware's XCC id (kernels/decimate.hip, stage1_ring.h): every id in
+        // [0, n_cus / 32) must show up in a chip-filling grid and no other may.  A CU mask or a partition mode that breaks that
+        // turns the draws off (fixed shares: slower, never wrong).
+        const uint32_t n_xcd = e->n_cus / 32u;
+        const uint32_t seen = hd::probe_xcc_mask(e->qa, e->n_cus, e->step_ctr.p + 2 * 16 * 32);
+        if (n_xcd > 16 || seen != (n_xcd >= 32 ? 0xFFFFFFFFu : (1u << n_xcd) - 1u)) e->no_claim = true;
+    } else
+        e->no_claim = true;
     if (e->stages.size() >= 1) {
         for (auto& h : e->hist1) HD_HIP(h.alloc((size_t)S * (e->stages[0].taps.size() - 1)));
         HD_HIP(e->stage_taps[0].alloc(e->stages[0].taps.size()));
@@ -498,6 +514,16 @@ int hd_engine_timing(hd_engine* e, hd_timing* out)
 {
     if (!e || !out) return fail(HD_ERR_INVALID, "null argument");
     *out = e->last_timing;
+    return HD_OK;
+}
+
+// diagnostic (not in include/habdec_amd.h): the two sets of per-XCD run counters of the step launches, [2][16] (after a device-wide wait)
+extern "C" int hd_debug_step_counters(hd_engine* e, unsigned int* out32)
+{
+    if (!e || !out32) return HD_ERR_INVALID;
+    std::vector<unsigned int> h(2 * 16 * 32);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h.data(), e->step_ctr.p, h.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return HD_ERR_DEVICE;
+    for (int i = 0; i < 32; ++i) out32[i] = h[(size_t)i * 32];
     return HD_OK;
 }
 
@@ -635,6 +661,12 @@ int collect(hd_engine* e, hd_engine::CallSlot& sl)
         ++e->last_timing.timed_calls;
     }
     int rc = HD_OK;
+    if (e->ring_gave_up.p && e->ring_gave_up.p[0]) {
+        char msg[128];
+        snprintf(msg, sizeof msg, "k_step_cu: a bounded wait ran out (consumers %u, loaders %u): results of this call are incomplete", e->ring_gave_up.p[0] & 0xFFFFu, e->ring_gave_up.p[0] >> 16);
+        e->ring_gave_up.p[0] = 0;
+        rc = fail(HD_ERR_DEVICE, msg);
+    }
     for (uint32_t s = 0; s < e->S; ++s) {
         StreamHost& st = e->st[s];
         const hd::StreamCall& c = sl.h_call.p[s];
@@ -882,9 +914,10 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     };
     // Equally sized pushes through a single-wave first stage of a two-stage plan: the stage-1 workgroups (eight resident per CU) draw
     // runs of tiles from per-XCD counters (kernels/decimate.hip) -- no cold start per run, no fixed shares that end ragged.
-    auto make_claim = [&](uint32_t lin_wgs /* stage 1 as a launch of its own: the workgroup count of its linear split (which needs four tiles per workgroup); 0 = step launch */) {
+    auto make_claim = [&](uint32_t lin_wgs /* stage 1 as a launch of its own: the workgroup count of its linear split (which needs four tiles per workgroup); 0 = step launch */,
+                          uint32_t run_len_cu = 0 /* != 0: runs for k_step_cu's loader */) {
         hd::StepClaim claim{};
-        const uint32_t ntiles = (max_n1 + 63) / 64, n_xcd = e->n_cus / 32u, run_len = e->step_run >= 2 ? e->step_run : 4u;   // (a run must hold the tile in front of which the next draw is issued: at least two; four re-read fewer halos than two)
+        const uint32_t ntiles = (max_n1 + 63) / 64, n_xcd = e->n_cus / 32u, run_len = run_len_cu ? run_len_cu : e->step_run >= 2 ? e->step_run : 4u;   // (a run must hold the tile in front of which the next draw is issued: at least two; four re-read fewer halos than two)
         const uint64_t runs = (uint64_t)S * ntiles / run_len;
         if (!e->no_claim && nst == 2 && (R1 == 32 || R1 == 64) && min_in == max_in && max_in && !any_zero1 && n_xcd && e->n_cus % 32u == 0 && n_xcd <= 16 &&
             ntiles % run_len == 0 && runs % n_xcd == 0 && max_n1 % 64 == 0 && !e->qa_cus && (uint64_t)S * ntiles < (1ull << 32) && (uint64_t)ntiles * S >= 4ull * lin_wgs) {   // (the two counter sets alternate: a launch that takes one must really run that way)
@@ -903,8 +936,28 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         hd_engine::CallSlot* ps = prev.valid ? &e->slot[prev.slot] : nullptr;
         if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
         uint32_t wgs = e->step_wgs ? e->step_wgs : 32u * e->n_cus;   // short runs of tiles: the dispatcher evens out the tail of the launch
-        const hd::StepClaim claim = make_claim(0);
+        // One workgroup per CU (loader + consumer waves for stage 1, the tails in the other four waves) where the plan and the sizes allow it
+        const uint32_t cu_tail = hd::step_cu_tail_lds((int)R1, (int)T1);
+        const uint32_t ntiles1 = (max_n1 + 63) / 64;
+        uint32_t ring_run = e->ring_run >= 2 ? e->ring_run : 8u;
+        while (ring_run > 2 && (ntiles1 % ring_run || ((uint64_t)S * ntiles1 / ring_run) % (e->n_cus / 32u ? e->n_cus / 32u : 1u))) ring_run >>= 1;
+        const bool want_cu = !e->no_cu_step && cu_tail && !any_zero1 && max_in % 2048u == 0 && ta_step.lds_bytes <= cu_tail &&
+                             (!prev.valid || prev.ta.lds_bytes <= cu_tail);
+        const hd::StepClaim claim = make_claim(0, want_cu ? ring_run : 0u);
         if (claim.ctr && !e->step_wgs) wgs = 8u * e->n_cus;
+        bool launched = false;
+        e->last_timing.step_variant = 0;
+        if (want_cu && claim.ctr) {
+            const uint32_t tb = std::max(ta_step.lds_bytes, prev.valid ? prev.ta.lds_bytes : 0u);
+            static const int cu_exp = getenv("HD_CU_EXP") ? atoi(getenv("HD_CU_EXP")) : 0;   // timing experiments only (results wrong): 1 = no tails, 2 = no stage 1
+            hd::StepClaim cl = claim;
+            if (cu_exp & 2) cl.runs_per_xcd = 0;
+            launched = hd::launch_step_cu(qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, e->n_cus, iq, stride,
+                                          e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, prev.ta,
+                                          (prev.valid && !(cu_exp & 1)) ? S : 0u, max_in, cl, (tb + 15u) & ~15u, e->ring_gave_up.dev);
+            e->last_timing.step_variant = launched ? 1u : 0u;
+        }
+        if (!launched)
         if (!hd::launch_step(qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, max_n1, iq, stride, e->hist1[hin].p,
                              e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, wgs, prev.ta, prev.valid ? S : 0u,
                              any_zero1 ? 0u : max_in, claim))

@@ -25,6 +25,7 @@
 
 #include "launch.h"
 #include "tail_body.h"
+#include "stage1_ring.h"
 
 #ifndef HD_DEC_LA
 #define HD_DEC_LA 4        // products this many taps ahead of the sum in the single-wave first stages
@@ -558,6 +559,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                             blockIdx.x - n_tail, 0u, gridDim.x - n_tail, tile4, uniform_n, claim);
 }
 
+// The step launch as ONE workgroup per CU (512 threads, all of the CU's LDS), roles by wave: wave 0 streams this call's stage-1 tiles
+// into an LDS ring with LDS-DMA, waves 1-3 compute them (stage1_ring.h), waves 4-7 run the previous call's stream tails -- four
+// streams per CU at 1024 streams, each in its own slice of LDS -- and afterwards leave the device copy of their streams' parameter
+// blocks for the next launch.  Compared with k_step (single-wave workgroups, dispatcher-scheduled) the loads of stage 1 never stop
+// while the tails hold half of the CU's wave slots, and what runs where does not depend on the dispatcher.
+template <int T, int D2, int T2>
+__global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const StreamCall* __restrict__ call, StreamCall* __restrict__ call_copy,
+                                                 const TailArgs ta, const uint32_t n_tail, const uint32_t n_streams, const uint32_t tail_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char cu_lds[];
+    unsigned char* ring = cu_lds;
+    RingCtl* ctl = reinterpret_cast<RingCtl*>(cu_lds + kRingSlots * ring_slot_bytes<T>());
+    unsigned char* tails = cu_lds + ring_bytes<T>();
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (threadIdx.x < sizeof(RingCtl) / 4) reinterpret_cast<uint32_t*>(ctl)[threadIdx.x] = threadIdx.x == 2 ? 0xFFFFFFFFu : 0u;   // end_seq = "not known yet"
+    __syncthreads();
+    if (w == 0) {
+#ifdef HD_RING_LOADER_PRIO
+        __builtin_amdgcn_s_setprio(HD_RING_LOADER_PRIO);
+#endif
+        ring_loader<T>(ra, ring, ctl);
+    } else if (w < 4) {
+        ring_consumer<T>(ra, ring, ctl);
+    } else {
+        __builtin_amdgcn_s_setprio(HD_STEP_PRIO);
+        const uint32_t k = w - 4u, lane = threadIdx.x & 63u;
+        const uint32_t s = blockIdx.x * 4u + k;                          // (the grid has at least n_streams / 4 workgroups)
+        if (s >= n_streams) return;
+        if (s < n_tail) tail_body<64, 4, D2, T2>(ta, s, tails + k * tail_bytes);
+        // this call's parameters live in mapped host memory; the tails of this call (next launch) read the device copy
+        if (call_copy && lane < 4) reinterpret_cast<uint4*>(call_copy + s)[lane] = reinterpret_cast<const uint4*>(call + s)[lane];
+    }
+}
+
+// XCC ids seen by a grid of single-wave workgroups: the run counters of the step launches are per XCD and indexed by the hardware's id
+// (a CU mask or a partition mode that hides an XCD, or numbers it differently, must switch the drawn runs off -- engine.cpp).
+__global__ void k_xcc_probe(unsigned int* mask)
+{
+    if (threadIdx.x == 0) atomicOr(mask, 1u << (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u));
+}
+
 __global__ void k_passthrough(const float2* __restrict__ in, size_t in_stride, float2* __restrict__ out, size_t out_stride,
                               const StreamCall* __restrict__ call, uint32_t fir_hist_cap)
 {
@@ -661,6 +703,46 @@ bool launch_step(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, u
     HD_STEP_CASE(32, 212, 2, 69) HD_STEP_CASE(32, 174, 4, 139) HD_STEP_CASE(64, 348, 4, 139)
 #undef HD_STEP_CASE
     return false;
+}
+
+uint32_t step_cu_tail_lds(int ratio, int ntaps)
+{
+    auto lim = [](int rb) { const uint32_t left = (163840u - (uint32_t)rb) / 4u; return (left < kStepLdsBytes ? left : kStepLdsBytes) & ~15u; };
+    if (ratio == 32 && ntaps == 212) return lim(ring_bytes<212>());
+    if (ratio == 32 && ntaps == 174) return lim(ring_bytes<174>());
+    return 0;
+}
+
+bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, uint32_t n_streams, uint32_t n_cus, const float2* in, size_t in_stride,
+                    const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
+                    StreamCall* call_copy, const TailArgs& ta, uint32_t n_tail, uint32_t uniform_n, const StepClaim& claim, uint32_t tail_bytes, unsigned int* gave_up)
+{
+    if (ratio != 32 || !claim.ctr || !uniform_n || uniform_n % 2048u) return false;
+    RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, uniform_n / 2048u, claim, gave_up};
+#define HD_CU_CASE(T, D2, T2)                                                                                                         \
+    if (ntaps == T && ratio2 == D2 && ntaps2 == T2) {                                                                                 \
+        const uint32_t lds = (uint32_t)ring_bytes<T>() + 4u * tail_bytes;                                                             \
+        if (lds > 163840u) return false;                                                                                              \
+        static bool attr_set = false;                                                                                                 \
+        if (!attr_set) {                                                                                                              \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_cu<T, D2, T2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) return false; \
+            attr_set = true;                                                                                                          \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((k_step_cu<T, D2, T2>), dim3(n_cus > (n_streams + 3u) / 4u ? n_cus : (n_streams + 3u) / 4u), dim3(512), lds, st, ra, call, call_copy, ta, n_tail, n_streams, tail_bytes); \
+        return true;                                                                                                                  \
+    }
+    HD_CU_CASE(212, 2, 69) HD_CU_CASE(174, 4, 139)
+#undef HD_CU_CASE
+    return false;
+}
+
+uint32_t probe_xcc_mask(hipStream_t st, uint32_t n_cus, unsigned int* d_word)
+{
+    if (hipMemsetAsync(d_word, 0, 4, st) != hipSuccess) return 0;
+    hipLaunchKernelGGL(k_xcc_probe, dim3(n_cus * 8u), dim3(64), 0, st, d_word);
+    unsigned int h = 0;
+    if (hipMemcpyAsync(&h, d_word, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 0;
+    return h;
 }
 
 void launch_passthrough(hipStream_t st, uint32_t n_streams, uint32_t max_n, const float2* in, size_t in_stride, float2* out,

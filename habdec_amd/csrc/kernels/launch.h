@@ -103,6 +103,15 @@ bool launch_step(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, u
                  StreamCall* call_copy, uint32_t stage1_wgs, const TailArgs& ta, uint32_t n_tail,
                  uint32_t uniform_n /* != 0: the streams' common sample count, and no stream restarts its stage-1 history this call */,
                  const StepClaim& claim = StepClaim{});
+// The same step as ONE 512-thread workgroup per CU (k_step_cu, decimate.hip): LDS-DMA loader + consumer waves for stage 1 (stage1_ring.h), the
+// tails in the other four waves.  Needs a /32 first stage, equally sized pushes that are a multiple of 2048 samples, drawn runs (claim.ctr) and
+// no history restart; returns false otherwise (the caller then launches k_step).  tail_bytes: LDS slice of one tail (<= step_cu_tail_lds).
+bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, uint32_t n_streams, uint32_t n_cus, const float2* in, size_t in_stride,
+                    const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
+                    StreamCall* call_copy, const TailArgs& ta, uint32_t n_tail, uint32_t uniform_n, const StepClaim& claim, uint32_t tail_bytes,
+                    unsigned int* gave_up /* mapped host word, see RingArgs */);
+uint32_t step_cu_tail_lds(int ratio, int ntaps);   // LDS a tail may use inside k_step_cu for that first stage; 0 = no such kernel
+uint32_t probe_xcc_mask(hipStream_t st, uint32_t n_cus, unsigned int* d_word);   // bit x set = some workgroup of a chip-filling grid ran on XCC id x
 uint32_t step_lds_bytes(int ratio, int ntaps);   // LDS of a step-launch workgroup for that first stage (its tile, at least kStepLdsBytes); 0 = no step kernel
 constexpr uint32_t kStepLdsBytes = 20480;   // LDS of a stage-1 workgroup slot (eight per CU): what a tail riding in the stage-1 launch may use
 

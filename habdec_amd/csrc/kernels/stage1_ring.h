@@ -1,0 +1,399 @@
+// First decimation stage (/32) as a loader wave + consumer waves around an LDS ring of tiles -- the stage-1 half of the per-CU step
+// kernel (k_step_cu, decimate.hip).
+//
+// What it computes is decimate.hip's sum (reference code/Decoder/Decimator.h:128-138): out[o] = sum_t buf[32 o + t] * tap[t], every output's T
+// products added by ONE lane in ascending tap order with separately rounded multiply and add.  What differs is who moves the bytes.
+// In the single-wave stage-1 workgroup (decimate_body) a wave is EITHER issuing the next tile's loads OR computing: its tile time is the
+// sum of an issue burst, the data's flight, an LDS store pass and the tap loop, the tile in flight sits in 72 VGPRs, and beside the
+// stream tails of a step launch -- which hold half of a CU's wave slots for the first half of the launch -- the four stage-1 waves left
+// on a CU pull a third of the CU's share of HBM.  Here ONE wave per CU does nothing but keep loads in flight: LDS-DMA
+// (global_load_lds_dwordx4: 64 lanes x 16 bytes straight into LDS, no VGPR destination, no ds_write) into a ring of four tile slots,
+// issued as soon as a slot is free, counted with s_waitcnt vmcnt(N) and published through an LDS word; three consumer waves take
+// published tiles in order and spend all their time in the tap loop.  Loads in flight no longer depend on what the computing waves are
+// doing, and the tile in flight costs no registers.
+//
+// Slot layout = the padded rows the tap loop reads without bank conflicts: rows of 32 samples (256 B, one output's stride) at a pitch
+// of 272 B, so that lane o's window starts 17 sixteen-byte chunks after lane o-1's and the lanes' ds_read_b128 fall into different
+// bank groups.  An LDS-DMA instruction writes 1 KiB CONTIGUOUSLY (wave-uniform base + lane * 16), so the pad cannot be skipped on the
+// LDS side; it is made on the SOURCE side instead: lane l of instruction i owns chunk P = 64 i + l of the slot, which is column
+// P % 17 of row P / 17 -- a data chunk (column < 16: it loads that chunk of the stream) or the pad (column 16: it loads the row's
+// last chunk again, never read).  64 rows are exactly 17 instructions; the HR halo rows in front (the T-1 samples before the tile's
+// first output's stride) are two more -- or, for a stream's first tile, HR dword-wide LDS-DMA rows out of the stage history, whose
+// samples sit at odd 8-byte offsets.
+//
+// Protocol (LDS words, RingCtl): the loader writes desc[seq & 7] = (stream, tile, slot) and, once `s_waitcnt vmcnt(younger instructions)`
+// says the tile has landed, bumps `landed`; a consumer draws seq = taken++ (ds_add_rtn), sleeps until landed > seq, computes, and
+// stores seq + 1 into slot_done[slot]; the loader (lane j watches slot j) sees the slot free again.  `end_seq` tells consumers how many
+// tiles there will be in all.  No s_barrier after the start: the stream tails in the workgroup's other four waves never take part.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "launch.h"
+
+namespace hd {
+
+typedef float r_f32x2 __attribute__((ext_vector_type(2)));
+typedef float r_f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRingRowBytes = 272;                  // 32 samples + one 16-byte pad
+constexpr int kRingSlots = 4;
+constexpr int kRingCtlBytes = 256;
+constexpr uint32_t kRingSpinLimit = 1u << 22;   // polls before a waiting wave gives up (seconds; a correct run waits microseconds)
+template <int T> constexpr int ring_halo_rows() { return (T - 1 + 31) / 32; }
+template <int T> constexpr int ring_slot_bytes() { return (64 + ring_halo_rows<T>()) * kRingRowBytes; }
+template <int T> constexpr int ring_bytes() { return kRingSlots * ring_slot_bytes<T>() + kRingCtlBytes; }
+
+#ifdef HD_STAMP_RING   // diagnostic build only (tools/micro/ring_stamps.py): where the loader and the consumers of k_step_cu spend their cycles
+__device__ unsigned long long g_ring_stamps[512 * 4 * 8];
+extern "C" void hd_debug_ring_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ring_stamps), n * 8); }
+#define RSTAMP_DECL unsigned long long rs_t = __builtin_amdgcn_s_memtime(), rs_acc[6] = {0, 0, 0, 0, 0, 0}; const unsigned long long rs_r0 = __builtin_amdgcn_s_memrealtime()
+#define RSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); rs_acc[i] += t_ - rs_t; rs_t = t_; } while (0)
+#define RSTAMP_WRITE(wave_, n_) do { if ((threadIdx.x & 63u) == 0 && blockIdx.x < 512) { unsigned long long* g_ = g_ring_stamps + ((size_t)blockIdx.x * 4 + (wave_)) * 8; \
+        for (int i_ = 0; i_ < 5; ++i_) g_[i_] = rs_acc[i_]; g_[5] = (n_); g_[6] = rs_r0; g_[7] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define RSTAMP_DECL do { } while (0)
+#define RSTAMP(i) do { } while (0)
+#define RSTAMP_WRITE(wave_, n_) do { } while (0)
+#endif
+
+struct RingCtl {
+    uint32_t landed;        // tiles published so far
+    uint32_t taken;         // next sequence number a consumer draws
+    uint32_t end_seq;       // 0xFFFFFFFF until the loader knows the total
+    uint32_t run_tail;      // runs the feeding consumer has put into run_q so far
+    uint32_t run_head;      // runs the loader has taken out
+    uint32_t run_q[2];      // drawn run numbers (0xFFFFFFFF: no more)
+    uint32_t _pad;
+    uint32_t slot_done[8];  // per slot: 1 + sequence number of the tile last finished in it
+    uint4 desc[8];          // per sequence number & 7: stream, tile, slot
+};
+static_assert(sizeof(RingCtl) <= kRingCtlBytes, "ring control block");
+
+struct RingArgs {
+    const float2* in; size_t in_stride;             // this call's IQ slab
+    const float2* hist_in; float2* hist_out;        // stage history [S][T-1], ping-pong
+    const float* taps;
+    float2* out; size_t out_stride;                 // stage-1 output [S][n/32]
+    uint32_t n;                                     // samples per stream this call (uniform, multiple of 2048)
+    uint32_t ntiles;                                // n / 2048
+    StepClaim claim;
+    unsigned int* gave_up;                          // mapped host word: += 1 by every wave whose bounded wait ran out (never in a correct run; the engine fails the call)
+};
+
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+// s_waitcnt vmcnt(n) for a run-time n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vmcnt(uint32_t n)
+{
+#define HD_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        HD_VMC(0) HD_VMC(1) HD_VMC(2) HD_VMC(3) HD_VMC(4) HD_VMC(5) HD_VMC(6) HD_VMC(7) HD_VMC(8) HD_VMC(9)
+        HD_VMC(10) HD_VMC(11) HD_VMC(12) HD_VMC(13) HD_VMC(14) HD_VMC(15) HD_VMC(16) HD_VMC(17) HD_VMC(18) HD_VMC(19)
+        HD_VMC(20) HD_VMC(21) HD_VMC(22) HD_VMC(23) HD_VMC(24) HD_VMC(25) HD_VMC(26) HD_VMC(27) HD_VMC(28) HD_VMC(29)
+        HD_VMC(30) HD_VMC(31) HD_VMC(32) HD_VMC(33) HD_VMC(34) HD_VMC(35) HD_VMC(36) HD_VMC(37) HD_VMC(38) HD_VMC(39)
+        HD_VMC(40) HD_VMC(41) HD_VMC(42) HD_VMC(43) HD_VMC(44) HD_VMC(45) HD_VMC(46) HD_VMC(47) HD_VMC(48) HD_VMC(49)
+        HD_VMC(50) HD_VMC(51) HD_VMC(52) HD_VMC(53) HD_VMC(54) HD_VMC(55) HD_VMC(56) HD_VMC(57) HD_VMC(58) HD_VMC(59)
+        HD_VMC(60) HD_VMC(61) HD_VMC(62)
+        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+    }
+#undef HD_VMC
+}
+
+// One LDS-DMA instruction: lane l's 16 (4) bytes at base + off go to LDS byte lds_dst + 16 l (4 l).  M0 carries the LDS address and is
+// written in the statement that uses it (the compiler does not preserve it around inline asm).  `base` must be wave-uniform.
+__device__ __forceinline__ void glds16(const void* base, uint32_t off, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const void* base, uint32_t off, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_dst) : "memory");
+}
+
+// Seventeen of them back to back -- a tile's 64 rows -- with M0 stepped by 1 KiB in between: one scalar instruction per DMA instruction
+// instead of five (the loader's issue time per tile is what bounds a CU's stream when nothing else does).
+__device__ __forceinline__ void glds16_x17(const void* base, const uint32_t (&off)[17], uint32_t lds_dst)
+{
+    unsigned keep, scc_keep;                      // (s_add_u32 writes SCC, which compiler code around the statement may hold live: saved and restored)
+#define HD_G1(n) "global_load_lds_dwordx4 %" #n ", %19\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+    asm volatile("s_cselect_b32 %1, 1, 0\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %20\n\ts_nop 0\n\t"
+                 HD_G1(2) HD_G1(3) HD_G1(4) HD_G1(5) HD_G1(6) HD_G1(7) HD_G1(8) HD_G1(9) HD_G1(10) HD_G1(11) HD_G1(12) HD_G1(13) HD_G1(14) HD_G1(15) HD_G1(16) HD_G1(17)
+                 "global_load_lds_dwordx4 %18, %19\n\ts_mov_b32 m0, %0\n\ts_cmp_lg_u32 %1, 0"
+                 : "=&s"(keep), "=&s"(scc_keep)
+                 : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]), "v"(off[8]), "v"(off[9]),
+                   "v"(off[10]), "v"(off[11]), "v"(off[12]), "v"(off[13]), "v"(off[14]), "v"(off[15]), "v"(off[16]), "s"(base), "s"(lds_dst)
+                 : "memory");
+#undef HD_G1
+}
+// HR history rows, one dword-wide DMA instruction per row (pitch 272 bytes)
+template <int HR>
+__device__ __forceinline__ void glds4_rows(const void* base, const uint32_t (&off)[HR], uint32_t lds_dst)
+{
+#pragma unroll
+    for (int r = 0; r < HR; ++r) glds4(base, off[r], lds_dst + (uint32_t)r * kRingRowBytes);
+}
+
+__device__ __forceinline__ const void* uniform_ptr(const void* p)
+{
+    const uint64_t b = reinterpret_cast<uint64_t>(p);
+    return reinterpret_cast<const void*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) << 32) |
+                                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b));
+}
+
+// ---------------------------------------------------------------------------------------------------------------- the loader wave
+template <int T>
+__device__ __forceinline__ void ring_loader(const RingArgs& a, unsigned char* __restrict__ ring, RingCtl* __restrict__ ctl)
+{
+    constexpr int HR = ring_halo_rows<T>();
+    constexpr int SLOT = ring_slot_bytes<T>();
+    constexpr int NBODY = 17;                       // 64 rows x 17 chunks = 17 x 64 chunks
+    constexpr int NHALO = (HR * 17 + 63) / 64;      // halo rows out of the stream itself (every tile but a stream's first)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t ring_lds = lds_addr_of(ring);
+
+    // per-lane source offsets (bytes from the tile's first body row / first halo row)
+    uint32_t boff[NBODY], hoff[NHALO], hist_off[HR];
+#pragma unroll
+    for (int i = 0; i < NBODY; ++i) { const uint32_t P = 64u * i + lane, row = P / 17u, col = P - row * 17u; boff[i] = row * 256u + (col < 16u ? col : 15u) * 16u; }
+#pragma unroll
+    for (int i = 0; i < NHALO; ++i) {
+        uint32_t P = 64u * i + lane; if (P >= (uint32_t)(HR * 17)) P = HR * 17 - 1;      // (the last instruction runs past the halo: those lanes are masked off below)
+        const uint32_t row = P / 17u, col = P - row * 17u; hoff[i] = row * 256u + (col < 16u ? col : 15u) * 16u;
+    }
+#pragma unroll
+    for (int r = 0; r < HR; ++r) {                  // history row r: dword `lane` of the row is component lane & 1 of stream sample (r - HR) * 32 + lane / 2
+        const int h = (r - HR) * 32 + (int)(lane >> 1) + (T - 1);                          // index into the T-1 history samples (< 0: in front of them, never read)
+        hist_off[r] = (uint32_t)(h < 0 ? 0 : h) * 8u + (lane & 1u) * 4u;
+    }
+
+    // ---- runs of tiles: drawn from this XCD's counter by the feeding consumer (ring_consumer), handed over through ctl->run_q.  (The
+    // loader itself issues nothing but LDS-DMA: a returning atomic among them would have to be counted by hand too, and its destination
+    // register is the compiler's to move before the value has arrived.)
+    const uint32_t xcd0 = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // XCC_ID
+    const uint32_t xcd = xcd0 < a.claim.n_xcd ? xcd0 : a.claim.n_xcd - 1;
+    const uint32_t runs = a.claim.runs_per_xcd, run_len = a.claim.run_len;
+    bool have = false, ended = false;
+    uint32_t s = 0, tile = 0, left = 0, run_head = 0;
+    auto open_run = [&](uint32_t rr) {
+        const uint32_t g0 = (xcd * runs + rr) * run_len;
+        s = g0 / a.ntiles; tile = g0 - s * a.ntiles; left = run_len;
+    };
+
+    // slot state: lane j < kRingSlots watches slot j
+    uint32_t my_seq = 0xFFFFFFFFu;                  // sequence number of the tile in my slot (none)
+    uint32_t issued = 0, landed = 0;                // tiles
+    uint32_t inflight_instr = 0;                    // VMEM instructions of the tiles issued and not yet waited for
+    unsigned long long fifo = 0;                    // their instruction counts, oldest in the low byte
+    uint32_t idle_spins = 0;
+    RSTAMP_DECL;
+
+    for (;;) {
+        RSTAMP(0);
+        if (!have && !ended) {                                         // the current run is used up: take the next one the feeder has drawn
+            const uint32_t tail = __hip_atomic_load(&ctl->run_tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (tail != run_head) {
+                const uint32_t rr = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->run_q[run_head & 1u]);
+                ++run_head;
+                if (lane == 0) __hip_atomic_store(&ctl->run_head, run_head, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (rr < runs) { have = true; open_run(rr); } else ended = true;
+            }
+        }
+        const uint32_t n_in_flight = issued - landed;
+        const uint32_t cnt = (tile == 0 ? (uint32_t)HR : (uint32_t)NHALO) + (uint32_t)NBODY;
+        unsigned long long free_mask = 0;
+        if (have && n_in_flight < 3u && inflight_instr + cnt <= 63u) { // (the hardware counts 63 vector-memory instructions per wave at most)
+            // which slots are free?
+            uint32_t done_v = 0;
+            if (lane < (uint32_t)kRingSlots) done_v = __hip_atomic_load(&ctl->slot_done[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            free_mask = __ballot(lane < (uint32_t)kRingSlots && (my_seq == 0xFFFFFFFFu || done_v == my_seq + 1u));
+        }
+        if (free_mask) {
+            // ---- issue tile (s, tile) into the lowest free slot
+            const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(free_mask));
+            const uint32_t dst = ring_lds + slot * (uint32_t)SLOT;
+            const unsigned char* body = reinterpret_cast<const unsigned char*>(a.in + (size_t)s * a.in_stride) + (size_t)tile * (64u * 256u);
+            if (tile == 0) {
+                const unsigned char* hb = reinterpret_cast<const unsigned char*>(a.hist_in + (size_t)s * (T - 1));
+                glds4_rows<HR>(hb, hist_off, dst);
+            } else {
+                const unsigned char* hb = body - HR * 256;
+#pragma unroll
+                for (int i = 0; i < NHALO; ++i) {
+                    if (64 * (i + 1) <= HR * 17 || lane < (uint32_t)(HR * 17 - 64 * i)) glds16(hb, hoff[i], dst + 1024u * i);
+                }
+            }
+            glds16_x17(body, boff, dst + (uint32_t)(HR * kRingRowBytes));
+            if (lane == 0) ctl->desc[issued & 7u] = make_uint4(s, tile, slot, 0u);
+            if (lane == slot) my_seq = issued;
+            fifo |= (unsigned long long)cnt << (8u * n_in_flight);
+            inflight_instr += cnt;
+            ++issued;
+            ++tile; --left;
+            if (!left) have = false;
+            idle_spins = 0;
+            RSTAMP(1);
+            continue;
+        }
+        if (n_in_flight) {
+            // ---- wait for the oldest tile in flight, publish it
+            const uint32_t oldest = (uint32_t)(fifo & 0xFFu);
+            wait_vmcnt(inflight_instr - oldest);
+            inflight_instr -= oldest; fifo >>= 8;
+            ++landed;
+            if (lane == 0) __hip_atomic_store(&ctl->landed, landed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            RSTAMP(2);
+            continue;
+        }
+        if (!have && ended) break;                                     // nothing left to issue, nothing in flight
+        if (++idle_spins > kRingSpinLimit) {                           // (bounded, see the consumers' wait)
+            if (lane == 0) (void)__hip_atomic_fetch_add(a.gave_up, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(2);                                   // every slot is busy, or the next run has not been drawn yet
+        RSTAMP(3);
+    }
+    RSTAMP_WRITE(0, issued);
+    if (lane == 0) __hip_atomic_store(&ctl->end_seq, issued, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// -------------------------------------------------------------------------------------------------------------- a consumer wave
+template <int J0, int J1>
+__device__ __forceinline__ void ring_mac16(r_f32x2& acc, const r_f32x4 (&x)[8], const float (&k)[16])
+{
+#pragma unroll
+    for (int j = J0; j < J1; ++j) {
+        const r_f32x2 smp = (j & 1) ? x[j >> 1].zw : x[j >> 1].xy;
+        acc = acc + smp * k[j];
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void ring_consumer(const RingArgs& a, const unsigned char* __restrict__ ring, RingCtl* __restrict__ ctl)
+{
+    constexpr int HR = ring_halo_rows<T>();
+    constexpr int SLOT = ring_slot_bytes<T>();
+    constexpr int JS = HR * 32 - (T - 1);           // slot of tap 0, counted from column 0 of the lane's first row
+    constexpr int NS = JS + T;                      // taps sit on slots [JS, NS)
+    constexpr int C0 = JS / 16, C1 = (NS - 1) / 16; // first and last 16-slot chunk that carries taps
+    static_assert(C1 - C0 >= 3, "filter shorter than four chunks");
+    const uint32_t lane = threadIdx.x & 63u;
+    typedef const float __attribute__((address_space(4)))* ctaps_t;
+    const ctaps_t taps = (ctaps_t)(uintptr_t)a.taps - JS;                                   // taps[slot]
+    auto coff = [](int c) { return (c >> 1) * kRingRowBytes + (c & 1) * 128; };
+    RSTAMP_DECL;
+    uint32_t n_done = 0;
+    const uint32_t my_wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // The consumer in wave 1 also feeds the loader its runs: it draws them from this XCD's counter (StepClaim, launch.h) -- a returning atomic
+    // the compiler counts and waits for, which a wave without DMA in flight can afford -- and keeps up to two of them in ctl->run_q.
+    bool feeding = my_wave == 1u;
+    uint32_t fed = 0;
+    const uint32_t xcd0 = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // XCC_ID
+    const uint32_t xcd = xcd0 < a.claim.n_xcd ? xcd0 : a.claim.n_xcd - 1;
+    unsigned int* my_ctr = a.claim.ctr + (size_t)xcd * 32;
+    unsigned int* next_ctr = a.claim.ctr_next + (size_t)xcd * 32;
+    auto feed = [&]() {
+        while (feeding) {
+            const uint32_t head = __hip_atomic_load(&ctl->run_head, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (fed - head >= 2u) break;
+            unsigned int t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(my_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+            // the first ticket past the end -- exactly one per XCD and launch -- resets the XCD's counter of the other set for the next step launch
+            if (t == a.claim.runs_per_xcd && lane == 0) (void)__hip_atomic_exchange(next_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t v = t < a.claim.runs_per_xcd ? t : 0xFFFFFFFFu;
+            if (lane == 0) {
+                ctl->run_q[fed & 1u] = v;
+                __hip_atomic_store(&ctl->run_tail, fed + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            ++fed;
+            if (v == 0xFFFFFFFFu) feeding = false;
+        }
+    };
+
+    for (;;) {
+        RSTAMP(2);
+        feed();
+        uint32_t seq = 0;
+        if (lane == 0) seq = __hip_atomic_fetch_add(&ctl->taken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)seq);
+        for (uint32_t spin = 0;; ++spin) {
+            const uint32_t l = __hip_atomic_load(&ctl->landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((int32_t)(l - seq) > 0) break;
+            const uint32_t e = __hip_atomic_load(&ctl->end_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (seq >= e) { RSTAMP(0); RSTAMP_WRITE(my_wave, n_done); return; }
+            if (spin > kRingSpinLimit) {            // (never in a correct run: a bounded wait cannot hang the device, and the engine reports it)
+                if (lane == 0) (void)__hip_atomic_fetch_add(a.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
+            feed();
+            __builtin_amdgcn_s_sleep(1);
+        }
+        RSTAMP(0);
+        const uint4 d = ctl->desc[seq & 7u];
+        const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.x), tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y),
+                       slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z);
+        const unsigned char* p = ring + slot * (uint32_t)SLOT + lane * (uint32_t)kRingRowBytes;
+
+        // the T-term sum in tap order: 16-slot chunks (half rows), the next chunk's samples and taps requested before the current one is summed
+        r_f32x2 acc = {0.f, 0.f};
+        r_f32x4 xa[8], xb[8];
+        float ka[16], kb[16];
+        auto rd = [&](r_f32x4 (&x)[8], float (&k)[16], const int c, auto j0, auto j1) {
+            const unsigned char* pc = p + coff(c);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (2 * q + 1 >= decltype(j0)::value && 2 * q < decltype(j1)::value) x[q] = *reinterpret_cast<const r_f32x4*>(pc + 16 * q);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) k[j] = (j >= decltype(j0)::value && j < decltype(j1)::value) ? taps[c * 16 + j] : 0.f;
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I16 = std::integral_constant<int, 16>;
+        using IFirst = std::integral_constant<int, JS % 16>;
+        using ILast = std::integral_constant<int, NS - 16 * C1>;
+        constexpr int NMID = C1 - C0 - 1;           // full chunks C0+1 .. C1-1
+        rd(xa, ka, C0, IFirst{}, I16{});
+        rd(xb, kb, C0 + 1, I0{}, I16{});
+        ring_mac16<JS % 16, 16>(acc, xa, ka);
+        int c = C0 + 1;                             // chunk c is in xb
+#pragma unroll 1
+        for (; c + 2 < C1; c += 2) {
+            rd(xa, ka, c + 1, I0{}, I16{});
+            ring_mac16<0, 16>(acc, xb, kb);
+            rd(xb, kb, c + 2, I0{}, I16{});
+            ring_mac16<0, 16>(acc, xa, ka);
+        }
+        if constexpr (NMID % 2 == 1) {              // chunk C1-1 is in xb, C1 follows
+            rd(xa, ka, C1, I0{}, ILast{});
+            ring_mac16<0, 16>(acc, xb, kb);
+            ring_mac16<0, NS - 16 * C1>(acc, xa, ka);
+        } else {                                    // chunk C1-2 is in xb
+            rd(xa, ka, C1 - 1, I0{}, I16{});
+            ring_mac16<0, 16>(acc, xb, kb);
+            rd(xb, kb, C1, I0{}, ILast{});
+            ring_mac16<0, 16>(acc, xa, ka);
+            ring_mac16<0, NS - 16 * C1>(acc, xb, kb);
+        }
+        // every LDS read of the slot has returned (the sum used them): hand the slot back before the stores
+#ifdef HD_STAMP_RING
+        asm volatile("" : "+v"(acc));
+        ++n_done;
+#endif
+        RSTAMP(1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&ctl->slot_done[slot], seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        a.out[(size_t)s * a.out_stride + (size_t)tile * 64u + lane] = make_float2(acc.x, acc.y);
+        if (tile + 1 == a.ntiles) {                 // the stream's last tile: carry the last T-1 inputs (Decimator.h:140-143)
+            const float2* in_s = a.in + (size_t)s * a.in_stride;
+            float2* hout = a.hist_out + (size_t)s * (T - 1);
+            for (uint32_t j = lane; j < (uint32_t)(T - 1); j += 64u) hout[j] = in_s[a.n - (T - 1) + j];
+        }
+    }
+}
+
+}  // namespace hd

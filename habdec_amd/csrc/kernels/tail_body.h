@@ -50,7 +50,7 @@ __device__ __forceinline__ cfloat_ptr as_const(const float* p) { return (cfloat_
 __device__ unsigned long long g_tail_stamps[8192 * 24];
 #define TSTAMP_DECL unsigned long long ts_t = __builtin_amdgcn_s_memtime(), ts_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long ts_r0 = __builtin_amdgcn_s_memrealtime()
 #define TSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ts_acc[i] += t_ - ts_t; ts_t = t_; } while (0)
-#define TSTAMP_WRITE() do { if (threadIdx.x == 0 && s < 8192) { unsigned long long* g_ = g_tail_stamps + (size_t)s * 24; for (int i_ = 0; i_ < 20; ++i_) g_[i_] = ts_acc[i_]; g_[20] = ts_r0; g_[21] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define TSTAMP_WRITE() do { if (tid == 0 && s < 8192) { unsigned long long* g_ = g_tail_stamps + (size_t)s * 24; for (int i_ = 0; i_ < 20; ++i_) g_[i_] = ts_acc[i_]; g_[20] = ts_r0; g_[21] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define TSTAMP_DECL do { } while (0)
 #define TSTAMP(i) do { } while (0)
@@ -86,7 +86,16 @@ __device__ __forceinline__ void tb_s2_tap(f32x2 (&acc)[OP], const f32x4 (&win)[N
 template <int NT>
 __device__ __forceinline__ void tb_sync()
 {
-    __syncthreads();      // a 64-lane workgroup is one wave: the compiler drops the s_barrier and keeps the memory ordering
+    if constexpr (NT == 64) {
+        // One wave per stream: what __syncthreads() is for a 64-lane workgroup once the compiler has dropped the s_barrier -- the
+        // memory ordering alone.  Spelled out because the same body also runs as ONE WAVE OF A LARGER workgroup (k_step_cu,
+        // decimate.hip), whose other waves must not be waited for.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        __syncthreads();
+    }
 }
 
 // NT lanes, OP stage-2 outputs per lane and piece, stage-2 design (D2, T2).
@@ -101,7 +110,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     constexpr int NW = NT / 64;
     const uint32_t B = 2 * P + a.pend_max;          // most discriminator outputs one low-pass round (two pieces) can release
     static_assert(((T2 - 1) & 1) == 0 && XCH % (2 * NT) == 0, "16-byte pairs must stay aligned");
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = NT == 64 ? (threadIdx.x & 63u) : threadIdx.x, lane = tid & 63u, wave = tid >> 6;   // (64 lanes: possibly one wave of a larger workgroup)
 
     uint32_t* sh = reinterpret_cast<uint32_t*>(lds);                    // [0] nfl [1] overflow [2] frontier [3] carry sum [4] flagged
     float2* X = reinterpret_cast<float2*>(lds + kTailHdrBytes);

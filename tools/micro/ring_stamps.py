@@ -1,0 +1,26 @@
+"""Loader and consumer waves of k_step_cu (diagnostic build: HD_EXTRA_FLAGS=-DHD_STAMP_RING): cycles per role and phase in the last launch."""
+import sys, ctypes, os, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch, bench, habdec_amd
+w = dict(bench.WORKLOADS["cfg4"]); S = 1024; C = w["C"]
+dev = torch.device("cuda", 0)
+ring, rc, _ = bench.generate_ring(torch, dev, w, S, 0, 1234)
+eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"], pipeline=True)
+eng.set_timing(1)
+L = habdec_amd.lib(); f = L.hd_debug_ring_stamps; f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+for i in range(int(os.environ.get("NCALLS", "30"))):
+    eng.process_device(ring.data_ptr() + (i % rc) * S * C * 8, C, C)
+eng.flush()
+n = 512 * 4 * 8
+st = np.zeros(n, np.uint64); f(st.ctypes.data, n); st = st.reshape(512, 4, 8).astype(np.float64)[:256]
+t0 = st[:, :, 6][st[:, :, 6] > 0].min()
+print("step kernel ms:", eng.timing()["ms_front"], "variant", eng.timing()["step_variant"])
+ld = st[:, 0]
+print("loader: tiles/CU p0/50/100", np.percentile(ld[:, 5], [0, 50, 100]).tolist(), " lifetime us p50/100", np.percentile((ld[:, 7] - ld[:, 6]) / 100, [50, 100]).round(1).tolist())
+tot = ld[:, :4].sum(axis=1)
+print("loader cycles total p50 %.0f; per tile: poll %.0f issue %.0f wait-landing %.0f idle %.0f" % ((np.median(tot),) + tuple(np.median(ld[:, i] / ld[:, 5]) for i in range(4))))
+for wv in (1, 2, 3):
+    c = st[:, wv]
+    print("consumer %d: tiles p0/50/100 %s; per tile: wait %.0f compute %.0f store+take %.0f; lifetime us p50 %.1f end us p100 %.1f" % (
+        wv, np.percentile(c[:, 5], [0, 50, 100]).tolist(), np.median(c[:, 0] / c[:, 5]), np.median(c[:, 1] / c[:, 5]), np.median(c[:, 2] / c[:, 5]),
+        np.median((c[:, 7] - c[:, 6]) / 100), ((c[:, 7] - t0) / 100).max()))

@@ -1,0 +1,174 @@
+// Cycles per 64-output stage-1 tile (/32, 212 taps) for ONE wave's tap loop, by where the taps come from and how the loop is pipelined.
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/micro/taploop.hip -o tools/micro/taploop && tools/micro/taploop
+// Layout = the ring layout of the loader/consumer stage 1: rows of 32 samples at a pitch of 34 (16-byte pad), lane o's window starts in
+// row o at sample 13 (slot s of the lane <-> row s/32, column s%32; taps sit on slots [13, 225)).
+//   MODE 0: taps through the scalar cache (s_load), 16-slot chunks, next chunk's reads requested before the current one is summed
+//   MODE 1: taps from an LDS table with broadcast ds_read_b128 (in-order returns: counted waits), same chunking
+//   MODE 2: MODE 1 on two tiles at once (two independent sums per lane, 2 x 18 KB of LDS)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int T = 212, JS = 13, NS = JS + T, NCH = (NS + 15) / 16;   // 15 chunks: chunk 0 holds taps on slots 13..15, chunk 14 on slot 224 only
+constexpr int ROWP = 34;                                            // samples per row incl. pad
+constexpr int TILE_ROWS = 64 + 7;
+constexpr int TILE_BYTES = TILE_ROWS * ROWP * 8;
+
+template <int J0, int J1>
+__device__ __forceinline__ void mac16(f32x2& acc, const f32x4 (&x)[8], const float (&k)[16])
+{
+#pragma unroll
+    for (int j = J0; j < J1; ++j) {
+        const f32x2 s = (j & 1) ? x[j >> 1].zw : x[j >> 1].xy;
+        acc = acc + s * k[j];
+    }
+}
+template <int J0, int J1>
+__device__ __forceinline__ void mac16v(f32x2& acc, const f32x4 (&x)[8], const f32x4 (&k)[4])
+{
+#pragma unroll
+    for (int j = J0; j < J1; ++j) {
+        const f32x2 s = (j & 1) ? x[j >> 1].zw : x[j >> 1].xy;
+        const f32x4 kk = k[j >> 2];
+        const float kv = (j & 3) == 0 ? kk.x : (j & 3) == 1 ? kk.y : (j & 3) == 2 ? kk.z : kk.w;
+        acc = acc + s * kv;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k(unsigned long long* out, float2* res, const float* __restrict__ taps /* NCH*16, zero outside [13,225) */, int iters)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float2* tile = reinterpret_cast<float2*>(lds);
+    constexpr int NT = MODE == 2 ? 2 : 1;
+    float* tl = reinterpret_cast<float*>(lds + NT * TILE_BYTES);
+    const int lane = threadIdx.x;
+    for (int i = lane; i < NT * TILE_ROWS * ROWP; i += 64) tile[i] = make_float2(0.001f * (float)((i * 37 + blockIdx.x) % 1000) - 0.5f, 0.002f * (float)((i * 11) % 500) - 0.5f);
+    for (int i = lane; i < NCH * 16; i += 64) tl[i] = taps[i];
+    __syncthreads();
+    const unsigned char* p = lds + lane * (ROWP * 8);
+    auto coff = [](int c) { return (c >> 1) * (ROWP * 8) + (c & 1) * 128; };
+    f32x2 total = {0.f, 0.f};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (MODE == 0) {
+            f32x2 acc = {0.f, 0.f};
+            f32x4 xa[8], xb[8]; float ka[16], kb[16];
+            auto rd = [&](f32x4 (&x)[8], float (&kk)[16], int c) {
+                const unsigned char* pc = p + coff(c);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x[q] = *reinterpret_cast<const f32x4*>(pc + 16 * q);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) kk[j] = taps[c * 16 + j];
+            };
+            rd(xa, ka, 0); rd(xb, kb, 1);
+            mac16<13, 16>(acc, xa, ka);
+            int c = 1;
+#pragma unroll 1
+            for (; c + 1 < NCH - 1; c += 2) {
+                rd(xa, ka, c + 1);
+                mac16<0, 16>(acc, xb, kb);
+                rd(xb, kb, c + 2);
+                mac16<0, 16>(acc, xa, ka);
+            }
+            // c == 13: chunk 13 in xb?  (NCH-1 = 14: loop runs c = 1,3,..,11 -> ends with c = 13, chunk 13 in xb)
+            rd(xa, ka, 14);
+            mac16<0, 16>(acc, xb, kb);
+            mac16<0, 1>(acc, xa, ka);
+            total = total + acc;
+        } else if constexpr (MODE == 1) {
+            f32x2 acc = {0.f, 0.f};
+            f32x4 xa[8], xb[8]; f32x4 ka[4], kb[4];
+            auto rd = [&](f32x4 (&x)[8], f32x4 (&kk)[4], int c) {
+                const unsigned char* pc = p + coff(c);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x[q] = *reinterpret_cast<const f32x4*>(pc + 16 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kk[j] = *reinterpret_cast<const f32x4*>(tl + c * 16 + 4 * j);
+            };
+            rd(xa, ka, 0); rd(xb, kb, 1);
+            mac16v<13, 16>(acc, xa, ka);
+            int c = 1;
+#pragma unroll 1
+            for (; c + 1 < NCH - 1; c += 2) {
+                rd(xa, ka, c + 1);
+                mac16v<0, 16>(acc, xb, kb);
+                rd(xb, kb, c + 2);
+                mac16v<0, 16>(acc, xa, ka);
+            }
+            rd(xa, ka, 14);
+            mac16v<0, 16>(acc, xb, kb);
+            mac16v<0, 1>(acc, xa, ka);
+            total = total + acc;
+        } else {
+            f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+            f32x4 xa[8], xb[8], ya[8], yb[8]; f32x4 ka[4], kb[4];
+            auto rd = [&](f32x4 (&x)[8], f32x4 (&y)[8], f32x4 (&kk)[4], int c) {
+                const unsigned char* pc = p + coff(c);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { x[q] = *reinterpret_cast<const f32x4*>(pc + 16 * q); y[q] = *reinterpret_cast<const f32x4*>(pc + TILE_BYTES + 16 * q); }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kk[j] = *reinterpret_cast<const f32x4*>(tl + c * 16 + 4 * j);
+            };
+            rd(xa, ya, ka, 0); rd(xb, yb, kb, 1);
+            mac16v<13, 16>(acc0, xa, ka); mac16v<13, 16>(acc1, ya, ka);
+            int c = 1;
+#pragma unroll 1
+            for (; c + 1 < NCH - 1; c += 2) {
+                rd(xa, ya, ka, c + 1);
+                mac16v<0, 16>(acc0, xb, kb); mac16v<0, 16>(acc1, yb, kb);
+                rd(xb, yb, kb, c + 2);
+                mac16v<0, 16>(acc0, xa, ka); mac16v<0, 16>(acc1, ya, ka);
+            }
+            rd(xa, ya, ka, 14);
+            mac16v<0, 16>(acc0, xb, kb); mac16v<0, 16>(acc1, yb, kb);
+            mac16v<0, 1>(acc0, xa, ka); mac16v<0, 1>(acc1, ya, ka);
+            total = total + acc0 + acc1;
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    res[blockIdx.x * 64 + lane] = make_float2(total.x, total.y);
+    if (lane == 0) out[blockIdx.x] = t1 - t0;
+}
+
+template <int MODE>
+void run(const char* name, const float* d_taps)
+{
+    constexpr int NT = MODE == 2 ? 2 : 1;
+    const size_t lds = NT * TILE_BYTES + NCH * 16 * 4;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int per_cu : {1, 4, 8}) {
+        if (per_cu * lds > 160 * 1024) continue;
+        const int blocks = 256 * per_cu, iters = 200;
+        unsigned long long* d; float2* r;
+        hipMalloc(&d, blocks * 8); hipMalloc(&r, blocks * 64 * 8);
+        k<MODE><<<blocks, 64, lds>>>(d, r, d_taps, 2);
+        hipDeviceSynchronize();
+        k<MODE><<<blocks, 64, lds>>>(d, r, d_taps, iters);
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> h(blocks);
+        hipMemcpy(h.data(), d, blocks * 8, hipMemcpyDeviceToHost);
+        double sum = 0; unsigned long long mx = 0;
+        for (auto v : h) { sum += (double)v; mx = v > mx ? v : mx; }
+        std::vector<float2> hr(64);
+        hipMemcpy(hr.data(), r, 64 * 8, hipMemcpyDeviceToHost);
+        printf("%-28s %d waves/CU: %.0f cycles per tile (mean), %.0f (max)   [check %.6f]\n", name, per_cu, sum / blocks / iters / NT, (double)mx / iters / NT, hr[5].x);
+        hipFree(d); hipFree(r);
+    }
+}
+
+int main()
+{
+    std::vector<float> taps(NCH * 16, 0.f);
+    for (int t = 0; t < T; ++t) taps[JS + t] = 0.01f * (float)((t * 7) % 13) - 0.05f;
+    float* d_taps; hipMalloc(&d_taps, taps.size() * 4);
+    hipMemcpy(d_taps, taps.data(), taps.size() * 4, hipMemcpyHostToDevice);
+    run<0>("taps via s_load", d_taps);
+    run<1>("taps via LDS broadcast", d_taps);
+    run<2>("LDS taps, two tiles per wave", d_taps);
+    return 0;
+}
