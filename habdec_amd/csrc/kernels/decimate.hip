@@ -559,10 +559,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                             blockIdx.x - n_tail, 0u, gridDim.x - n_tail, tile4, uniform_n, claim);
 }
 
-// The step launch as ONE workgroup per CU (512 threads, all of the CU's LDS), roles by wave: wave 0 streams this call's stage-1 tiles
-// into an LDS ring with LDS-DMA, waves 1-3 compute them (stage1_ring.h), waves 4-7 run the previous call's stream tails -- four
-// streams per CU at 1024 streams, each in its own slice of LDS -- and afterwards leave the device copy of their streams' parameter
-// blocks for the next launch.  Compared with k_step (single-wave workgroups, dispatcher-scheduled) the loads of stage 1 never stop
+// The step launch as ONE workgroup per CU (512 threads, all of the CU's LDS), roles by wave: waves 0-1 stream this call's stage-1 tiles
+// into LDS slots with LDS-DMA, waves 2-3 compute them (stage1_ring.h), waves 4-7 run the previous call's stream tails -- four
+// streams per CU at 1024 streams, each in its own slice of LDS -- leave the device copy of their streams' parameter blocks for the
+// next launch, and then join the computing waves.  Compared with k_step (single-wave workgroups, dispatcher-scheduled) the loads of stage 1 never stop
 // while the tails hold half of the CU's wave slots, and what runs where does not depend on the dispatcher.
 template <int T, int D2, int T2>
 __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const StreamCall* __restrict__ call, StreamCall* __restrict__ call_copy,
@@ -572,24 +572,45 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
     unsigned char* ring = cu_lds;
     RingCtl* ctl = reinterpret_cast<RingCtl*>(cu_lds + kRingSlots * ring_slot_bytes<T>());
     unsigned char* tails = cu_lds + ring_bytes<T>();
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (threadIdx.x < sizeof(RingCtl) / 4) reinterpret_cast<uint32_t*>(ctl)[threadIdx.x] = threadIdx.x == 2 ? 0xFFFFFFFFu : 0u;   // end_seq = "not known yet"
+    if (threadIdx.x < kRingCtlBytes / 4) reinterpret_cast<uint32_t*>(ctl)[threadIdx.x] = (threadIdx.x == 2 || threadIdx.x == 3) ? 0xFFFFFFFFu : 0u;   // end[] = "not known yet"
     __syncthreads();
-    if (w == 0) {
+    // Roles by SIMD, not by wave number.  A 512-thread workgroup at 256 VGPRs puts exactly two waves on each of the CU's four SIMDs; which two
+    // is the hardware's choice.  The tap loops and the tails are both VALU work, the loaders are not: SIMDs 0 and 1 each get a loader and a
+    // computing wave (which then has its SIMD's vector pipe to itself), SIMDs 2 and 3 two tails each (latency chains that leave each other
+    // most of the issue slots).  The first wave to arrive on a SIMD (an LDS counter) takes the first role.
+#ifndef HD_CU_ROLES_BY_WAVE
+    const uint32_t simd = (__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4)) & 3u;                    // HW_ID.SIMD_ID
+    uint32_t rank = 0;
+    if ((threadIdx.x & 63u) == 0) rank = __hip_atomic_fetch_add(&ctl->simd_rank[simd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)rank) & 1u;
+    const uint32_t w = simd < 2u ? (rank ? 2u + simd : simd) : 4u + 2u * (simd - 2u) + rank;               // 0-1 loaders, 2-3 computing, 4-7 tails
+#else
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#endif
+    if (w < 2) {
 #ifdef HD_RING_LOADER_PRIO
         __builtin_amdgcn_s_setprio(HD_RING_LOADER_PRIO);
 #endif
-        ring_loader<T>(ra, ring, ctl);
+#ifndef HD_RING_REGS
+        ring_loader<T>(ra, ring, ctl, w);
+#else
+        ring_loader_regs<T>(ra, ring, ctl, w);       // (the same tiles staged through the loader's registers: measured equal, kept for A/B)
+#endif
     } else if (w < 4) {
-        ring_consumer<T>(ra, ring, ctl);
+        ring_consumer<T>(ra, ring, ctl, w == 2);
     } else {
         __builtin_amdgcn_s_setprio(HD_STEP_PRIO);
         const uint32_t k = w - 4u, lane = threadIdx.x & 63u;
         const uint32_t s = blockIdx.x * 4u + k;                          // (the grid has at least n_streams / 4 workgroups)
-        if (s >= n_streams) return;
+        if (s < n_streams) {
         if (s < n_tail) tail_body<64, 4, D2, T2>(ta, s, tails + k * tail_bytes);
         // this call's parameters live in mapped host memory; the tails of this call (next launch) read the device copy
         if (call_copy && lane < 4) reinterpret_cast<uint4*>(call_copy + s)[lane] = reinterpret_cast<const uint4*>(call + s)[lane];
+        }
+#ifndef HD_CU_NO_LATE_CONSUMERS
+        __builtin_amdgcn_s_setprio(0);
+        ring_consumer<T>(ra, ring, ctl, false);                          // the tail is done: one more wave for the tap loops
+#endif
     }
 }
 

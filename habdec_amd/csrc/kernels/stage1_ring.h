@@ -1,16 +1,17 @@
-// First decimation stage (/32) as a loader wave + consumer waves around an LDS ring of tiles -- the stage-1 half of the per-CU step
-// kernel (k_step_cu, decimate.hip).
+// First decimation stage (/32) as loader waves + consumer waves around LDS tile slots -- the stage-1 half of the per-CU step kernel
+// (k_step_cu, decimate.hip).
 //
 // What it computes is decimate.hip's sum (reference code/Decoder/Decimator.h:128-138): out[o] = sum_t buf[32 o + t] * tap[t], every output's T
 // products added by ONE lane in ascending tap order with separately rounded multiply and add.  What differs is who moves the bytes.
 // In the single-wave stage-1 workgroup (decimate_body) a wave is EITHER issuing the next tile's loads OR computing: its tile time is the
 // sum of an issue burst, the data's flight, an LDS store pass and the tap loop, the tile in flight sits in 72 VGPRs, and beside the
 // stream tails of a step launch -- which hold half of a CU's wave slots for the first half of the launch -- the four stage-1 waves left
-// on a CU pull a third of the CU's share of HBM.  Here ONE wave per CU does nothing but keep loads in flight: LDS-DMA
-// (global_load_lds_dwordx4: 64 lanes x 16 bytes straight into LDS, no VGPR destination, no ds_write) into a ring of four tile slots,
-// issued as soon as a slot is free, counted with s_waitcnt vmcnt(N) and published through an LDS word; three consumer waves take
-// published tiles in order and spend all their time in the tap loop.  Loads in flight no longer depend on what the computing waves are
-// doing, and the tile in flight costs no registers.
+// on a CU pull a third of the CU's share of HBM.  Here TWO waves per CU do nothing but keep loads in flight: LDS-DMA
+// (global_load_lds_dwordx4: 64 lanes x 16 bytes straight into LDS, no VGPR destination, no ds_write) into two tile slots each, a tile
+// issued as soon as its slot is free and published through an LDS word once the wave's vector-memory counter says it has landed
+// (tools/micro/loader_bw.hip: one such wave per CU streams 5.5 TB/s over the chip, two 6.2); the other waves take published tiles in
+// order and spend their time in the tap loop.  Loads in flight no longer depend on what the computing waves are doing, and a tile in
+// flight costs no registers.
 //
 // Slot layout = the padded rows the tap loop reads without bank conflicts: rows of 32 samples (256 B, one output's stride) at a pitch
 // of 272 B, so that lane o's window starts 17 sixteen-byte chunks after lane o-1's and the lanes' ds_read_b128 fall into different
@@ -21,10 +22,13 @@
 // first output's stride) are two more -- or, for a stream's first tile, HR dword-wide LDS-DMA rows out of the stage history, whose
 // samples sit at odd 8-byte offsets.
 //
-// Protocol (LDS words, RingCtl): the loader writes desc[seq & 7] = (stream, tile, slot) and, once `s_waitcnt vmcnt(younger instructions)`
-// says the tile has landed, bumps `landed`; a consumer draws seq = taken++ (ds_add_rtn), sleeps until landed > seq, computes, and
-// stores seq + 1 into slot_done[slot]; the loader (lane j watches slot j) sees the slot free again.  `end_seq` tells consumers how many
-// tiles there will be in all.  No s_barrier after the start: the stream tails in the workgroup's other four waves never take part.
+// Protocol (LDS words, RingCtl).  Loader L (0, 1) numbers its tiles l = 0, 1, ... and puts tile l into its slot l & 1: it waits until
+// slot_done says the consumer of tile l - 2 is finished, writes desc = (stream, tile), issues the DMA, and bumps landed[L] when
+// IB_STS.VM_CNT shows the tile has arrived.  Consumers draw g = taken++ (tile g >> 1 of loader g & 1), sleep until it is published,
+// compute, and store l + 1 into slot_done.  Runs of tiles come from the per-XCD counters of the step launches (StepClaim, launch.h):
+// the first consumer wave draws them -- a returning atomic, which a wave without DMA in flight can simply wait for -- and feeds both
+// loaders through run_q.  end[L] tells consumers how many tiles a loader had in all.  No s_barrier after the start: the stream tails in
+// the workgroup's other waves never take part; every wait is bounded and reported (RingArgs::gave_up).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -44,11 +48,11 @@ template <int T> constexpr int ring_slot_bytes() { return (64 + ring_halo_rows<T
 template <int T> constexpr int ring_bytes() { return kRingSlots * ring_slot_bytes<T>() + kRingCtlBytes; }
 
 #ifdef HD_STAMP_RING   // diagnostic build only (tools/micro/ring_stamps.py): where the loader and the consumers of k_step_cu spend their cycles
-__device__ unsigned long long g_ring_stamps[512 * 4 * 8];
+__device__ unsigned long long g_ring_stamps[512 * 8 * 8];
 extern "C" void hd_debug_ring_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ring_stamps), n * 8); }
 #define RSTAMP_DECL unsigned long long rs_t = __builtin_amdgcn_s_memtime(), rs_acc[6] = {0, 0, 0, 0, 0, 0}; const unsigned long long rs_r0 = __builtin_amdgcn_s_memrealtime()
 #define RSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); rs_acc[i] += t_ - rs_t; rs_t = t_; } while (0)
-#define RSTAMP_WRITE(wave_, n_) do { if ((threadIdx.x & 63u) == 0 && blockIdx.x < 512) { unsigned long long* g_ = g_ring_stamps + ((size_t)blockIdx.x * 4 + (wave_)) * 8; \
+#define RSTAMP_WRITE(wave_, n_) do { if ((threadIdx.x & 63u) == 0 && blockIdx.x < 512) { unsigned long long* g_ = g_ring_stamps + ((size_t)blockIdx.x * 8 + (wave_)) * 8; \
         for (int i_ = 0; i_ < 5; ++i_) g_[i_] = rs_acc[i_]; g_[5] = (n_); g_[6] = rs_r0; g_[7] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define RSTAMP_DECL do { } while (0)
@@ -57,15 +61,16 @@ extern "C" void hd_debug_ring_stamps(unsigned long long* host, size_t n) { (void
 #endif
 
 struct RingCtl {
-    uint32_t landed;        // tiles published so far
+    uint32_t landed[2];     // per loader: tiles published so far
+    uint32_t end[2];        // per loader: its total, 0xFFFFFFFF until it has issued its last tile
     uint32_t taken;         // next sequence number a consumer draws
-    uint32_t end_seq;       // 0xFFFFFFFF until the loader knows the total
     uint32_t run_tail;      // runs the feeding consumer has put into run_q so far
-    uint32_t run_head;      // runs the loader has taken out
-    uint32_t run_q[2];      // drawn run numbers (0xFFFFFFFF: no more)
+    uint32_t run_head;      // runs the loaders have claimed (fetch-add)
     uint32_t _pad;
-    uint32_t slot_done[8];  // per slot: 1 + sequence number of the tile last finished in it
-    uint4 desc[8];          // per sequence number & 7: stream, tile, slot
+    uint32_t run_q[4];      // drawn run numbers (0xFFFFFFFF: no more)
+    uint32_t slot_done[4];  // per slot 2 L + (l & 1): 1 + l of the tile last finished in it
+    uint4 desc[4];          // per slot: stream, tile
+    uint32_t simd_rank[4];  // waves of the workgroup that have arrived on each SIMD (role assignment, k_step_cu)
 };
 static_assert(sizeof(RingCtl) <= kRingCtlBytes, "ring control block");
 
@@ -147,16 +152,16 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p)
                                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b));
 }
 
-// ---------------------------------------------------------------------------------------------------------------- the loader wave
+// ---------------------------------------------------------------------------------------------------------------- a loader wave
 template <int T>
-__device__ __forceinline__ void ring_loader(const RingArgs& a, unsigned char* __restrict__ ring, RingCtl* __restrict__ ctl)
+__device__ __forceinline__ void ring_loader(const RingArgs& a, unsigned char* __restrict__ ring, RingCtl* __restrict__ ctl, const uint32_t L)
 {
     constexpr int HR = ring_halo_rows<T>();
     constexpr int SLOT = ring_slot_bytes<T>();
     constexpr int NBODY = 17;                       // 64 rows x 17 chunks = 17 x 64 chunks
     constexpr int NHALO = (HR * 17 + 63) / 64;      // halo rows out of the stream itself (every tile but a stream's first)
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t ring_lds = lds_addr_of(ring);
+    const uint32_t ring_lds = lds_addr_of(ring) + 2u * L * (uint32_t)SLOT;
 
     // per-lane source offsets (bytes from the tile's first body row / first halo row)
     uint32_t boff[NBODY], hoff[NHALO], hist_off[HR];
@@ -173,67 +178,78 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, unsigned char* __
         hist_off[r] = (uint32_t)(h < 0 ? 0 : h) * 8u + (lane & 1u) * 4u;
     }
 
-    // ---- runs of tiles: drawn from this XCD's counter by the feeding consumer (ring_consumer), handed over through ctl->run_q.  (The
-    // loader itself issues nothing but LDS-DMA: a returning atomic among them would have to be counted by hand too, and its destination
-    // register is the compiler's to move before the value has arrived.)
+    // ---- runs of tiles: drawn from this XCD's counter by the feeding consumer (ring_consumer), handed over through ctl->run_q.  (A loader
+    // issues nothing but LDS-DMA: a returning atomic among them would have to be counted by hand too, and its destination register is
+    // the compiler's to move before the value has arrived.)
     const uint32_t xcd0 = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // XCC_ID
     const uint32_t xcd = xcd0 < a.claim.n_xcd ? xcd0 : a.claim.n_xcd - 1;
     const uint32_t runs = a.claim.runs_per_xcd, run_len = a.claim.run_len;
-    bool have = false, ended = false;
-    uint32_t s = 0, tile = 0, left = 0, run_head = 0;
-    auto open_run = [&](uint32_t rr) {
-        const uint32_t g0 = (xcd * runs + rr) * run_len;
-        s = g0 / a.ntiles; tile = g0 - s * a.ntiles; left = run_len;
-    };
-
-    // slot state: lane j < kRingSlots watches slot j
-    uint32_t my_seq = 0xFFFFFFFFu;                  // sequence number of the tile in my slot (none)
-    uint32_t issued = 0, landed = 0;                // tiles
-    uint32_t inflight_instr = 0;                    // VMEM instructions of the tiles issued and not yet waited for
-    unsigned long long fifo = 0;                    // their instruction counts, oldest in the low byte
+    bool have = false, ended = false, claimed = false;
+    uint32_t s = 0, tile = 0, left = 0, my_run = 0;
+    uint32_t issued = 0, landed = 0;                // my tiles
+    uint32_t cnt_new = 0;                           // vector-memory instructions of the newer of two tiles in flight (0: at most one in flight)
     uint32_t idle_spins = 0;
     RSTAMP_DECL;
 
     for (;;) {
         RSTAMP(0);
+        // ---- publish what has landed, without blocking: the wave's count of outstanding vector-memory instructions is readable
+        // (IB_STS.VM_CNT, low four bits in [3:0], high two in [23:22]); the older tile in flight has landed once no more than the
+        // instructions issued after it are outstanding.
+        while (issued != landed) {
+            const uint32_t ib = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 7);
+            if (((ib & 15u) | (((ib >> 22) & 3u) << 4)) > cnt_new) break;
+            wait_vmcnt(cnt_new);                                       // (returns at once; an ordering point for the compiler)
+            cnt_new = 0;                                               // (what was the newer tile is now the only one in flight)
+            ++landed;
+            if (lane == 0) __hip_atomic_store(&ctl->landed[L], landed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        RSTAMP(2);
         if (!have && !ended) {                                         // the current run is used up: take the next one the feeder has drawn
+            if (!claimed) {
+                uint32_t idx = 0;
+                if (lane == 0) idx = __hip_atomic_fetch_add(&ctl->run_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                my_run = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+                claimed = true;
+            }
             const uint32_t tail = __hip_atomic_load(&ctl->run_tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (tail != run_head) {
-                const uint32_t rr = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->run_q[run_head & 1u]);
-                ++run_head;
-                if (lane == 0) __hip_atomic_store(&ctl->run_head, run_head, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (rr < runs) { have = true; open_run(rr); } else ended = true;
+            if ((int32_t)(tail - my_run) > 0) {
+                const uint32_t rr = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->run_q[my_run & 3u]);
+                claimed = false;
+                if (rr < runs) {
+                    const uint32_t g0 = (xcd * runs + rr) * run_len;
+                    s = g0 / a.ntiles; tile = g0 - s * a.ntiles; left = run_len; have = true;
+                } else {
+                    ended = true;
+                    if (lane == 0) __hip_atomic_store(&ctl->end[L], issued, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
-        const uint32_t n_in_flight = issued - landed;
-        const uint32_t cnt = (tile == 0 ? (uint32_t)HR : (uint32_t)NHALO) + (uint32_t)NBODY;
-        unsigned long long free_mask = 0;
-        if (have && n_in_flight < 3u && inflight_instr + cnt <= 63u) { // (the hardware counts 63 vector-memory instructions per wave at most)
-            // which slots are free?
-            uint32_t done_v = 0;
-            if (lane < (uint32_t)kRingSlots) done_v = __hip_atomic_load(&ctl->slot_done[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            free_mask = __ballot(lane < (uint32_t)kRingSlots && (my_seq == 0xFFFFFFFFu || done_v == my_seq + 1u));
+        bool can = have && issued - landed < 2u;
+        if (can && issued >= 2u) {                                     // my slot issued & 1 held tile issued - 2: is its consumer finished?
+            const uint32_t dn = __hip_atomic_load(&ctl->slot_done[2u * L + (issued & 1u)], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            can = dn == issued - 1u;
         }
-        if (free_mask) {
-            // ---- issue tile (s, tile) into the lowest free slot
-            const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(free_mask));
+        if (can) {
+            const uint32_t slot = issued & 1u;
             const uint32_t dst = ring_lds + slot * (uint32_t)SLOT;
             const unsigned char* body = reinterpret_cast<const unsigned char*>(a.in + (size_t)s * a.in_stride) + (size_t)tile * (64u * 256u);
+            if (lane == 0) ctl->desc[2u * L + slot] = make_uint4(s, tile, 0u, 0u);
+            uint32_t cnt = NBODY;
             if (tile == 0) {
                 const unsigned char* hb = reinterpret_cast<const unsigned char*>(a.hist_in + (size_t)s * (T - 1));
                 glds4_rows<HR>(hb, hist_off, dst);
+                cnt += HR;
             } else {
                 const unsigned char* hb = body - HR * 256;
 #pragma unroll
                 for (int i = 0; i < NHALO; ++i) {
                     if (64 * (i + 1) <= HR * 17 || lane < (uint32_t)(HR * 17 - 64 * i)) glds16(hb, hoff[i], dst + 1024u * i);
                 }
+                cnt += NHALO;
             }
             glds16_x17(body, boff, dst + (uint32_t)(HR * kRingRowBytes));
-            if (lane == 0) ctl->desc[issued & 7u] = make_uint4(s, tile, slot, 0u);
-            if (lane == slot) my_seq = issued;
-            fifo |= (unsigned long long)cnt << (8u * n_in_flight);
-            inflight_instr += cnt;
+            cnt_new = issued == landed ? 0u : cnt;                     // instructions younger than the older tile in flight
             ++issued;
             ++tile; --left;
             if (!left) have = false;
@@ -241,26 +257,119 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, unsigned char* __
             RSTAMP(1);
             continue;
         }
-        if (n_in_flight) {
-            // ---- wait for the oldest tile in flight, publish it
-            const uint32_t oldest = (uint32_t)(fifo & 0xFFu);
-            wait_vmcnt(inflight_instr - oldest);
-            inflight_instr -= oldest; fifo >>= 8;
-            ++landed;
-            if (lane == 0) __hip_atomic_store(&ctl->landed, landed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            RSTAMP(2);
-            continue;
-        }
-        if (!have && ended) break;                                     // nothing left to issue, nothing in flight
-        if (++idle_spins > kRingSpinLimit) {                           // (bounded, see the consumers' wait)
+        if (!have && ended && issued == landed) break;                 // nothing left to issue, nothing in flight
+        if (issued == landed && ++idle_spins > kRingSpinLimit) {       // (bounded, see the consumers' wait)
             if (lane == 0) (void)__hip_atomic_fetch_add(a.gave_up, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (lane == 0) __hip_atomic_store(&ctl->end[L], issued, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             break;
         }
-        __builtin_amdgcn_s_sleep(2);                                   // every slot is busy, or the next run has not been drawn yet
+        __builtin_amdgcn_s_sleep(1);                                   // my slot is busy, the next run has not been drawn yet, or loads are on their way
         RSTAMP(3);
     }
-    RSTAMP_WRITE(0, issued);
-    if (lane == 0) __hip_atomic_store(&ctl->end_seq, issued, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    RSTAMP_WRITE(L, issued);
+}
+
+// ------------------------------------------------------------------------------------------- a loader wave that stages through registers
+// The LDS-DMA loader above can only have in flight what has a slot to land in, and a CU that also hosts four stream tails has four slots:
+// two computing, two in flight -- half of what it takes to keep HBM busy (tools/micro/loader_bw.hip).  This variant keeps its tiles in flight
+// in REGISTERS instead -- a loader wave has 256 of them and no other use for them: three tiles of 18 sixteen-byte loads per lane -- and copies a
+// tile into its LDS slot (ds_write_b128, the padded layout) only when the tile has arrived AND the slot is free.  The slots then hold only
+// tiles that are being summed or are ready to be; what is in flight costs no LDS at all.  Plain loads: the compiler counts them.
+template <int T>
+__device__ __forceinline__ void ring_loader_regs(const RingArgs& a, unsigned char* __restrict__ ring, RingCtl* __restrict__ ctl, const uint32_t L)
+{
+    constexpr int HR = ring_halo_rows<T>();
+    constexpr int SLOT = ring_slot_bytes<T>();
+    constexpr int NCH = (64 + HR) * 16;             // sixteen-byte chunks of a tile, halo rows first
+    constexpr int NV = (NCH + 63) / 64;             // loads per lane
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned char* my_slots = ring + 2u * L * (uint32_t)SLOT;
+    const uint32_t xcd0 = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // XCC_ID
+    const uint32_t xcd = xcd0 < a.claim.n_xcd ? xcd0 : a.claim.n_xcd - 1;
+    const uint32_t runs = a.claim.runs_per_xcd, run_len = a.claim.run_len;
+
+    struct Desc { uint32_t s, tile; bool valid; };
+    bool ended = false;
+    uint32_t s = 0, tile = 0, left = 0;
+    uint32_t landed = 0;
+    auto next_tile = [&]() -> Desc {                // the next tile of my sequence; blocks (bounded) until the feeder has drawn the next run
+        if (!left && !ended) {
+            uint32_t idx = 0;
+            if (lane == 0) idx = __hip_atomic_fetch_add(&ctl->run_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+            for (uint32_t spin = 0;; ++spin) {
+                const uint32_t tail = __hip_atomic_load(&ctl->run_tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((int32_t)(tail - idx) > 0) break;
+                if (spin > kRingSpinLimit) { if (lane == 0) (void)__hip_atomic_fetch_add(a.gave_up, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ended = true; return Desc{0, 0, false}; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const uint32_t rr = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->run_q[idx & 3u]);
+            if (rr < runs) {
+                const uint32_t g0 = (xcd * runs + rr) * run_len;
+                s = g0 / a.ntiles; tile = g0 - s * a.ntiles; left = run_len;
+            } else ended = true;
+        }
+        if (!left) return Desc{0, 0, false};
+        const Desc d{s, tile, true};
+        ++tile; --left;
+        return d;
+    };
+    auto load = [&](float4 (&r)[NV], const Desc& d) {
+        const float2* in_s = a.in + (size_t)d.s * a.in_stride;
+        if (d.tile) {                               // every tile but a stream's first: one scalar base, plain loads at immediate offsets
+            const unsigned char* base = reinterpret_cast<const unsigned char*>(in_s) + (size_t)d.tile * (64u * 256u) - HR * 256;
+            base = reinterpret_cast<const unsigned char*>(uniform_ptr(base));
+#pragma unroll
+            for (int it = 0; it < NV; ++it)
+                if ((it + 1) * 64 <= NCH || lane < (uint32_t)(NCH - it * 64)) r[it] = *reinterpret_cast<const float4*>(base + (lane + 64u * it) * 16u);
+        } else {                                    // the halo rows come out of the stage history (T-1 samples at odd 8-byte offsets)
+            const float2* hist_s = a.hist_in + (size_t)d.s * (T - 1);
+#pragma unroll
+            for (int it = 0; it < NV; ++it) {
+                const uint32_t P = lane + 64u * it;
+                if ((it + 1) * 64 <= NCH || P < (uint32_t)NCH) {
+                    const int x = ((int)(P >> 4) - HR) * 32 + (int)(P & 15u) * 2;       // stream sample of the chunk's first half
+                    if (x >= 0) r[it] = *reinterpret_cast<const float4*>(in_s + x);
+                    else {
+                        const int h = x + (T - 1);  // (x is even and T-1 odd: h + 1 <= T-1 - 1)
+                        const float2 lo = h >= 0 ? hist_s[h] : make_float2(0.f, 0.f), hi = h + 1 >= 0 ? hist_s[h + 1] : make_float2(0.f, 0.f);
+                        r[it] = make_float4(lo.x, lo.y, hi.x, hi.y);
+                    }
+                }
+            }
+        }
+    };
+    auto stash = [&](const float4 (&r)[NV], const Desc& d) {           // my next slot: wait until it is free, copy, publish
+        const uint32_t slot = landed & 1u;
+        if (landed >= 2u)
+            for (uint32_t spin = 0;; ++spin) {
+                const uint32_t dn = __hip_atomic_load(&ctl->slot_done[2u * L + slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (dn == landed - 1u) break;
+                if (spin > kRingSpinLimit) { if (lane == 0) (void)__hip_atomic_fetch_add(a.gave_up, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        unsigned char* dst = my_slots + slot * (uint32_t)SLOT;
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const uint32_t P = lane + 64u * it;
+            if ((it + 1) * 64 <= NCH || P < (uint32_t)NCH) *reinterpret_cast<float4*>(dst + (P >> 4) * (uint32_t)kRingRowBytes + (P & 15u) * 16u) = r[it];
+        }
+        if (lane == 0) ctl->desc[2u * L + slot] = make_uint4(d.s, d.tile, 0u, 0u);
+        ++landed;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&ctl->landed[L], landed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    float4 r0[NV], r1[NV], r2[NV];
+    Desc d0 = next_tile(); if (d0.valid) load(r0, d0);
+    Desc d1 = next_tile(); if (d1.valid) load(r1, d1);
+    Desc d2 = next_tile(); if (d2.valid) load(r2, d2);
+    while (d0.valid || d1.valid || d2.valid) {
+        if (d0.valid) { stash(r0, d0); d0 = next_tile(); if (d0.valid) load(r0, d0); }
+        if (d1.valid) { stash(r1, d1); d1 = next_tile(); if (d1.valid) load(r1, d1); }
+        if (d2.valid) { stash(r2, d2); d2 = next_tile(); if (d2.valid) load(r2, d2); }
+    }
+    if (lane == 0) __hip_atomic_store(&ctl->end[L], landed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // -------------------------------------------------------------------------------------------------------------- a consumer wave
@@ -274,8 +383,46 @@ __device__ __forceinline__ void ring_mac16(r_f32x2& acc, const r_f32x4 (&x)[8], 
     }
 }
 
+// Sixteen taps of ONE sum, scheduled by hand: the sum is a serial chain of adds by definition (ascending tap order, one accumulator), the
+// products are not -- but written as "acc = acc + x * k" the compiler multiplies into a temporary right in front of each add, and a lone wave
+// then waits out the multiplier's latency sixteen times per chunk (tools/micro/valu_rate.hip: 6.4 cycles per instruction against 5.2 for
+// independent ones).  Here the products run three taps ahead of the adds through four rotating temporaries, so an independent multiply sits
+// between consecutive adds.  Same instructions, same order of the adds, separately rounded multiply and add: bit-identical results.
+// Taps arrive as eight aligned scalar pairs; op_sel picks the pair's low or high word for both halves of the packed multiply.
+__device__ __forceinline__ void ring_mac16_asm(r_f32x2& acc, const r_f32x4 (&x)[8], const r_f32x2 (&kp)[8])
+{
+    r_f32x2 t0, t1, t2, t3;
+#define HD_MUL_E(t, xi, ki) "v_pk_mul_f32 %" #t ", %" #xi ", %" #ki " op_sel_hi:[1,0]\n\t"
+#define HD_MUL_O(t, xi, ki) "v_pk_mul_f32 %" #t ", %" #xi ", %" #ki " op_sel:[0,1]\n\t"
+#define HD_ADD(t) "v_pk_add_f32 %0, %0, %" #t "\n\t"
+    // operands: 0 acc; 1-4 temporaries; 5-20 the sixteen sample pairs (x[0].xy, x[0].zw, x[1].xy, ...); 21-28 the eight tap pairs
+    asm volatile(
+        HD_MUL_E(1, 5, 21) HD_MUL_O(2, 6, 21) HD_MUL_E(3, 7, 22)
+        HD_ADD(1) HD_MUL_O(4, 8, 22)
+        HD_ADD(2) HD_MUL_E(1, 9, 23)
+        HD_ADD(3) HD_MUL_O(2, 10, 23)
+        HD_ADD(4) HD_MUL_E(3, 11, 24)
+        HD_ADD(1) HD_MUL_O(4, 12, 24)
+        HD_ADD(2) HD_MUL_E(1, 13, 25)
+        HD_ADD(3) HD_MUL_O(2, 14, 25)
+        HD_ADD(4) HD_MUL_E(3, 15, 26)
+        HD_ADD(1) HD_MUL_O(4, 16, 26)
+        HD_ADD(2) HD_MUL_E(1, 17, 27)
+        HD_ADD(3) HD_MUL_O(2, 18, 27)
+        HD_ADD(4) HD_MUL_E(3, 19, 28)
+        HD_ADD(1) HD_MUL_O(4, 20, 28)
+        HD_ADD(2) HD_ADD(3) "v_pk_add_f32 %0, %0, %4"
+        : "+v"(acc), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(x[0].xy), "v"(x[0].zw), "v"(x[1].xy), "v"(x[1].zw), "v"(x[2].xy), "v"(x[2].zw), "v"(x[3].xy), "v"(x[3].zw),
+          "v"(x[4].xy), "v"(x[4].zw), "v"(x[5].xy), "v"(x[5].zw), "v"(x[6].xy), "v"(x[6].zw), "v"(x[7].xy), "v"(x[7].zw),
+          "s"(kp[0]), "s"(kp[1]), "s"(kp[2]), "s"(kp[3]), "s"(kp[4]), "s"(kp[5]), "s"(kp[6]), "s"(kp[7]));
+#undef HD_MUL_E
+#undef HD_MUL_O
+#undef HD_ADD
+}
+
 template <int T>
-__device__ __forceinline__ void ring_consumer(const RingArgs& a, const unsigned char* __restrict__ ring, RingCtl* __restrict__ ctl)
+__device__ __forceinline__ void ring_consumer(const RingArgs& a, const unsigned char* __restrict__ ring, RingCtl* __restrict__ ctl, const bool feeder)
 {
     constexpr int HR = ring_halo_rows<T>();
     constexpr int SLOT = ring_slot_bytes<T>();
@@ -290,10 +437,10 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const unsigned 
     RSTAMP_DECL;
     uint32_t n_done = 0;
     const uint32_t my_wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // The consumer in wave 1 also feeds the loader its runs: it draws them from this XCD's counter (StepClaim, launch.h) -- a returning atomic
-    // the compiler counts and waits for, which a wave without DMA in flight can afford -- and keeps up to two of them in ctl->run_q.
-    bool feeding = my_wave == 1u;
-    uint32_t fed = 0;
+    // The feeding consumer also draws the runs for both loaders from this XCD's counter (StepClaim, launch.h) -- a returning atomic the
+    // compiler counts and waits for, which a wave without DMA in flight can afford -- and keeps two of them ready in ctl->run_q.
+    bool feeding = feeder;
+    uint32_t fed = 0, sentinels = 0;
     const uint32_t xcd0 = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // XCC_ID
     const uint32_t xcd = xcd0 < a.claim.n_xcd ? xcd0 : a.claim.n_xcd - 1;
     unsigned int* my_ctr = a.claim.ctr + (size_t)xcd * 32;
@@ -301,33 +448,42 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const unsigned 
     auto feed = [&]() {
         while (feeding) {
             const uint32_t head = __hip_atomic_load(&ctl->run_head, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (fed - head >= 2u) break;
-            unsigned int t = 0;
-            if (lane == 0) t = __hip_atomic_fetch_add(my_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
-            // the first ticket past the end -- exactly one per XCD and launch -- resets the XCD's counter of the other set for the next step launch
-            if (t == a.claim.runs_per_xcd && lane == 0) (void)__hip_atomic_exchange(next_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t v = t < a.claim.runs_per_xcd ? t : 0xFFFFFFFFu;
+            if ((int32_t)(fed - head) >= 2) break;  // two unclaimed runs are ready (entries are reused four later: a claimed one has been read long before)
+            uint32_t v = 0xFFFFFFFFu;
+            if (!sentinels) {
+                unsigned int t = 0;
+                if (lane == 0) t = __hip_atomic_fetch_add(my_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+                // the first ticket past the end -- exactly one per XCD and launch -- resets the XCD's counter of the other set for the next step launch
+                if (t == a.claim.runs_per_xcd && lane == 0) (void)__hip_atomic_exchange(next_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t < a.claim.runs_per_xcd) v = t;
+            }
             if (lane == 0) {
-                ctl->run_q[fed & 1u] = v;
+                ctl->run_q[fed & 3u] = v;
                 __hip_atomic_store(&ctl->run_tail, fed + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             ++fed;
-            if (v == 0xFFFFFFFFu) feeding = false;
+            if (v == 0xFFFFFFFFu && ++sentinels == 2u) feeding = false;                    // one "no more" for each loader
         }
     };
 
     for (;;) {
         RSTAMP(2);
         feed();
-        uint32_t seq = 0;
-        if (lane == 0) seq = __hip_atomic_fetch_add(&ctl->taken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)seq);
+        uint32_t g = 0;
+        if (lane == 0) g = __hip_atomic_fetch_add(&ctl->taken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+        const uint32_t L = g & 1u, seq = g >> 1;
+        bool skip = false;
         for (uint32_t spin = 0;; ++spin) {
-            const uint32_t l = __hip_atomic_load(&ctl->landed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t l = __hip_atomic_load(&ctl->landed[L], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if ((int32_t)(l - seq) > 0) break;
-            const uint32_t e = __hip_atomic_load(&ctl->end_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (seq >= e) { RSTAMP(0); RSTAMP_WRITE(my_wave, n_done); return; }
+            const uint32_t e = __hip_atomic_load(&ctl->end[L], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (seq >= e) {                         // this loader never issues tile seq; the other one may still have some
+                const uint32_t e2 = __hip_atomic_load(&ctl->end[L ^ 1u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (seq >= e2 && !feeding) { RSTAMP(0); RSTAMP_WRITE(my_wave, n_done); return; }
+                if (seq < e2) { skip = true; break; }
+            }
             if (spin > kRingSpinLimit) {            // (never in a correct run: a bounded wait cannot hang the device, and the engine reports it)
                 if (lane == 0) (void)__hip_atomic_fetch_add(a.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 return;
@@ -335,22 +491,33 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const unsigned 
             feed();
             __builtin_amdgcn_s_sleep(1);
         }
+        if (skip) continue;
         RSTAMP(0);
-        const uint4 d = ctl->desc[seq & 7u];
-        const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.x), tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y),
-                       slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z);
+        const uint32_t slot = 2u * L + (seq & 1u);
+        const uint4 d = ctl->desc[slot];
+        const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.x), tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y);
         const unsigned char* p = ring + slot * (uint32_t)SLOT + lane * (uint32_t)kRingRowBytes;
 
         // the T-term sum in tap order: 16-slot chunks (half rows), the next chunk's samples and taps requested before the current one is summed
         r_f32x2 acc = {0.f, 0.f};
         r_f32x4 xa[8], xb[8];
-        float ka[16], kb[16];
-        auto rd = [&](r_f32x4 (&x)[8], float (&k)[16], const int c, auto j0, auto j1) {
+        r_f32x2 ka[8], kb[8];                       // the chunk's sixteen taps as eight pairs (wave-uniform: scalar registers)
+        auto rd = [&](r_f32x4 (&x)[8], r_f32x2 (&k)[8], const int c, auto j0, auto j1) {
             const unsigned char* pc = p + coff(c);
 #pragma unroll
             for (int q = 0; q < 8; ++q) if (2 * q + 1 >= decltype(j0)::value && 2 * q < decltype(j1)::value) x[q] = *reinterpret_cast<const r_f32x4*>(pc + 16 * q);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) k[j] = (j >= decltype(j0)::value && j < decltype(j1)::value) ? taps[c * 16 + j] : 0.f;
+            for (int j = 0; j < 16; j += 2) {
+                k[j >> 1].x = (j >= decltype(j0)::value && j < decltype(j1)::value) ? taps[c * 16 + j] : 0.f;
+                k[j >> 1].y = (j + 1 >= decltype(j0)::value && j + 1 < decltype(j1)::value) ? taps[c * 16 + j + 1] : 0.f;
+            }
+        };
+        auto mac_part = [&](const r_f32x4 (&x)[8], const r_f32x2 (&k)[8], auto j0, auto j1) {      // a chunk only part of whose slots carry taps
+#pragma unroll
+            for (int j = decltype(j0)::value; j < decltype(j1)::value; ++j) {
+                const r_f32x2 smp = (j & 1) ? x[j >> 1].zw : x[j >> 1].xy;
+                acc = acc + smp * ((j & 1) ? k[j >> 1].y : k[j >> 1].x);
+            }
         };
         using I0 = std::integral_constant<int, 0>;
         using I16 = std::integral_constant<int, 16>;
@@ -359,25 +526,25 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const unsigned 
         constexpr int NMID = C1 - C0 - 1;           // full chunks C0+1 .. C1-1
         rd(xa, ka, C0, IFirst{}, I16{});
         rd(xb, kb, C0 + 1, I0{}, I16{});
-        ring_mac16<JS % 16, 16>(acc, xa, ka);
+        mac_part(xa, ka, IFirst{}, I16{});
         int c = C0 + 1;                             // chunk c is in xb
 #pragma unroll 1
         for (; c + 2 < C1; c += 2) {
             rd(xa, ka, c + 1, I0{}, I16{});
-            ring_mac16<0, 16>(acc, xb, kb);
+            ring_mac16_asm(acc, xb, kb);
             rd(xb, kb, c + 2, I0{}, I16{});
-            ring_mac16<0, 16>(acc, xa, ka);
+            ring_mac16_asm(acc, xa, ka);
         }
         if constexpr (NMID % 2 == 1) {              // chunk C1-1 is in xb, C1 follows
             rd(xa, ka, C1, I0{}, ILast{});
-            ring_mac16<0, 16>(acc, xb, kb);
-            ring_mac16<0, NS - 16 * C1>(acc, xa, ka);
+            ring_mac16_asm(acc, xb, kb);
+            mac_part(xa, ka, I0{}, ILast{});
         } else {                                    // chunk C1-2 is in xb
             rd(xa, ka, C1 - 1, I0{}, I16{});
-            ring_mac16<0, 16>(acc, xb, kb);
+            ring_mac16_asm(acc, xb, kb);
             rd(xb, kb, C1, I0{}, ILast{});
-            ring_mac16<0, 16>(acc, xa, ka);
-            ring_mac16<0, NS - 16 * C1>(acc, xb, kb);
+            ring_mac16_asm(acc, xa, ka);
+            mac_part(xb, kb, I0{}, ILast{});
         }
         // every LDS read of the slot has returned (the sum used them): hand the slot back before the stores
 #ifdef HD_STAMP_RING

@@ -11,16 +11,19 @@ L = habdec_amd.lib(); f = L.hd_debug_ring_stamps; f.argtypes = [ctypes.c_void_p,
 for i in range(int(os.environ.get("NCALLS", "30"))):
     eng.process_device(ring.data_ptr() + (i % rc) * S * C * 8, C, C)
 eng.flush()
-n = 512 * 4 * 8
-st = np.zeros(n, np.uint64); f(st.ctypes.data, n); st = st.reshape(512, 4, 8).astype(np.float64)[:256]
+n = 512 * 8 * 8
+st = np.zeros(n, np.uint64); f(st.ctypes.data, n); st = st.reshape(512, 8, 8).astype(np.float64)[:256]
 t0 = st[:, :, 6][st[:, :, 6] > 0].min()
 print("step kernel ms:", eng.timing()["ms_front"], "variant", eng.timing()["step_variant"])
-ld = st[:, 0]
-print("loader: tiles/CU p0/50/100", np.percentile(ld[:, 5], [0, 50, 100]).tolist(), " lifetime us p50/100", np.percentile((ld[:, 7] - ld[:, 6]) / 100, [50, 100]).round(1).tolist())
-tot = ld[:, :4].sum(axis=1)
-print("loader cycles total p50 %.0f; per tile: poll %.0f issue %.0f wait-landing %.0f idle %.0f" % ((np.median(tot),) + tuple(np.median(ld[:, i] / ld[:, 5]) for i in range(4))))
-for wv in (1, 2, 3):
+for ldw in (0, 1):
+  ld = st[:, ldw]
+  print("loader %d: tiles/CU p0/50/100" % ldw, np.percentile(ld[:, 5], [0, 50, 100]).tolist(), " lifetime us p50/100", np.percentile((ld[:, 7] - ld[:, 6]) / 100, [50, 100]).round(1).tolist())
+  tot = ld[:, :4].sum(axis=1)
+  print("  cycles total p50 %.0f; per tile: take-run %.0f issue %.0f publish+poll %.0f idle %.0f" % ((np.median(tot),) + tuple(np.median(ld[:, i] / ld[:, 5]) for i in range(4))))
+for wv in (2, 3, 4, 5, 6, 7):
     c = st[:, wv]
+    if not (c[:, 5] > 0).any(): continue
+    c = c[c[:, 5] > 0]
     print("consumer %d: tiles p0/50/100 %s; per tile: wait %.0f compute %.0f store+take %.0f; lifetime us p50 %.1f end us p100 %.1f" % (
         wv, np.percentile(c[:, 5], [0, 50, 100]).tolist(), np.median(c[:, 0] / c[:, 5]), np.median(c[:, 1] / c[:, 5]), np.median(c[:, 2] / c[:, 5]),
         np.median((c[:, 7] - c[:, 6]) / 100), ((c[:, 7] - t0) / 100).max()))
