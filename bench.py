@@ -165,8 +165,23 @@ def cpu_baseline(w, host_iq, chunks, C, lookup_mode=1):
     return total / dt / 1e6, best, sample, logs, {str(k): round(v, 1) for k, v in table.items()}
 
 
+def physical_cores():
+    """Physical cores of the host (distinct (package, core) pairs in /proc/cpuinfo); None where that cannot be read."""
+    try:
+        seen, pkg = set(), None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                pkg = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                seen.add((pkg, ln.split(":")[1].strip()))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
 STAGE1 = {64: "k_decimate<32,212,64>", 16: "k_decimate<8,54,256>", 4: "k_decimate<4,139,256>", 256: "k_decimate<64,348,64>"}
 STEP = {64: "k_step<32,212,2,69>", 256: "k_step<64,348,4,139>"}
+STEP_CU = {64: "k_step_cu<212,2,69>", 128: "k_step_cu<174,4,139>"}     # one workgroup per CU: loader + computing waves for stage 1, the tails in the others
 PATHS = {0: "separate kernels", 1: "fused back end", 2: "stream tail kernel", 3: "step kernel (stage 1 + previous call's stream tails)"}
 
 
@@ -183,7 +198,7 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
                             device=local_rank, pipeline=0 if sync else int(os.environ.get("HD_BENCH_PIPELINE", "2")))
     ring, ring_chunks, texts = generate_ring(torch, dev, w, S, rank, seed=1234 + rank)
     K = K or ring_chunks
-    eng.set_timing(7)          # HIP-event brackets on every 7th call (each record is a barrier packet worth microseconds of queue time; 7, not 8: every 4th
+    eng.set_timing(3)          # HIP-event brackets on every 3rd call (each record is a barrier packet worth microseconds of queue time; 3, not 4: every 4th
                                # launch carries the streams' spectra, and the sample must see light and heavy launches in their true proportion)
     base = ring.data_ptr()
 
@@ -231,17 +246,23 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     # stage 1 of this call and the stream tails of the previous one -- B(D) = 8 + 12/D bytes per input sample;
     # a stage-1 kernel on its own reads the IQ slab and writes its decimated output.
     if path == 3:
-        kernel, alg_bytes = STEP.get(w["D"], "k_step"), int(S * C * bytes_per_sample(w["D"]))
+        kernel, alg_bytes = (STEP_CU if tm.get("step_variant") == 1 else STEP).get(w["D"], "k_step"), int(S * C * bytes_per_sample(w["D"]))
     else:
         kernel, alg_bytes = STAGE1.get(w["D"], "k_decimate"), int(front_bytes)
     achieved = alg_bytes / (avg_front_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, prof = None, {}
     tf = ROOT / "profiles" / "traffic.json"
     if tf.exists():
         try:
-            traffic = json.loads(tf.read_text()).get(name, {}).get("front_kernel_hbm_bytes_per_launch")
+            prof = json.loads(tf.read_text()).get(name, {})
+            traffic = prof.get("front_kernel_hbm_bytes_per_launch")
         except Exception:
-            traffic = None
+            traffic, prof = None, {}
+    if prof.get("rocprof_avg_launch_ms") and prof.get("front_kernel") == kernel.replace(" ", ""):
+        # the committed rocprofv3 --kernel-trace --stats summary of the same command (tools/collect_profiles.py): the live figure must agree with it
+        rp = {"rocprof_avg_launch_ms": prof["rocprof_avg_launch_ms"], "rocprof_launches": prof.get("rocprof_launches"), "rocprof_source": prof.get("stats_source")}
+    else:
+        rp = {}
     valu = w["D"] == 4                                      # configs[2]: the FIR chain's multiply-adds bind, not HBM
     tflops = value / world * 1e6 * flops_per_sample(w) / 1e12
     res = {
@@ -250,6 +271,8 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_front_ms, 5),
+                     "n_samples": len(front_ms), "min_launch_ms": round(float(np.min(front_ms)), 5), "max_launch_ms": round(float(np.max(front_ms)), 5),
+                     "sampling": "HIP events on the engine's queue around every 3rd launch of the timed region",
                      "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 4)},
         "pipeline": {"bytes_per_sample": round(bytes_per_sample(w["D"]), 3),
                      "hbm_frac_end_to_end": round(value / world * 1e6 * bytes_per_sample(w["D"]) / 1e9 / HBM_PEAK_GBS, 4),
@@ -263,6 +286,7 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
                                           "text_stage": round(float(np.mean([h[2] for h in host_us])), 1)},
                      "mode": "sync" if sync else "batch (calls pipelined; up to three undelivered)"},
     }
+    res["roofline"].update(rp)
     if valu:
         res["roofline"] = {"bound": "valu", "kernel": "FIR chain: " + kernel + " + k_fir_demod (exact mode: separately rounded multiply and add)",
                            "achieved": round(tflops, 2), "peak": VALU_NONFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / VALU_NONFMA_TFLOPS, 4),
@@ -303,7 +327,8 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
         gpu_bits = [eng.bits_total(s) for s in range(nthreads)]
         n_chars, n_bits = int(sum(len(x.chars) for x in logs)), int(sum(x.bits for x in logs))
         same = gpu_sent == [list(x) for x in logs] and gpu_chars == [x.chars for x in logs] and gpu_bits == [x.bits for x in logs]
-        res["cpu_baseline"] = {"value": round(v, 1), "unit": "MS/s", "cores": c, "threads": c, "nproc": nproc, "kind": "port", "sample": sample,
+        res["cpu_baseline"] = {"value": round(v, 1), "unit": "MS/s", "cores": min(c, physical_cores() or c), "threads": c, "nproc": nproc,
+                               "physical_cores": physical_cores(), "kind": "port", "sample": sample,
                                "threads_calibration_MSps": calib,
                                "gpu_matches_oracle_on_sample": (bool(same) if n_bits else None),
                                "compared": "per stream: symbols produced, characters emitted, sentences -- GPU engine vs oracle over warm-up + timed steps",

@@ -65,7 +65,11 @@ struct BitsHeader {
     uint32_t nflips;        // flip points found this call
     uint32_t overflow;      // 1 = more bits/flips than the slot can hold (never with the derived capacities)
     uint32_t uncached;      // backlog samples whose windows are not final yet (sizes the next call's window kernel)
-    uint32_t _pad[3];
+    // Stream tail only (tail_body.h): a checksum of the call's discriminator output, so that a test can compare every call of a free-running
+    // batch with a CPU reference without asking for the samples (which would flush the pipeline and change the launch shape):
+    // demod_ck[0] = sum bits(d[i]), demod_ck[1] = sum (i + 1) * bits(d[i]) (mod 2^32) over the demod_n = fir_m samples of the call.
+    uint32_t demod_ck[2];
+    uint32_t demod_n;       // 0xFFFFFFFF when the kernel that wrote the slot does not compute it
 };
 
 struct SpectrumStatsDev {   // must match hd::SpectrumStats (host/afc_tracker.hpp)

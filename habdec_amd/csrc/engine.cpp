@@ -98,6 +98,8 @@ struct StreamHost {
     uint64_t bits_total = 0;
     int last_buf = 0;
     std::vector<uint32_t> last_words;
+    uint32_t demod_ck[2] = {0, 0}, demod_ck_n = 0xFFFFFFFFu;   // discriminator checksum of the call delivered last (BitsHeader::demod_ck)
+    uint64_t demod_ck_call = 0;                               // ... and that call's index (0 = the engine's first hd_process_* call)
 };
 
 }  // namespace
@@ -684,6 +686,7 @@ int collect(hd_engine* e, hd_engine::CallSlot& sl)
         st.win_ub = hdr->uncached + st.inflight_m;
         st.last_nbits = hdr->nbits; st.last_nflips = hdr->nflips;
         st.bits_total += hdr->nbits;
+        st.demod_ck[0] = hdr->demod_ck[0]; st.demod_ck[1] = hdr->demod_ck[1]; st.demod_ck_n = hdr->demod_n; st.demod_ck_call = e->delivered;
         if (hdr->overflow) rc = fail(HD_ERR_CAPACITY, "symbol result slot overflow on stream " + std::to_string(s));
         const uint32_t* words = slot + sizeof(hd::BitsHeader) / 4;
         st.last_words.assign(words, words + (hdr->nbits + 31) / 32);
@@ -719,6 +722,7 @@ int hd_flush(hd_engine* e)
 {
     if (!e) return fail(HD_ERR_INVALID, "null engine");
     std::lock_guard<std::recursive_mutex> lock(e->mtx);
+    if (e->in_callback) return fail(HD_ERR_INVALID, "hd_flush cannot be called from a sentence / character callback (the delivery it would join is the one running)");
     HD_HIP(hipSetDevice(e->cfg.device));
     return flush_locked(e);
 }
@@ -729,6 +733,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     if (!d_iq) return fail(HD_ERR_INVALID, "null IQ pointer");
     if ((reinterpret_cast<uintptr_t>(d_iq) & 15) || (stride & 1)) return fail(HD_ERR_INVALID, "IQ base must be 16-byte aligned and stream_stride even");
     std::lock_guard<std::recursive_mutex> lock(e->mtx);
+    if (e->in_callback) return fail(HD_ERR_INVALID, "hd_process_* cannot be called from a sentence / character callback");   // (a nested delivery would count the slot being delivered twice)
     const auto h0 = std::chrono::steady_clock::now();
     HD_HIP(hipSetDevice(e->cfg.device));
     const uint32_t S = e->S;
@@ -1094,6 +1099,8 @@ int hd_process_host(hd_engine* e, const float* iq, size_t stride, const uint32_t
 {
     if (!e) return fail(HD_ERR_INVALID, "null engine");
     if (!iq) return fail(HD_ERR_INVALID, "null IQ pointer");
+    std::lock_guard<std::recursive_mutex> lock(e->mtx);   // (recursive: hd_process_device below takes it again)
+    if (e->in_callback) return fail(HD_ERR_INVALID, "hd_process_* cannot be called from a sentence / character callback");
     HD_HIP(hipSetDevice(e->cfg.device));
     const size_t dstride = e->cfg.max_chunk;
     // validate the sizes before anything is queued (hd_process_device checks the rest and leaves every stream untouched on error)
@@ -1325,6 +1332,16 @@ uint64_t hd_stream_bits_total(hd_engine* e, uint32_t s)
     if (check_stream(e, s)) return 0;
     std::lock_guard<std::recursive_mutex> l(e->mtx);
     return e->st[s].bits_total;
+}
+int hd_stream_demod_checksum(hd_engine* e, uint32_t s, uint64_t* call_index, uint32_t* n, uint32_t ck[2])
+{
+    if (check_stream(e, s)) return HD_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
+    const StreamHost& st = e->st[s];
+    if (call_index) *call_index = st.demod_ck_call;
+    if (n) *n = st.demod_ck_n;
+    if (ck) { ck[0] = st.demod_ck[0]; ck[1] = st.demod_ck[1]; }
+    return HD_OK;
 }
 uint32_t hd_stream_symbol_backlog(hd_engine* e, uint32_t s)
 {

@@ -189,19 +189,19 @@ inline Distance gps_distance(double lat1, double lon1, double alt1, double lat2,
     ::sincos(lat1, &s1, &c1);
     ::sincos(lat2, &s2, &c2);
     ::sincos(dlon, &sd, &cd);
-    const double sa = c2 * sd;
-    const double sb = (c1 * s2) - (s1 * c2 * cd);
-    double bearing = std::atan2(sa, sb);
-    const double aa = std::sqrt((sa * sa) + (sb * sb));
-    const double ab = (s1 * s2) + (c1 * c2 * cd);
-    const double angle = std::atan2(aa, ab);
-    const double ta = r + alt1, tb = r + alt2;
+    const double east = c2 * sd;                                   // bearing: atan2(east, north) of the great-circle direction at point 1
+    const double north = (c1 * s2) - (s1 * c2 * cd);
+    double bearing = std::atan2(east, north);
+    const double sin_arc = std::sqrt((east * east) + (north * north)); // central angle between the two points
+    const double cos_arc = (s1 * s2) + (c1 * c2 * cd);
+    const double angle = std::atan2(sin_arc, cos_arc);
+    const double rad1 = r + alt1, rad2 = r + alt2;                  // distances from the Earth's centre
     double sn, cs;
     ::sincos(angle, &sn, &cs);
-    const double ea = (cs * tb) - ta;
-    const double eb = sn * tb;
-    const double elevation = std::atan2(ea, eb);
-    const double line = std::sqrt((ta * ta) + (tb * tb) - 2 * tb * ta * cs);
+    const double rise = (cs * rad2) - rad1;                         // point 2 seen from point 1: up and along the local horizon
+    const double run = sn * rad2;
+    const double elevation = std::atan2(rise, run);
+    const double line = std::sqrt((rad1 * rad1) + (rad2 * rad2) - 2 * rad2 * rad1 * cs);
     if (bearing < 0) bearing += 2 * M_PI;
     return {line, angle * r, angle, elevation / rad, bearing / rad};
 }

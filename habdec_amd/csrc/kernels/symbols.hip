@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     const uint32_t m = call[s].fir_m;
     const SymState old = sym[s];
     if (!m) {                                               // symbol stage not reached this call
-        if (tid == 0) { hdr->nbits = 0; hdr->held_after = old.held; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = old.base + old.held - old.cached; }
+        if (tid == 0) { hdr->nbits = 0; hdr->held_after = old.held; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = old.base + old.held - old.cached; hdr->demod_n = 0xFFFFFFFFu; }
         return;
     }
     const SymbolParams q = sp[s];
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     // run finds one sweep of work instead of two -- busy streams alternate between the two kinds of call.
     const bool search = !(h < q.min_held || h < q.spb);
     if (!search && (q.min_held == 0xFFFFFFFFu || h < q.R)) {
-        if (tid == 0) { sym[s] = st; hdr->nbits = 0; hdr->held_after = h; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = st.base + h - st.cached; }
+        if (tid == 0) { sym[s] = st; hdr->nbits = 0; hdr->held_after = h; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = st.base + h - st.cached; hdr->demod_n = 0xFFFFFFFFu; }
         return;
     }
     const uint32_t R = q.R, rmask = ring_cap - 1;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
         if (tid == 0) {
             if ((int32_t)(pend - st.cached) > 0) st.cached = pend;
             sym[s] = st;
-            hdr->nbits = 0; hdr->held_after = h; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = end - st.cached;
+            hdr->nbits = 0; hdr->held_after = h; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = end - st.cached; hdr->demod_n = 0xFFFFFFFFu;
         }
         STAMP(2); STAMP(3); STAMP(4); STAMP(5);
         return;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
         st.base += last;
         st.held = h - last;
         sym[s] = st;
-        hdr->nbits = nbits; hdr->held_after = st.held; hdr->nflips = nfl; hdr->overflow = overflow; hdr->uncached = end - st.cached;
+        hdr->nbits = nbits; hdr->held_after = st.held; hdr->nflips = nfl; hdr->overflow = overflow; hdr->uncached = end - st.cached; hdr->demod_n = 0xFFFFFFFFu;
 #ifdef HD_STAMP
         g_sym_stamps[s * 8 + 6] = nfl; g_sym_stamps[s * 8 + 7] = nfl ? flips[nfl - 1] : 0;
 #endif

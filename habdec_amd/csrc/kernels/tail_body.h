@@ -162,6 +162,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     const uint32_t end_old = old.base + old.held;                       // ring position of this call's first discriminator output
     uint32_t c0 = st.cached;                                            // next position whose window sum is due; V[0] is sample c0
     uint32_t vcnt = 0;                                                  // samples in V
+    uint32_t ck0 = 0, ck1 = 0;                                          // this lane's share of the discriminator checksum (BitsHeader::demod_ck)
     unsigned long long carry_word = 0ull;                               // flags of the positions [c0 & ~63, c0), as earlier sweeps left them
     const uint32_t old_cnt = do_sums ? end_old - c0 : 0u;              // backlog samples whose windows are not final yet (R-1 in steady state)
 
@@ -541,6 +542,9 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
                             d[3] = discriminate(c3.x, c3.y, c2.x, c2.y);
 #endif
                             const f32x2 av[4] = {c0, c1, c2, c3};
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if ((uint32_t)u < nv) { const uint32_t b = __builtin_bit_cast(uint32_t, d[u]); ck0 += b; ck1 += (i + (uint32_t)u + 1u) * b; }
                             float* dm = a.demod + (size_t)s * a.demod_stride + i;   // i and demod_stride are even
                             const uint32_t pos = end_old + i;           // SymbolExtractor::pushSamples: append to the backlog ring
                             const float4 d4 = make_float4(d[0], d[1], d[2], d[3]);
@@ -855,6 +859,20 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     TSTAMP(11);
     };
     second_half();
+    {   // the call's discriminator checksum (BitsHeader::demod_ck): lanes -> wave -> (256-lane variant) workgroup
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { ck0 += (uint32_t)__shfl_xor((int)ck0, o, 64); ck1 += (uint32_t)__shfl_xor((int)ck1, o, 64); }
+        if constexpr (NT == 64) {
+            if (tid == 0) { hdr->demod_ck[0] = ck0; hdr->demod_ck[1] = ck1; hdr->demod_n = m; }
+        } else {
+            tb_sync<NT>();
+            if (tid == 0) { sh[5] = 0; sh[6] = 0; }
+            tb_sync<NT>();
+            if (lane == 0) { atomicAdd(&sh[5], ck0); atomicAdd(&sh[6], ck1); }
+            tb_sync<NT>();
+            if (tid == 0) { hdr->demod_ck[0] = sh[5]; hdr->demod_ck[1] = sh[6]; hdr->demod_n = m; }
+        }
+    }
     // ---- the stream's spectrum, when its 4096-sample buffer completed in this call (Decoder.h:475-489): transform, half swap, power and
     // AFC statistics by this same wave (spectrum_wave.h) -- no launches of their own, no fft_raw round trip.  The buffer's last samples
     // were stored by this workgroup a moment ago.

@@ -146,6 +146,12 @@ class Engine:
 
     def bits_total(self, s=0) -> int: return int(self.L.hd_stream_bits_total(self.h, s))
 
+    def demod_checksum(self, s=0):
+        """(call index, n, ck0, ck1) of the call delivered last for stream s -- no flush; n is None where the launch path does not compute it."""
+        ci, n, ck = C.c_uint64(0), C.c_uint32(0), (C.c_uint32 * 2)()
+        check(self.L.hd_stream_demod_checksum(self.h, s, C.byref(ci), C.byref(n), ck))
+        return int(ci.value), (None if n.value == 0xFFFFFFFF else int(n.value)), int(ck[0]), int(ck[1])
+
     def timing(self) -> dict:
         t = capi.hd_timing()
         check(self.L.hd_engine_timing(self.h, C.byref(t)))

@@ -156,6 +156,10 @@ size_t hd_stream_bits(hd_engine* e, uint32_t stream, uint8_t* bits, size_t cap);
 size_t hd_stream_flips(hd_engine* e, uint32_t stream, uint32_t* flips, size_t cap);        /* flip points of the last call */
 size_t hd_stream_fir_taps(hd_engine* e, uint32_t stream, float* taps, size_t cap);
 uint32_t hd_stream_symbol_backlog(hd_engine* e, uint32_t stream);                          /* samples held by the symbol extractor */
+/* Checksum of the discriminator output (getDemodulated(), Decoder.h:131) of the call DELIVERED last for this stream, without flushing the
+ * pipeline: ck[0] = sum of the samples' bit patterns, ck[1] = sum of (i + 1) * bit pattern, mod 2^32, over n samples; *call_index counts
+ * hd_process_* calls from 0.  n = 0xFFFFFFFF when the launch path that served the call does not compute it (only the stream tail does). */
+int hd_stream_demod_checksum(hd_engine* e, uint32_t stream, uint64_t* call_index, uint32_t* n, uint32_t ck[2]);
 uint64_t hd_stream_bits_total(hd_engine* e, uint32_t stream);                              /* symbols produced since the engine was created (delivered calls) */
 
 /* ---- measurement ---- */

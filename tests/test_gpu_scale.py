@@ -73,12 +73,31 @@ def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, s
             assert (ga["peak_l"], ga["peak_r"]) == (oa["peak_l"], oa["peak_r"]), ("peaks", k, s)
             assert ga["correction"] == pytest.approx(oa["correction"], rel=1e-9, abs=1e-9), ("afc", k, s)
     assert eng.timing()["path"] == 3                         # the step kernel is what ran
-    for k in range(n_checked, n_checked + n_free):           # free running: two calls in flight, tails inside the next call's launch
+    # Free running: two (three) calls in flight, every call's tails INSIDE the next call's step launch -- the launch shape bench.py times.
+    # Asking for samples would flush the pipeline and turn the pending tails into a launch of their own, so each call is checked through
+    # the checksum of its discriminator output that the tail leaves in the result slot (BitsHeader::demod_ck) -- call by call, against the
+    # oracle's output of the same call -- plus the symbols it produced.
+    want, seen = {}, {s: set() for s in check}
+    def compare_delivered():
+        for s in check:
+            ci, n, c0, c1 = eng.demod_checksum(s)
+            if ci in want and ci not in seen[s]:
+                assert (n, c0, c1) == want[ci][s], ("discriminator checksum of a call served inside a step launch", ci, s)
+                seen[s].add(ci)
+    for k in range(n_checked, n_checked + n_free):
         eng.process_device(ring[k % ring_chunks].data_ptr(), C, C)
+        want[k] = {}
         for s, o in orcs.items():
             o(host[s][k % ring_chunks], fs)
             obits[s] += len(o.bits())
+            d = o.array("last_demod").view(np.uint32).astype(np.uint64)
+            want[k][s] = (len(d), int(d.sum() & 0xFFFFFFFF), int((d * np.arange(1, len(d) + 1, dtype=np.uint64)).sum() & 0xFFFFFFFF))
+        compare_delivered()
+    assert eng.timing()["path"] == 3
+    in_launch = min(len(v) for v in seen.values())           # calls whose tails rode in a step launch and were compared before the final flush
+    assert in_launch >= n_free - 4, in_launch
     eng.flush()
+    compare_delivered()
     busy = 0
     for s, o in orcs.items():
         assert eng.take_chars(s) == o.text("chars_log"), ("chars", s)

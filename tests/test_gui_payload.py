@@ -114,3 +114,70 @@ def test_payloads_from_a_live_engine():
         assert np.max(np.abs(back - thin)) <= (hi - lo) / (2 ** (8 * ts) - 1) * 1.01
         got, sent = ours_demod(L, d, 256, ts)
         assert sent == 256 and len(got) == 20 + 256 * ts
+
+
+LIVE = json.loads((ROOT / "tests" / "golden" / "gui_live.json").read_text())
+
+
+def _spectrum_header(b):
+    """SpectrumInfoHeader (NetTransport.h:29-46): 13 little-endian words."""
+    i = np.frombuffer(b[:52], np.int32); f = np.frombuffer(b[:52], np.float32)
+    return dict(header_size=int(i[0]), noise_floor=float(f[1]), noise_variance=float(f[2]), sampling_rate=float(f[3]), shift=float(f[4]),
+                peak_left=int(i[5]), peak_right=int(i[6]), peak_left_valid=int(i[7]), peak_right_valid=int(i[8]), min=float(f[9]), max=float(f[10]),
+                type_size=int(i[11]), size=int(i[12]))
+
+
+@pytest.mark.gpu
+def test_live_engine_payloads_against_the_reference_bytes():
+    """SURVEY 8(f) row 1, pinned: tests/golden/gui_live.json holds the payload bytes the REFERENCE's serializers (NetTransport.h + CompressedVector.cpp,
+    compiled as they are) produce from the CPU oracle's power spectrum / AFC read-outs / discriminator output of one seeded stream
+    (tools/gen_golden_gui_live.py).  The GPU engine decodes the same stream and its getters go through hd_host_*_payload:
+      * demodulation payloads must be the reference's bytes exactly (the discriminator output is bit-identical);
+      * spectrum payloads: every integer header field equal (sizes, peaks and their validity, type size), float header fields and the
+        32-bit values within the spectrum's parity tolerance (the transform is compared norm-wise everywhere: 1e-5 of the strongest bin,
+        which is 5e-3 dB on bins within 40 dB of it), 8/16-bit values within one quantisation step of the reference's."""
+    import habdec_amd
+    from habdec_amd import synth
+    inp = LIVE["input"]
+    x = synth.fsk_iq(synth.rtty_bits(synth.make_sentence(*inp["text"]) * 2, 8, 2, 4, 4), inp["fs"], inp["baud"], seed=inp["seed"], sigma=inp["sigma"])
+    x = x[:len(x) // inp["chunk"] * inp["chunk"]]
+    assert len(x) == inp["samples"]
+    eng = habdec_amd.Engine(n_streams=1, max_chunk=inp["chunk"], sampling_rate=inp["fs"], decimation=inp["factor"], baud=inp["baud"])
+    for k in range(len(x) // inp["chunk"]):
+        eng.process_host(x[None, k * inp["chunk"]:(k + 1) * inp["chunk"]])
+    L = eng.L
+    p, a, d = eng.power(0), eng.afc(0), eng.demodulated(0)
+    assert p.size == LIVE["n_power"] and d.size == LIVE["n_demod"]
+    assert (a["peak_l"], a["peak_r"]) == (LIVE["afc"]["peak_l"], LIVE["afc"]["peak_r"])
+    for e in LIVE["demod"]:
+        got, sent = ours_demod(L, d, e["resolution"], e["type_size"])
+        assert sent == e["values_sent"] and got.hex() == e["payload"], ("demod payload", e["resolution"], e["type_size"])
+    fsd = inp["fs"] / inp["factor"]
+    for e in LIVE["spectrum"]:
+        buf = np.zeros(1 << 16, np.uint8); sent = C.c_size_t(0)
+        nb = L.hd_host_spectrum_payload(p, p.size, a["noise_floor"], a["noise_var"], fsd, a["shift_hz"], a["peak_l"], a["peak_r"], e["zoom"], e["resolution"],
+                                        e["type_size"], buf, buf.size, C.byref(sent))
+        got, want = bytes(buf[:nb]), bytes.fromhex(e["payload"])
+        assert sent.value == e["bins_sent"] and len(got) == len(want)
+        hg, hw = _spectrum_header(got), _spectrum_header(want)
+        for k in ("header_size", "peak_left", "peak_right", "peak_left_valid", "peak_right_valid", "type_size", "size"):
+            assert hg[k] == hw[k], (k, hg[k], hw[k])
+        assert hg["sampling_rate"] == hw["sampling_rate"] and hg["shift"] == hw["shift"]
+        assert hg["noise_floor"] == pytest.approx(hw["noise_floor"], rel=1e-5) and hg["noise_variance"] == pytest.approx(hw["noise_variance"], rel=1e-4)
+        ts, n = e["type_size"], e["bins_sent"]
+        span = hw["max"] - hw["min"]
+        if ts == 4:
+            vg, vw = np.frombuffer(got[52:], np.float32), np.frombuffer(want[52:], np.float32)
+            strong = vw > vw.max() - 40.0
+            assert np.max(np.abs(vg - vw)[strong]) <= 5e-3                     # dB, bins within 40 dB of the strongest
+            assert np.max(np.abs(vg - vw)) <= 0.5                               # dB, the noise bins (a rounding difference in a near-empty bin is a large ratio)
+        else:
+            assert hg["min"] == pytest.approx(hw["min"], abs=0.5) and hg["max"] == pytest.approx(hw["max"], abs=5e-3)
+            qg = np.frombuffer(got[52:], np.uint8 if ts == 1 else np.uint16).astype(np.float64)
+            qw = np.frombuffer(want[52:], np.uint8 if ts == 1 else np.uint16).astype(np.float64)
+            step = span / (2 ** (8 * ts) - 1)
+            back_g = hg["min"] + qg / (2 ** (8 * ts) - 1) * (hg["max"] - hg["min"])
+            back_w = hw["min"] + qw / (2 ** (8 * ts) - 1) * span
+            strong = back_w > hw["max"] - 40.0
+            assert np.max(np.abs(back_g - back_w)[strong]) <= step + 5e-3, (ts, n)
+    eng.close()

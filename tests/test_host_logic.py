@@ -235,13 +235,13 @@ def test_atan2_restatement_matches_libm(L, O):
 def test_oracle_discriminator_is_the_fdlibm_restatement_not_the_box_libm():
     """The oracle evaluates arg() through its own fdlibm restatement (oracle/orc_atan2f.h), so bit-exact discriminator asserts compare
     like with like on any libm.  On glibc 2.35 (this image) the box's atan2f agrees with it on every probe; elsewhere a difference is
-    REPORTED, never a failure -- it means "another libm", not "a wrong kernel"."""
-    import warnings
+    RECORDED in the results as an expected failure (xfail), not passed over in silence: it means "another libm" -- the reference built on
+    this host would differ from the golden vectors in the same way -- not "a wrong kernel"."""
     from oracle import pyoracle
     bad = pyoracle.atan2f_libm_mismatches(400000, seed=7)
     if bad:
-        warnings.warn(f"this box's libm atan2f differs from the fdlibm restatement on {bad} of 400289 probes: "
-                      "discriminator parity is checked against the restatement (glibc 2.35 behaviour), not against this libm")
+        pytest.xfail(f"this box's libm atan2f differs from the fdlibm restatement on {bad} of 400289 probes: "
+                     "discriminator parity is checked against the restatement (glibc 2.35 behaviour), not against this libm")
 
 
 @pytest.mark.parametrize("factor,want", [(1, 1), (2, 68), (4, 140), (8, 280), (16, 544), (32, 1088), (64, 2176), (128, 4480), (256, 8960), (3, 0)])

@@ -73,6 +73,35 @@ def test_rounds_match_reference_semantics(tmp_path, loop, chunk, granule, length
         assert all(src.rewinds(s) > 0 for s in range(len(lengths)))
 
 
+def test_realtime_throttle_paces_the_rounds_like_the_reference(tmp_path):
+    """IQSource_File.h:165-168 sleeps size_t(read / rate * 1000) milliseconds after a read when it plays a file in real time; the batch reader does
+    that once per round for the longest read of the round.  Eight rounds of 4096 samples at 40960 samples/s are eight sleeps of 100 ms; the
+    data is what the unthrottled reader delivers."""
+    import time
+    import habdec_amd
+    datas, paths = write_files(tmp_path, [4096 * 8, 4096 * 8])
+    fast = habdec_amd.IqFiles(paths, chunk=4096, granule=64)
+    slow = habdec_amd.IqFiles(paths, chunk=4096, granule=64, realtime_rate=40960.0)
+    t0 = time.perf_counter()
+    rounds = [fast.next() for _ in range(8)]
+    t_fast = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for want in rounds:
+        slab, n, alive = slow.next()
+        assert alive == want[2] and list(n) == list(want[1])
+        assert np.array_equal(slab.view(np.uint32), want[0].view(np.uint32))
+    t_slow = time.perf_counter() - t0
+    assert t_fast < 0.2
+    assert 0.8 <= t_slow < 2.0, t_slow                              # 8 x 100 ms (sleep_for never returns early)
+    # the truncation to whole milliseconds (size_t(...)): 100 samples at 40960 samples/s are 2.44 ms -> 2 ms, not 0 and not 3
+    tiny = habdec_amd.IqFiles(paths, chunk=128, granule=64, realtime_rate=40960.0)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        tiny.next()
+    dt = time.perf_counter() - t0
+    assert 0.06 <= dt < 0.5, dt                                     # 20 x 3 ms (128 samples: 3.125 ms -> 3 ms)
+
+
 def test_open_errors(tmp_path):
     import habdec_amd
     _, paths = write_files(tmp_path, [100])

@@ -56,9 +56,12 @@ def main():
     front = max((k for k in table if k.startswith("k_decimate") or k.startswith("k_step")), key=lambda k: table[k]["hbm_bytes"])
     tf = dst / "traffic.json"
     cur = json.loads(tf.read_text()) if tf.exists() else {}
+    st = next((r for r in rows if r[0] == front), None)      # the same kernel in the --kernel-trace --stats pass: bench.py reports it beside its live figure
     cur[workload] = {"front_kernel": front, "front_kernel_hbm_bytes_per_launch": table[front]["hbm_bytes"],
                      "fetch_bytes_x2_corrected": table[front]["fetch_bytes"], "write_bytes": table[front]["write_bytes"],
-                     "source": f"profiles/{rnd}_pmc_traffic.json"}
+                     "source": f"profiles/{rnd}_pmc_traffic.json",
+                     "rocprof_avg_launch_ms": round(float(st[3]) / 1e6, 5) if st else None, "rocprof_launches": int(st[1]) if st else None,
+                     "stats_source": f"profiles/{rnd}_kernel_stats.csv"}
     tf.write_text(json.dumps(cur, indent=1) + "\n")
     for b in ("stats", "fetch", "write"):
         p = src / f"{b}_bench.json"
