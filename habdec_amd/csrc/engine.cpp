@@ -946,8 +946,9 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         const uint32_t ntiles1 = (max_n1 + 63) / 64;
         uint32_t ring_run = e->ring_run >= 2 ? e->ring_run : 8u;
         while (ring_run > 2 && (ntiles1 % ring_run || ((uint64_t)S * ntiles1 / ring_run) % (e->n_cus / 32u ? e->n_cus / 32u : 1u))) ring_run >>= 1;
-        const bool want_cu = !e->no_cu_step && cu_tail && !any_zero1 && max_in % 2048u == 0 && ta_step.lds_bytes <= cu_tail &&
-                             (!prev.valid || prev.ta.lds_bytes <= cu_tail);
+        static const int cu_exp0 = getenv("HD_CU_EXP") ? atoi(getenv("HD_CU_EXP")) : 0;
+        const bool want_cu = !e->no_cu_step && cu_tail && !any_zero1 && max_in % 2048u == 0 && ((cu_exp0 & 1) || (ta_step.lds_bytes <= cu_tail &&
+                             (!prev.valid || prev.ta.lds_bytes <= cu_tail)));
         const hd::StepClaim claim = make_claim(0, want_cu ? ring_run : 0u);
         if (claim.ctr && !e->step_wgs) wgs = 8u * e->n_cus;
         bool launched = false;

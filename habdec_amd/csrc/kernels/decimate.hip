@@ -328,35 +328,47 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
                           "the look-ahead read of the last chunk must stay inside the workgroup's LDS");
             f32x2 acc = {0.f, 0.f};
             f32x4 xa[8], xb[8];
-            float ka[16], kb[16];                               // the chunk's taps (wave-uniform: scalar registers), requested with its samples
-            auto rd = [&](f32x4 (&x)[8], float (&k)[16], const int c, auto j0, auto j1) {
+            f32x2 ka[8], kb[8];                                 // the chunk's taps as eight pairs (wave-uniform: scalar registers), requested with its samples
+            auto rd = [&](f32x4 (&x)[8], f32x2 (&k)[8], const int c, auto j0, auto j1) {
                 const float2* pc = p + c * CH + 2 * ((c * CH) / D);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) x[q] = *reinterpret_cast<const f32x4*>(pc + 2 * q);
                 const float* tb = taps + (c * CH - JS);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) k[j] = (j >= decltype(j0)::value && j < decltype(j1)::value) ? tb[j] : 0.f;
+                for (int j = 0; j < 16; j += 2) {
+                    k[j >> 1].x = (j >= decltype(j0)::value && j < decltype(j1)::value) ? tb[j] : 0.f;
+                    k[j >> 1].y = (j + 1 >= decltype(j0)::value && j + 1 < decltype(j1)::value) ? tb[j + 1] : 0.f;
+                }
+            };
+            auto mac_part = [&](const f32x4 (&x)[8], const f32x2 (&k)[8], auto j0, auto j1) {    // a chunk only part of whose slots carry taps
+#pragma unroll
+                for (int j = decltype(j0)::value; j < decltype(j1)::value; ++j) {
+                    const f32x2 smp = (j & 1) ? x[j >> 1].zw : x[j >> 1].xy;
+                    acc = acc + smp * ((j & 1) ? k[j >> 1].y : k[j >> 1].x);
+                }
             };
             using I0 = std::integral_constant<int, 0>;
             using I16 = std::integral_constant<int, 16>;
-            rd(xa, ka, 0, std::integral_constant<int, JS>{}, I16{});
+            using IJS = std::integral_constant<int, JS>;
+            using IRem = std::integral_constant<int, NS % CH>;
+            rd(xa, ka, 0, IJS{}, I16{});
             rd(xb, kb, 1, I0{}, I16{});
-            dec_chunk_mac<JS, CH, LA>(acc, xa, ka);
+            if constexpr (JS == 0) ring_mac16_asm(acc, xa, ka); else mac_part(xa, ka, IJS{}, I16{});
             int c = 1;
 #pragma unroll 1
             for (; c + 1 < NCH; c += 2) {                       // chunk c is in xb
                 rd(xa, ka, c + 1, I0{}, I16{});
-                dec_chunk_mac<0, CH, LA>(acc, xb, kb);
+                ring_mac16_asm(acc, xb, kb);                    // (sixteen taps with the products three ahead of the adds: stage1_ring.h)
                 if (c + 2 < NCH) rd(xb, kb, c + 2, I0{}, I16{});
-                else rd(xb, kb, NCH, I0{}, std::integral_constant<int, NS % CH>{});    // the partial chunk behind the last pair (or nothing)
-                dec_chunk_mac<0, CH, LA>(acc, xa, ka);
+                else rd(xb, kb, NCH, I0{}, IRem{});             // the partial chunk behind the last pair (or nothing)
+                ring_mac16_asm(acc, xa, ka);
             }
             if constexpr ((NCH - 1) % 2) {                      // one full chunk left over (in xb)
-                rd(xa, ka, NCH, I0{}, std::integral_constant<int, NS % CH>{});
-                dec_chunk_mac<0, CH, LA>(acc, xb, kb);
-                if constexpr (NS % CH) dec_chunk_mac<0, NS % CH, LA>(acc, xa, ka);
+                rd(xa, ka, NCH, I0{}, IRem{});
+                ring_mac16_asm(acc, xb, kb);
+                if constexpr (NS % CH) mac_part(xa, ka, I0{}, IRem{});
             } else {
-                if constexpr (NS % CH) dec_chunk_mac<0, NS % CH, LA>(acc, xb, kb);
+                if constexpr (NS % CH) mac_part(xb, kb, I0{}, IRem{});
             }
             yq[0] = make_float2(acc.x, acc.y);
         } else
@@ -728,7 +740,7 @@ bool launch_step(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, u
 
 uint32_t step_cu_tail_lds(int ratio, int ntaps)
 {
-    auto lim = [](int rb) { const uint32_t left = (163840u - (uint32_t)rb) / 4u; return (left < kStepLdsBytes ? left : kStepLdsBytes) & ~15u; };
+    auto lim = [](int rb) { const uint32_t left = rb < 163840 ? (163840u - (uint32_t)rb) / 4u : 16u; return (left < kStepLdsBytes ? left : kStepLdsBytes) & ~15u; };
     if (ratio == 32 && ntaps == 212) return lim(ring_bytes<212>());
     if (ratio == 32 && ntaps == 174) return lim(ring_bytes<174>());
     return 0;
@@ -742,7 +754,7 @@ bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2
     RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, uniform_n / 2048u, claim, gave_up};
 #define HD_CU_CASE(T, D2, T2)                                                                                                         \
     if (ntaps == T && ratio2 == D2 && ntaps2 == T2) {                                                                                 \
-        const uint32_t lds = (uint32_t)ring_bytes<T>() + 4u * tail_bytes;                                                             \
+        const uint32_t lds = (uint32_t)ring_bytes<T>() + (n_tail ? 4u * tail_bytes : 0u);                                             \
         if (lds > 163840u) return false;                                                                                              \
         static bool attr_set = false;                                                                                                 \
         if (!attr_set) {                                                                                                              \

@@ -6,11 +6,11 @@
 // samples never go to HBM unless a parity test asks for them: per decimated sample the kernel reads 8 B and writes
 // 4 B, the "8/D + 4/D" terms of the pipeline's byte model.
 //
-// Mapping: grid = (tiles, streams), 256 lanes per tile, TWO adjacent outputs per lane (2l, 2l+1 within the tile), so
-// that one 16-byte LDS read (samples 2l+2k, 2l+2k+1) feeds four multiply-adds: the kernel is bound by the LDS read
-// rate (8 B per complex sample x tap at one output per lane), and two outputs per lane halve that to the level of the
-// packed-f32 issue rate.  Tiles advance by 510 outputs and overlap by two: lane 0 only recomputes the predecessor
-// y[i-1] that lane 1's first output needs.  The per-stream input buffer keeps the FIR history right in front of the
+// Mapping: grid = (tiles, streams), 256 lanes per tile, FOUR adjacent outputs per lane (4l .. 4l+3 within the tile) on a rolling
+// register window: one 16-byte LDS read (two samples) feeds eight packed multiply-adds, and the four independent sums let a wave
+// issue back to back (one sum per lane waits out the adder on every tap; two, as in rounds 1-2, left the kernel at half the
+// packed-f32 rate with 44 registers in use).  Taps come in blocks of sixteen through the scalar cache, requested a block ahead.
+// Tiles advance by 1020 outputs and overlap by four: lane 0 only recomputes the predecessor y[i-1] that lane 1's first output needs.  The per-stream input buffer keeps the FIR history right in front of the
 // pending samples, so a tile's 512+T-1 inputs are one contiguous, coalesced read into LDS.  Taps are per stream and
 // wave-uniform (scalar loads).
 #include <hip/hip_runtime.h>
@@ -21,14 +21,29 @@
 namespace hd {
 
 constexpr int kFirLanes = 256;
-constexpr int kFirTile = 2 * kFirLanes;          // outputs computed per tile
-constexpr int kFirAdvance = kFirTile - 2;        // outputs written per tile
+constexpr int kFirOut = 4;                       // adjacent outputs per lane
+constexpr int kFirTile = kFirOut * kFirLanes;    // outputs computed per tile
+constexpr int kFirAdvance = kFirTile - kFirOut;  // outputs written per tile (lane 0 only supplies lane 1's predecessor)
+constexpr int kFirSlack = 24;                    // samples a lane may read past its last tap (whole 16-tap blocks of a four-output window)
 
-#define HD_FIR_PAIR(P, N, k0, k1)                  \
-    a0r = a0r + (P).x * (k0); a0i = a0i + (P).y * (k0); \
-    a1r = a1r + (P).z * (k0); a1i = a1i + (P).w * (k0); \
-    a0r = a0r + (P).z * (k1); a0i = a0i + (P).w * (k1); \
-    a1r = a1r + (N).x * (k1); a1i = a1i + (N).y * (k1);
+typedef float fd_f32x2 __attribute__((ext_vector_type(2)));
+typedef float fd_f32x4 __attribute__((ext_vector_type(4)));
+
+// Sixteen taps for a lane's four adjacent outputs.  w[0..9] are the twenty samples x[4l + t0 .. 4l + t0 + 19] (pairs); output q takes sample
+// j + q with tap j.  Four independent sums: per tap four products, then four adds -- every sum still receives its products in ascending tap
+// order with separately rounded multiply and add, and one wave keeps issuing back to back (a single chain waits out the add on every tap).
+__device__ __forceinline__ void fir_block16(fd_f32x2 (&acc)[kFirOut], const fd_f32x4 (&w)[10], const float (&k)[16])
+{
+    auto smp = [&](int i) -> fd_f32x2 { return (i & 1) ? w[i >> 1].zw : w[i >> 1].xy; };
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        fd_f32x2 pr[kFirOut];
+#pragma unroll
+        for (int q = 0; q < kFirOut; ++q) pr[q] = smp(j + q) * k[j];
+#pragma unroll
+        for (int q = 0; q < kFirOut; ++q) acc[q] = acc[q] + pr[q];
+    }
+}
 
 __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restrict__ fbuf, size_t stride,
                                                           const float* __restrict__ taps, uint32_t taps_stride,
@@ -42,7 +57,7 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
                                                           const float2* __restrict__ head_in, const uint32_t* __restrict__ head_n_in,
                                                           float2* __restrict__ head_out, uint32_t* __restrict__ head_n_out, uint32_t head_cap)
 {
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];   // [kFirTile + T + 1] inputs, then reused for outputs
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];   // [kFirTile + T + kFirSlack] inputs, then reused for outputs
     const uint32_t s = blockIdx.y;
     const StreamCall c = call[s];
     const uint32_t m = c.fir_m, T = c.fir_taps;
@@ -72,11 +87,11 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && m == 0) carry_out[s] = carry_in[s];   // idle stream: carry passes through
     if (!m || !T) return;
-    const long i0 = (long)blockIdx.x * kFirAdvance - 2;            // output index of lane 0's first output (may be -2)
-    if (i0 + 2 >= (long)m) return;
+    const long i0 = (long)blockIdx.x * kFirAdvance - kFirOut;      // output index of lane 0's first output (may be -4)
+    if (i0 + kFirOut >= (long)m) return;
     const long b0 = (long)fir_hist_cap - (long)(T - 1) + i0;       // buffer index of tile-local sample 0
     const uint32_t live = (uint32_t)min((long)kFirTile, (long)m - i0);   // outputs of this tile that exist
-    const uint32_t need = ((live + 1u) & ~1u) + T + 1;             // + the pair read one past the last tap
+    const uint32_t need = ((live + 3u) & ~3u) + T + kFirSlack;     // + what whole blocks read past the last tap (zero-filled)
     const long end = (long)fir_hist_cap + (long)m;                 // one past the last valid input
     constexpr int LB = 4;                                          // loads in flight per lane before the first LDS store
     for (uint32_t j0 = threadIdx.x; j0 < need; j0 += LB * kFirLanes) {
@@ -105,79 +120,91 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
     }
     __syncthreads();
 
-    const float* tp = taps + (size_t)s * taps_stride;
-    const bool active = 2u * threadIdx.x < live;
-    float a0r = 0.f, a0i = 0.f, a1r = 0.f, a1i = 0.f;
+    typedef const float __attribute__((address_space(4)))* ctaps_t;
+    const ctaps_t tp = (ctaps_t)(uintptr_t)(taps + (size_t)s * taps_stride);   // per stream, wave-uniform: scalar loads
+    const bool active = (uint32_t)kFirOut * threadIdx.x < live;
+    fd_f32x2 acc[kFirOut];
+#pragma unroll
+    for (int q = 0; q < kFirOut; ++q) acc[q] = fd_f32x2{0.f, 0.f};
     if (active) {
-        const float4* p = reinterpret_cast<const float4*>(lds) + threadIdx.x;    // pair k: samples 2l+2k, 2l+2k+1
-        uint32_t t = 0;
-        float4 P = p[0];
-        if (T >= 8) {       // software-pipelined: the LDS pairs and the (scalar) taps of block t+8 are requested before block t's math
-            float4 N0 = p[1], N1 = p[2], N2 = p[3], N3 = p[4];
-            float k0 = tp[0], k1 = tp[1], k2 = tp[2], k3 = tp[3], k4 = tp[4], k5 = tp[5], k6 = tp[6], k7 = tp[7];
-            for (; t + 8 <= T; t += 8) {
-                float4 M0 = N3, M1 = N3, M2 = N3, M3 = N3;
-                float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, q4 = 0.f, q5 = 0.f, q6 = 0.f, q7 = 0.f;
-                if (t + 16 <= T) {
-                    const float4* pn = p + (t >> 1) + 5;
-                    M0 = pn[0]; M1 = pn[1]; M2 = pn[2]; M3 = pn[3];
-                    const float* tn = tp + t + 8;
-                    q0 = tn[0]; q1 = tn[1]; q2 = tn[2]; q3 = tn[3]; q4 = tn[4]; q5 = tn[5]; q6 = tn[6]; q7 = tn[7];
-                }
-                HD_FIR_PAIR(P, N0, k0, k1)
-                HD_FIR_PAIR(N0, N1, k2, k3)
-                HD_FIR_PAIR(N1, N2, k4, k5)
-                HD_FIR_PAIR(N2, N3, k6, k7)
-                P = N3;
-                N0 = M0; N1 = M1; N2 = M2; N3 = M3;
-                k0 = q0; k1 = q1; k2 = q2; k3 = q3; k4 = q4; k5 = q5; k6 = q6; k7 = q7;
+        // lane l's outputs 4l .. 4l+3 take samples 4l + t + q: a rolling window of twenty samples per sixteen taps, eight new 16-byte reads per
+        // block (half the LDS reads per multiply-add of the two-output version), the next block's samples and taps requested before this
+        // block's 128 packed operations.
+        const fd_f32x4* p = reinterpret_cast<const fd_f32x4*>(lds) + 2u * threadIdx.x;    // pair index: sample 4l + 2k
+        const uint32_t nblk = T / 16u;
+        fd_f32x4 w[10], wn[10];
+        float k[16], kn[16];
+        if (nblk) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) w[i] = p[i];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) k[j] = tp[j];
+        }
+        for (uint32_t b = 0; b < nblk; ++b) {
+            if (b + 1 < nblk) {
+                const fd_f32x4* pn = p + 8u * (b + 1u);
+#pragma unroll
+                for (int i = 0; i < 10; ++i) wn[i] = pn[i];
+                const ctaps_t tn = tp + 16u * (b + 1u);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) kn[j] = tn[j];
             }
+            fir_block16(acc, w, k);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) w[i] = wn[i];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) k[j] = kn[j];
         }
-        for (; t + 2 <= T; t += 2) {
-            const float4 N = p[(t >> 1) + 1];
-            const float k0 = tp[t], k1 = tp[t + 1];
-            HD_FIR_PAIR(P, N, k0, k1)
-            P = N;
-        }
-        if (t < T) {
-            const float k0 = tp[t];
-            a0r = a0r + P.x * k0; a0i = a0i + P.y * k0;
-            a1r = a1r + P.z * k0; a1i = a1i + P.w * k0;
+        for (uint32_t t = nblk * 16u; t < T; ++t) {                 // the taps behind the last whole block, one at a time
+            const float kt = tp[t];
+            const float2* x = lds + (uint32_t)kFirOut * threadIdx.x + t;
+            fd_f32x2 pr[kFirOut];
+#pragma unroll
+            for (int q = 0; q < kFirOut; ++q) { const float2 v = x[q]; pr[q] = fd_f32x2{v.x, v.y} * kt; }
+#pragma unroll
+            for (int q = 0; q < kFirOut; ++q) acc[q] = acc[q] + pr[q];
         }
     }
     __syncthreads();                       // everyone is done reading inputs: reuse LDS for the outputs
-    if (active) reinterpret_cast<float4*>(lds)[threadIdx.x] = make_float4(a0r, a0i, a1r, a1i);
+    if (active) {
+        reinterpret_cast<float4*>(lds)[2u * threadIdx.x] = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
+        reinterpret_cast<float4*>(lds)[2u * threadIdx.x + 1u] = make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y);
+    }
     __syncthreads();
 
     if (threadIdx.x == 0 || !active) return;           // lane 0 only supplied lane 1's predecessor
-    const long i = i0 + 2l * (long)threadIdx.x;        // >= 0 here
+    const long i = i0 + (long)kFirOut * (long)threadIdx.x;         // >= 0 here
     float pr, pi;
-    if (i > 0) { const float2 q = lds[2 * threadIdx.x - 1]; pr = q.x; pi = q.y; }
+    if (i > 0) { const float2 q = lds[kFirOut * threadIdx.x - 1]; pr = q.x; pi = q.y; }
     else {
-        const DemodCarry k = carry_in[s];
-        if (k.primed) { pr = k.re; pi = k.im; } else { pr = a0r; pi = a0i; }   // very first sample: arg(y0*conj(y0))
+        const DemodCarry kc = carry_in[s];
+        if (kc.primed) { pr = kc.re; pi = kc.im; } else { pr = acc[0].x; pi = acc[0].y; }   // very first sample: arg(y0*conj(y0))
     }
-    const bool two = i + 1 < (long)m;
-    const float d0 = discriminate(a0r, a0i, pr, pi);
-    const float d1 = two ? discriminate(a1r, a1i, a0r, a0i) : 0.f;
-    float* dm = demod + (size_t)s * demod_stride + i;
-    if (two) *reinterpret_cast<float2*>(dm) = make_float2(d0, d1); else dm[0] = d0;     // i is even, demod_stride is even
+    const uint32_t nv = (uint32_t)min((long)kFirOut, (long)m - i);  // outputs of this lane that exist
+    float d[kFirOut];
+    d[0] = discriminate(acc[0].x, acc[0].y, pr, pi);
+#pragma unroll
+    for (int q = 1; q < kFirOut; ++q) d[q] = (uint32_t)q < nv ? discriminate(acc[q].x, acc[q].y, acc[q - 1].x, acc[q - 1].y) : 0.f;
+    float* dm = demod + (size_t)s * demod_stride + i;                // i is a multiple of four, demod_stride is even
+    if (nv >= 2) *reinterpret_cast<float2*>(dm) = make_float2(d[0], d[1]); else dm[0] = d[0];
+    if (nv == 4) *reinterpret_cast<float2*>(dm + 2) = make_float2(d[2], d[3]); else if (nv == 3) dm[2] = d[2];
     if (sym_ring) {      // append straight into the symbol extractor's ring (SymbolExtractor::pushSamples); a vent
         const SymState st = sym[s];   // (backlog > 30000) restarts the backlog at the same position base + held
         float* ring = sym_ring + (size_t)s * ring_cap;
         const uint32_t pos = st.base + st.held + (uint32_t)i;
-        ring[pos & (ring_cap - 1)] = d0;
-        if (two) ring[(pos + 1) & (ring_cap - 1)] = d1;
+#pragma unroll
+        for (int q = 0; q < kFirOut; ++q) if ((uint32_t)q < nv) ring[(pos + (uint32_t)q) & (ring_cap - 1)] = d[q];
     }
     if (filtered) {
-        filtered[(size_t)s * demod_stride + i] = make_float2(a0r, a0i);
-        if (two) filtered[(size_t)s * demod_stride + i + 1] = make_float2(a1r, a1i);
+#pragma unroll
+        for (int q = 0; q < kFirOut; ++q) if ((uint32_t)q < nv) filtered[(size_t)s * demod_stride + i + q] = make_float2(acc[q].x, acc[q].y);
     }
     const long last = (long)m - 1;
-    if (i == last || (two && i + 1 == last)) {
-        DemodCarry k; k.primed = 1; k._pad = 0;
-        if (i == last) { k.re = a0r; k.im = a0i; } else { k.re = a1r; k.im = a1i; }
-        carry_out[s] = k;
+    if (i <= last && last < i + (long)kFirOut) {
+        DemodCarry kc; kc.primed = 1; kc._pad = 0;
+        const fd_f32x2 y = last == i ? acc[0] : last == i + 1 ? acc[1] : last == i + 2 ? acc[2] : acc[3];
+        kc.re = y.x; kc.im = y.y;
+        carry_out[s] = kc;
     }
 }
 
@@ -214,7 +241,7 @@ void launch_fir_demod(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32
                       const float2* head_in, const uint32_t* head_n_in, float2* head_out, uint32_t* head_n_out, uint32_t head_cap)
 {
     const uint32_t tiles = max_m ? (max_m + kFirAdvance - 1) / kFirAdvance : 1;
-    const size_t lds = (size_t)(kFirTile + (max_taps ? max_taps : 1) + 2) * sizeof(float2);
+    const size_t lds = (size_t)(kFirTile + (max_taps ? max_taps : 1) + kFirSlack + 4) * sizeof(float2);
     dim3 grid(tiles, n_streams);
     hipLaunchKernelGGL(k_fir_demod, grid, dim3(kFirLanes), lds, st, fbuf, stride, taps, taps_stride, demod, demod_stride, filtered,
                        carry_in, carry_out, call, fir_hist_cap, sym_ring, ring_cap, sym, fbuf_next, head_in, head_n_in, head_out, head_n_out, head_cap);

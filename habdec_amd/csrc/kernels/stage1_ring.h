@@ -40,7 +40,11 @@ typedef float r_f32x2 __attribute__((ext_vector_type(2)));
 typedef float r_f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kRingRowBytes = 272;                  // 32 samples + one 16-byte pad
-constexpr int kRingSlots = 4;
+#ifndef HD_RING_NSL
+#define HD_RING_NSL 2
+#endif
+constexpr int kRingNSL = HD_RING_NSL;                 // tile slots per loader wave
+constexpr int kRingSlots = 2 * kRingNSL;
 constexpr int kRingCtlBytes = 256;
 constexpr uint32_t kRingSpinLimit = 1u << 22;   // polls before a waiting wave gives up (seconds; a correct run waits microseconds)
 template <int T> constexpr int ring_halo_rows() { return (T - 1 + 31) / 32; }
@@ -68,8 +72,8 @@ struct RingCtl {
     uint32_t run_head;      // runs the loaders have claimed (fetch-add)
     uint32_t _pad;
     uint32_t run_q[4];      // drawn run numbers (0xFFFFFFFF: no more)
-    uint32_t slot_done[4];  // per slot 2 L + (l & 1): 1 + l of the tile last finished in it
-    uint4 desc[4];          // per slot: stream, tile
+    uint32_t slot_done[8];  // per slot NSL L + l % NSL: 1 + l of the tile last finished in it
+    uint4 desc[8];          // per slot: stream, tile
     uint32_t simd_rank[4];  // waves of the workgroup that have arrived on each SIMD (role assignment, k_step_cu)
 };
 static_assert(sizeof(RingCtl) <= kRingCtlBytes, "ring control block");
@@ -161,7 +165,7 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, unsigned char* __
     constexpr int NBODY = 17;                       // 64 rows x 17 chunks = 17 x 64 chunks
     constexpr int NHALO = (HR * 17 + 63) / 64;      // halo rows out of the stream itself (every tile but a stream's first)
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t ring_lds = lds_addr_of(ring) + 2u * L * (uint32_t)SLOT;
+    const uint32_t ring_lds = lds_addr_of(ring) + (uint32_t)kRingNSL * L * (uint32_t)SLOT;
 
     // per-lane source offsets (bytes from the tile's first body row / first halo row)
     uint32_t boff[NBODY], hoff[NHALO], hist_off[HR];
@@ -226,15 +230,15 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, unsigned char* __
             }
         }
         bool can = have && issued - landed < 2u;
-        if (can && issued >= 2u) {                                     // my slot issued & 1 held tile issued - 2: is its consumer finished?
-            const uint32_t dn = __hip_atomic_load(&ctl->slot_done[2u * L + (issued & 1u)], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            can = dn == issued - 1u;
+        if (can && issued >= (uint32_t)kRingNSL) {                     // my slot issued % NSL held tile issued - NSL: is its consumer finished?
+            const uint32_t dn = __hip_atomic_load(&ctl->slot_done[(uint32_t)kRingNSL * L + issued % (uint32_t)kRingNSL], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            can = dn == issued - (uint32_t)kRingNSL + 1u;
         }
         if (can) {
-            const uint32_t slot = issued & 1u;
+            const uint32_t slot = issued % (uint32_t)kRingNSL;
             const uint32_t dst = ring_lds + slot * (uint32_t)SLOT;
             const unsigned char* body = reinterpret_cast<const unsigned char*>(a.in + (size_t)s * a.in_stride) + (size_t)tile * (64u * 256u);
-            if (lane == 0) ctl->desc[2u * L + slot] = make_uint4(s, tile, 0u, 0u);
+            if (lane == 0) ctl->desc[(uint32_t)kRingNSL * L + slot] = make_uint4(s, tile, 0u, 0u);
             uint32_t cnt = NBODY;
             if (tile == 0) {
                 const unsigned char* hb = reinterpret_cast<const unsigned char*>(a.hist_in + (size_t)s * (T - 1));
@@ -283,7 +287,7 @@ __device__ __forceinline__ void ring_loader_regs(const RingArgs& a, unsigned cha
     constexpr int NCH = (64 + HR) * 16;             // sixteen-byte chunks of a tile, halo rows first
     constexpr int NV = (NCH + 63) / 64;             // loads per lane
     const uint32_t lane = threadIdx.x & 63u;
-    unsigned char* my_slots = ring + 2u * L * (uint32_t)SLOT;
+    unsigned char* my_slots = ring + (uint32_t)kRingNSL * L * (uint32_t)SLOT;
     const uint32_t xcd0 = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // XCC_ID
     const uint32_t xcd = xcd0 < a.claim.n_xcd ? xcd0 : a.claim.n_xcd - 1;
     const uint32_t runs = a.claim.runs_per_xcd, run_len = a.claim.run_len;
@@ -340,11 +344,11 @@ __device__ __forceinline__ void ring_loader_regs(const RingArgs& a, unsigned cha
         }
     };
     auto stash = [&](const float4 (&r)[NV], const Desc& d) {           // my next slot: wait until it is free, copy, publish
-        const uint32_t slot = landed & 1u;
-        if (landed >= 2u)
+        const uint32_t slot = landed % (uint32_t)kRingNSL;
+        if (landed >= (uint32_t)kRingNSL)
             for (uint32_t spin = 0;; ++spin) {
-                const uint32_t dn = __hip_atomic_load(&ctl->slot_done[2u * L + slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (dn == landed - 1u) break;
+                const uint32_t dn = __hip_atomic_load(&ctl->slot_done[(uint32_t)kRingNSL * L + slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (dn == landed - (uint32_t)kRingNSL + 1u) break;
                 if (spin > kRingSpinLimit) { if (lane == 0) (void)__hip_atomic_fetch_add(a.gave_up, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -354,7 +358,7 @@ __device__ __forceinline__ void ring_loader_regs(const RingArgs& a, unsigned cha
             const uint32_t P = lane + 64u * it;
             if ((it + 1) * 64 <= NCH || P < (uint32_t)NCH) *reinterpret_cast<float4*>(dst + (P >> 4) * (uint32_t)kRingRowBytes + (P & 15u) * 16u) = r[it];
         }
-        if (lane == 0) ctl->desc[2u * L + slot] = make_uint4(d.s, d.tile, 0u, 0u);
+        if (lane == 0) ctl->desc[(uint32_t)kRingNSL * L + slot] = make_uint4(d.s, d.tile, 0u, 0u);
         ++landed;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) __hip_atomic_store(&ctl->landed[L], landed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -493,7 +497,7 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const unsigned 
         }
         if (skip) continue;
         RSTAMP(0);
-        const uint32_t slot = 2u * L + (seq & 1u);
+        const uint32_t slot = (uint32_t)kRingNSL * L + seq % (uint32_t)kRingNSL;
         const uint4 d = ctl->desc[slot];
         const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.x), tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y);
         const unsigned char* p = ring + slot * (uint32_t)SLOT + lane * (uint32_t)kRingRowBytes;

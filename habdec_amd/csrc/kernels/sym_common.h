@@ -9,7 +9,9 @@
 namespace hd {
 
 constexpr int kAvgLanes = 256;
-constexpr uint32_t kMaxFlipsPerCall = 1024;   // upper bound of the LDS flip list (the launcher sizes it from backlog / R; overflow is flagged)
+constexpr uint32_t kMaxFlipsPerCall = 512;    // upper bound of the LDS flip list ON EVERY LAUNCH PATH (the launcher sizes it from backlog / R; overflow is flagged):
+                                              // 512 is what fits beside a stage-1 slot inside a step launch, and a stream must get the same answer -- including the
+                                              // same HD_ERR_CAPACITY -- whichever path serves it; three symbols' worth of backlog holds a dozen flip points
 
 __device__ __forceinline__ int sgnf(float v) { return (0.0f < v) - (v < 0.0f); }
 

@@ -41,16 +41,7 @@ bool tail_layout(TailArgs& a, int lanes, int ratio2, int ntaps2, uint32_t max_ta
     a.lmask_off = off; off += (ring_cap / 64) * 8;
     uint32_t fl_cap = ring_cap / (min_R ? min_R : 4u) + 2u;              // a flip point moves the search on by R
     fl_cap = (fl_cap + 63u) & ~63u;
-    // (inside a step launch LDS is a stage-1 slot: 512 flip points per call there -- three symbols' worth of backlog holds a dozen; more would be
-    // reported as an overflow, as with the 1024 of the roomier kernels)
-    // (inside a step launch LDS is a stage-1 slot with room for 512 flip points; a stream whose backlog could produce more -- a small R, i.e. a high
-    // symbol rate -- does not get the smaller list there: the layout is refused and the engine serves the call through k_tail, with the 1024 of
-    // every other path, so that the same input gives the same answer on every launch path)
-    const uint32_t fl_max = lds_limit <= 24576 ? 512u : kMaxFlipsPerCall;
-    if (fl_cap > fl_max) {
-        if (fl_max < kMaxFlipsPerCall) return false;
-        fl_cap = fl_max;
-    }
+    if (fl_cap > kMaxFlipsPerCall) fl_cap = kMaxFlipsPerCall;           // (the same bound on every path: sym_common.h)
     a.fl_cap = fl_cap;
     a.flips_off = off; off += fl_cap * 8;
     a.strips_off = off; off += (NT / 64) * kTailStrip * 4;

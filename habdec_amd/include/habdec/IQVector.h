@@ -4,6 +4,7 @@
 #pragma once
 #include <atomic>
 #include <complex>
+#include <ostream>
 #include <vector>
 
 namespace habdec {
@@ -31,5 +32,13 @@ public:
 private:
     std::atomic<double> rate_{0.0};
 };
+
+// the samples as "(re,im) (re,im) ..." (IQVector.h:67-73)
+template <typename T>
+std::ostream& operator<<(std::ostream& os, const IQVector<T>& v)
+{
+    for (const auto& z : v) os << z << " ";
+    return os;
+}
 
 }  // namespace habdec
