@@ -172,7 +172,7 @@ struct hd_engine {
         PinBuf<hd::StreamCall> h_call;
         PinBuf<uint32_t> h_slots;                 // written by the symbol scan kernel over PCIe (zero-copy), read after ev_done
         PinBuf<hd::SpectrumStatsDev> h_stats;    // written by the spectrum kernel
-        bool timed = false;                       // this call carries the timing events
+        bool timed = false, timed_step = false;   // this call carries the timing events (a step call: only the two around its one launch)
         hipEvent_t ev_front = nullptr, ev_done = nullptr, ev_params = nullptr, t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr;
         bool busy = false;
         uint64_t total_in = 0;
@@ -654,8 +654,8 @@ int collect(hd_engine* e, hd_engine::CallSlot& sl)
     sl.busy = false;
     if (sl.timed) {
         float a = 0, b = 0;
-        HD_HIP(hipEventElapsedTime(&a, sl.t0, sl.t3));
         HD_HIP(hipEventElapsedTime(&b, sl.t1, sl.t2));
+        if (sl.timed_step) a = b; else HD_HIP(hipEventElapsedTime(&a, sl.t0, sl.t3));
         e->last_timing.ms_total = a;
         e->last_timing.ms_front = b;
         e->last_timing.samples = sl.total_in;
@@ -865,7 +865,8 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     const bool lean = fuse && !e->one_stream;
     if (!lean && e->calls >= 2 && !e->one_stream) HD_HIP(hipStreamWaitEvent(qa, e->slot[(e->calls - 2) % hd_engine::kSlots].ev_done, 0));
     sl.timed = e->timing_every && (e->calls % e->timing_every) == 0;
-    if (sl.timed) HD_HIP(hipEventRecord(sl.t0, qa));
+    sl.timed_step = sl.timed && step;                       // a step call is ONE launch: two event records (each a barrier packet), not four
+    if (sl.timed && !step) HD_HIP(hipEventRecord(sl.t0, qa));
     if (lean) {
         if (e->sym_dirty && e->calls > e->delivered) { if (int rc = flush_locked(e)) return rc; }   // symbol parameters are uploaded below: nothing may still read them
     } else {
@@ -973,7 +974,6 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             if (!prev.ta.fft_tw) { if (const int r = run_spectrum(e, qa, *ps, prev.any_fft)) return r; }
             HD_HIP(hipEventRecord(ps->ev_done, qa));
         }
-        if (sl.timed) HD_HIP(hipEventRecord(sl.t3, qa));
         e->pend.valid = true; e->pend.ta = ta_step; e->pend.slot = (int)(e->calls % hd_engine::kSlots); e->pend.any_fft = any_fft;
         e->pend.r2 = (int)R2; e->pend.t2 = (int)T2; e->pend_max_taps = max_taps;
         HD_HIP(hipGetLastError());
