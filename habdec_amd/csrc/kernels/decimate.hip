@@ -756,10 +756,12 @@ bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2
     if (ntaps == T && ratio2 == D2 && ntaps2 == T2) {                                                                                 \
         const uint32_t lds = (uint32_t)ring_bytes<T>() + (n_tail ? 4u * tail_bytes : 0u);                                             \
         if (lds > 163840u) return false;                                                                                              \
-        static bool attr_set = false;                                                                                                 \
-        if (!attr_set) {                                                                                                              \
+        static bool attr_set[64] = {};                             /* per device: the attribute belongs to the function on the current device */ \
+        int dev_ = 0;                                                                                                                 \
+        if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return false;                                                \
+        if (!attr_set[dev_]) {                                                                                                        \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_cu<T, D2, T2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) return false; \
-            attr_set = true;                                                                                                          \
+            attr_set[dev_] = true;                                                                                                    \
         }                                                                                                                             \
         hipLaunchKernelGGL((k_step_cu<T, D2, T2>), dim3(n_cus > (n_streams + 3u) / 4u ? n_cus : (n_streams + 3u) / 4u), dim3(512), lds, st, ra, call, call_copy, ta, n_tail, n_streams, tail_bytes); \
         return true;                                                                                                                  \

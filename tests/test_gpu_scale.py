@@ -36,10 +36,11 @@ def headline_ring():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("shares", ["drawn", "drawn2", "fixed", "deep", "rocfft"])
+@pytest.mark.parametrize("shares", ["drawn", "drawn2", "fixed", "deep", "rocfft", "single_wave", "regs_run4"])
 def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, shares):
-    """shares: how the step launch's stage-1 workgroups get their tiles -- runs of four drawn from per-XCD counters (the default), runs of
-    two, or the fixed shares of HD_NO_CLAIM (the first call of a stream, which restarts its history, always takes fixed shares); "deep" = pipeline 2,
+    """shares: which step kernel serves the batch and how its stage-1 tiles are handed out -- k_step_cu (one workgroup per CU: LDS-DMA loader
+    waves + computing waves, runs of eight tiles drawn from per-XCD counters: the default; "regs_run4": runs of four), or the single-wave
+    k_step ("single_wave"; "drawn2": with runs of two -- HD_STEP_RUN does not reach k_step_cu) -- or the fixed shares of HD_NO_CLAIM (the first call of a stream, which restarts its history, always takes fixed shares); "deep" = pipeline 2,
     three calls undelivered in the free-running stretch."""
     import habdec_amd
     from oracle import pyoracle
@@ -49,6 +50,10 @@ def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, s
         monkeypatch.setenv("HD_NO_CLAIM", "1")
     if shares == "rocfft":                                   # the spectra as launches of their own (rocFFT + commit) instead of inside the tails
         monkeypatch.setenv("HD_ROCFFT", "1")
+    if shares == "single_wave":                              # round 2's step kernel (single-wave workgroups) instead of one workgroup per CU
+        monkeypatch.setenv("HD_NO_CU_STEP", "1")
+    if shares == "regs_run4":                                # k_step_cu with four-tile runs (more run changes, more halo rows out of the history path)
+        monkeypatch.setenv("HD_RING_RUN", "4")
     w, ring, ring_chunks = headline_ring
     S, fs = w["S"], w["fs"]
     # 7/8 of the streams are within +-200 Hz, every 8th is far off: sample both kinds (and the first / last stream of XCD blocks)
@@ -94,6 +99,8 @@ def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, s
             want[k][s] = (len(d), int(d.sum() & 0xFFFFFFFF), int((d * np.arange(1, len(d) + 1, dtype=np.uint64)).sum() & 0xFFFFFFFF))
         compare_delivered()
     assert eng.timing()["path"] == 3
+    # which step kernel: one workgroup per CU (loader + computing waves, stage1_ring.h) unless switched off or the runs are not drawn
+    assert eng.timing()["step_variant"] == (0 if shares in ("fixed", "single_wave") else 1), shares
     in_launch = min(len(v) for v in seen.values())           # calls whose tails rode in a step launch and were compared before the final flush
     assert in_launch >= n_free - 4, in_launch
     eng.flush()
@@ -240,6 +247,35 @@ def test_two_engines_in_one_process_on_two_threads():
             t.join()
         assert threaded == serial
         assert all(len(x[1]) >= 1 for x in serial[0][0])          # (sentences were decoded at all)
+
+
+def test_one_engine_per_device_in_one_process():
+    """SURVEY section 8(e) as it is written: one engine + host thread PER DEVICE in one process (bench.py's N-GPU driver is one process per GPU).
+    Needs two visible GPUs; the boxes the suite usually runs on have one, where this is skipped."""
+    torch = pytest.importorskip("torch")
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible GPU")
+    import habdec_amd
+    fs, S = 2.048e6, 16
+    texts = [synth.make_sentence(f"DEV{s}", f"{s},52.{s},21.0") * 2 for s in range(S)]
+    nchunks = int(np.ceil((max(len(t) for t in texts) * 11 + 40) * fs / 300 / C)) + 1
+    iq = np.stack([synth.fsk_iq(synth.rtty_bits(texts[s], 8, 2, 6 + s, 10), fs, 300, sigma=0.08, seed=500 + s, n_samples=nchunks * C) for s in range(S)])
+    out = {}
+
+    def run(dev):
+        eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=64, device=dev, pipeline=1)
+        for k in range(nchunks):
+            eng.process_host(np.ascontiguousarray(iq[:, k * C:(k + 1) * C]))
+        eng.flush()
+        out[dev] = [(eng.take_chars(s), eng.take_sentences(s), eng.rtty(s), eng.demodulated(s).tobytes()) for s in range(S)]
+        eng.close()
+
+    th = [threading.Thread(target=run, args=(d,)) for d in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert out[0] == out[1] and all(len(x[1]) >= 1 for x in out[0])
 
 
 @pytest.mark.parametrize("pipeline", [False, True])
