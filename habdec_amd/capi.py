@@ -33,6 +33,7 @@ class hd_timing(C.Structure):
 
 
 SENTENCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p)
+MATCH_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int)
 CHARS_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.POINTER(C.c_char), C.c_size_t)
 
 _vp, _u32, _sz, _dbl, _int, _f = C.c_void_p, C.c_uint32, C.c_size_t, C.c_double, C.c_int, C.c_float
@@ -56,6 +57,7 @@ ENGINE_API = {
     "hd_stream_set_dc_remove": (_int, [_vp, _u32, _int]),
     "hd_stream_reset_frequency_correction": (_int, [_vp, _u32, _dbl]),
     "hd_set_sentence_callback": (None, [_vp, SENTENCE_CB, _vp]),
+    "hd_set_match_callback": (None, [_vp, MATCH_CB, _vp]),
     "hd_set_chars_callback": (None, [_vp, CHARS_CB, _vp]),
     "hd_process_host": (_int, [_vp, _vp, _sz, _vp, _u32]),
     "hd_process_device": (_int, [_vp, _vp, _sz, _vp, _u32]),

@@ -190,6 +190,7 @@ struct hd_engine {
     std::recursive_mutex mtx;   // recursive: a sentence / character callback (fired under it, on the calling thread) may call the text getters
     bool in_callback = false;   // ... but not the data getters that would have to flush the pipeline from inside a delivery
     hd_sentence_cb sentence_cb = nullptr; void* sentence_user = nullptr;
+    hd_match_cb match_cb = nullptr; void* match_user = nullptr;
     hd_chars_cb chars_cb = nullptr; void* chars_user = nullptr;
     uint64_t sentences_ok = 0;
 
@@ -530,6 +531,7 @@ extern "C" int hd_debug_step_counters(hd_engine* e, unsigned int* out32)
 }
 
 void hd_set_sentence_callback(hd_engine* e, hd_sentence_cb cb, void* user) { if (e) { e->sentence_cb = cb; e->sentence_user = user; } }
+void hd_set_match_callback(hd_engine* e, hd_match_cb cb, void* user) { if (e) { e->match_cb = cb; e->match_user = user; } }
 void hd_set_chars_callback(hd_engine* e, hd_chars_cb cb, void* user) { if (e) { e->chars_cb = cb; e->chars_user = user; } }
 
 /* ---------------------------------------------------------------- control plane -------------------------------- */
@@ -695,6 +697,8 @@ int collect(hd_engine* e, hd_engine::CallSlot& sl)
         const std::string chars = st.text.run(hdr->nbits != 0, [&](const hd::SentenceMatch& m) {
             ++e->sentences_ok;
             if (e->sentence_cb) { e->in_callback = true; e->sentence_cb(e->sentence_user, s, m.callsign.c_str(), m.data.c_str(), m.crc.c_str()); e->in_callback = false; }
+        }, [&](const hd::SentenceMatch& m, bool ok) {
+            if (e->match_cb) { e->in_callback = true; e->match_cb(e->match_user, s, m.callsign.c_str(), m.data.c_str(), m.crc.c_str(), ok ? 1 : 0); e->in_callback = false; }
         });
         if (!chars.empty() && e->chars_cb) { e->in_callback = true; e->chars_cb(e->chars_user, s, chars.data(), chars.size()); e->in_callback = false; }
     }

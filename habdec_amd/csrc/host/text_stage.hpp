@@ -22,8 +22,10 @@ struct TextStage {
     uint64_t ok_count = 0;
 
     // `bits` of this call have already been pushed into `framer`.  Returns the printable chars of this call.
-    template <typename OnSentence>
-    std::string run(bool had_bits, OnSentence&& on_sentence)
+    // on_match: every sentence the scan finds, with the verdict of its CRC (what the reference prints, Decoder.h:601); on_sentence: those whose
+    // CRC16 matches (Decoder.h:604-606).
+    template <typename OnSentence, typename OnMatch>
+    std::string run(bool had_bits, OnSentence&& on_sentence, OnMatch&& on_match)
     {
         std::string raw;
         if (had_bits) framer.frame(raw);
@@ -39,7 +41,9 @@ struct TextStage {
                 stream = m.rest;
                 last_sentence = m.callsign + "," + m.data + "*" + m.crc;
                 match_log += last_sentence + "\n";
-                if (m.crc == crc16_ccitt_hex(m.callsign + "," + m.data)) {
+                const bool ok = m.crc == crc16_ccitt_hex(m.callsign + "," + m.data);
+                on_match(m, ok);
+                if (ok) {
                     ok_log += last_sentence + "\n";
                     ++ok_count;
                     on_sentence(m);
@@ -49,6 +53,8 @@ struct TextStage {
         if (stream.size() > 1000) stream.erase(0, stream.rfind('$'));
         return printable;
     }
+    template <typename OnSentence>
+    std::string run(bool had_bits, OnSentence&& on_sentence) { return run(had_bits, on_sentence, [](const SentenceMatch&, bool) {}); }
 };
 
 }  // namespace hd

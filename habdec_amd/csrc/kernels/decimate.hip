@@ -594,8 +594,23 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
     const uint32_t simd = (__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4)) & 3u;                    // HW_ID.SIMD_ID
     uint32_t rank = 0;
     if ((threadIdx.x & 63u) == 0) rank = __hip_atomic_fetch_add(&ctl->simd_rank[simd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)rank) & 1u;
-    const uint32_t w = simd < 2u ? (rank ? 2u + simd : simd) : 4u + 2u * (simd - 2u) + rank;               // 0-1 loaders, 2-3 computing, 4-7 tails
+    rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)rank);
+    uint32_t w = simd < 2u ? (rank ? 2u + simd : simd) : 4u + 2u * (simd - 2u) + rank;                     // 0-1 loaders, 2-3 computing, 4-7 tails
+    // (Two per SIMD is what the register budget gives today; should a build ever fit a third wave on a SIMD, that wave takes one of the roles
+    // nobody claimed -- every role must be filled exactly once, whatever the placement.)
+    if (rank < 2u && (threadIdx.x & 63u) == 0) (void)__hip_atomic_fetch_or(&ctl->roles_taken, 1u << w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    if (rank >= 2u) {
+        uint32_t pick = 0;
+        if ((threadIdx.x & 63u) == 0) {
+            for (;;) {                                                       // claim the lowest role still free
+                const uint32_t taken = __hip_atomic_load(&ctl->roles_taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pick = (uint32_t)__builtin_ctz(~taken);
+                if (!(__hip_atomic_fetch_or(&ctl->roles_taken, 1u << pick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & (1u << pick))) break;
+            }
+        }
+        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)pick);
+    }
 #else
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #endif
@@ -609,7 +624,7 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
         ring_loader_regs<T>(ra, ring, ctl, w);       // (the same tiles staged through the loader's registers: measured equal, kept for A/B)
 #endif
     } else if (w < 4) {
-        ring_consumer<T>(ra, ring, ctl, w == 2);
+        ring_consumer<T>(ra, ring, ctl, w == 2, w);
     } else {
         __builtin_amdgcn_s_setprio(HD_STEP_PRIO);
         const uint32_t k = w - 4u, lane = threadIdx.x & 63u;
@@ -621,7 +636,7 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
         }
 #ifndef HD_CU_NO_LATE_CONSUMERS
         __builtin_amdgcn_s_setprio(0);
-        ring_consumer<T>(ra, ring, ctl, false);                          // the tail is done: one more wave for the tap loops
+        ring_consumer<T>(ra, ring, ctl, false, w);                       // the tail is done: one more wave for the tap loops
 #endif
     }
 }

@@ -75,6 +75,7 @@ struct RingCtl {
     uint32_t slot_done[8];  // per slot NSL L + l % NSL: 1 + l of the tile last finished in it
     uint4 desc[8];          // per slot: stream, tile
     uint32_t simd_rank[4];  // waves of the workgroup that have arrived on each SIMD (role assignment, k_step_cu)
+    uint32_t roles_taken;   // bit w: role w has a wave
 };
 static_assert(sizeof(RingCtl) <= kRingCtlBytes, "ring control block");
 
@@ -426,7 +427,8 @@ __device__ __forceinline__ void ring_mac16_asm(r_f32x2& acc, const r_f32x4 (&x)[
 }
 
 template <int T>
-__device__ __forceinline__ void ring_consumer(const RingArgs& a, const unsigned char* __restrict__ ring, RingCtl* __restrict__ ctl, const bool feeder)
+__device__ __forceinline__ void ring_consumer(const RingArgs& a, const unsigned char* __restrict__ ring, RingCtl* __restrict__ ctl, const bool feeder,
+                                              const uint32_t role /* the wave's role number in the workgroup (diagnostic builds: its row in the stamp table) */)
 {
     constexpr int HR = ring_halo_rows<T>();
     constexpr int SLOT = ring_slot_bytes<T>();
@@ -440,7 +442,7 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const unsigned 
     auto coff = [](int c) { return (c >> 1) * kRingRowBytes + (c & 1) * 128; };
     RSTAMP_DECL;
     uint32_t n_done = 0;
-    const uint32_t my_wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t my_wave = role; (void)my_wave;
     // The feeding consumer also draws the runs for both loaders from this XCD's counter (StepClaim, launch.h) -- a returning atomic the
     // compiler counts and waits for, which a wave without DMA in flight can afford -- and keeps two of them ready in ctl->run_q.
     bool feeding = feeder;

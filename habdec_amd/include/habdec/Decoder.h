@@ -9,7 +9,7 @@
 //                  spectrum, AFC reductions, low-pass FIR, discriminator, symbol extractor on the GPU; AFC state
 //                  machine, RTTY framing, sentence scan, CRC on the host; callbacks fire before process() returns.
 // Differences from the reference, all outside the decoded data: no SSDV image side-channel (ssdv_callback_ never fires;
-// the fsphil/ssdv sources are not part of the reference checkout), sentences are printed without the OK/ERR tally, and
+// the fsphil/ssdv sources are not part of the reference checkout), and
 // changing the decimation factor or the sampling rate after data has flowed restarts the stream state.
 #pragma once
 
@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <iomanip>
 #include <iostream>
 #include <mutex>
 #include <string>
@@ -219,8 +220,23 @@ private:
     static void on_sentence(void* self, uint32_t, const char* call, const char* data, const char* crc)
     {
         auto* d = static_cast<Decoder*>(self);
-        std::cout << call << "," << data << "*" << crc << std::endl;     // the reference prints every matched sentence
         if (d->events_) d->events_->push_back(Event{call, data, crc});   // delivered by process() once its lock is released
+    }
+    // What the reference writes to stdout for EVERY sentence its scan finds, CRC-valid or not (Decoder.h:601 -> printHabhubSentence,
+    // print_habhub_sentence.cpp:33-62, then `cout<<endl`): the line in magenta + " OK" or red + " ERR", and a running tally whose counters
+    // are function-local statics there -- shared by all decoders of the process -- and are so here.
+    static void on_match(void*, uint32_t, const char* call, const char* data, const char* crc, int crc_ok)
+    {
+        static int success = 0, failure = 0;
+#ifdef __linux__
+        const char *magenta = "\033[1;35m", *red = "\033[1;31m", *off = "\033[0m", *clear = "\033[2K";
+#else
+        const char *magenta = "", *red = "", *off = "", *clear = "";
+#endif
+        std::cout << clear << '\r' << "" << (crc_ok ? magenta : red) << call << "," << data << "*" << crc << (crc_ok ? " OK" : " ERR") << off;
+        ++(crc_ok ? success : failure);
+        std::cout << "\t\tOK:" << success << "  ERR:" << failure << "  Ratio:" << std::setprecision(2) << (float(success) / (success + failure));
+        std::cout << std::endl;
     }
     static void on_chars(void* self, uint32_t, const char* chars, size_t n)
     {
@@ -248,6 +264,7 @@ private:
         c.lowpass_bw_hz = lowpass_bw_; c.lowpass_trans = lowpass_trans_; c.dc_remove = dc_remove_;
         if (hd_engine_create(&c, &engine_) != HD_OK) { std::cout << "habdec_amd: " << hd_last_error() << std::endl; engine_ = nullptr; return false; }
         hd_set_sentence_callback(engine_, &Decoder::on_sentence, this);
+        hd_set_match_callback(engine_, &Decoder::on_match, this);
         hd_set_chars_callback(engine_, &Decoder::on_chars, this);
         return true;
     }

@@ -103,6 +103,10 @@ int hd_stream_reset_frequency_correction(hd_engine* e, uint32_t stream, double c
 typedef void (*hd_sentence_cb)(void* user, uint32_t stream, const char* callsign, const char* data, const char* crc);
 typedef void (*hd_chars_cb)(void* user, uint32_t stream, const char* chars, size_t n);
 void hd_set_sentence_callback(hd_engine* e, hd_sentence_cb cb, void* user);   /* fires only on CRC match */
+/* every sentence the scan finds, CRC-valid or not, in the order found and before the sentence callback of the same sentence: the point at which
+ * the reference prints "<sentence> OK|ERR" and its running tally (Decoder.h:601 -> print_habhub_sentence.cpp:33-62) */
+typedef void (*hd_match_cb)(void* user, uint32_t stream, const char* callsign, const char* data, const char* crc, int crc_ok);
+void hd_set_match_callback(hd_engine* e, hd_match_cb cb, void* user);
 void hd_set_chars_callback(hd_engine* e, hd_chars_cb cb, void* user);         /* printable chars of this call */
 
 /* ---- data path: pushSamples() + operator()() (Decoder.h:206-219, 416-638) for all S streams ----

@@ -37,6 +37,16 @@ def test_decoder_facade_on_iq_file(tmp_path, fs, dec, baud, bits, stops, lowpass
     assert got_sent == o.sentences() and len(got_sent) >= 1
     assert got_rtty == o.text("rtty_stream").replace("\n", "\n").split("\n")[0] or got_rtty.startswith(o.text("rtty_stream").split("\n")[0])
     assert got_last == o.text("last_sentence")
+    # stdout carries what the reference prints for every sentence its scan finds (Decoder.h:601 -> print_habhub_sentence.cpp:33-62): the line in
+    # colour with its CRC verdict and the running OK / ERR tally
+    matches = [m for m in o.text("match_log").split("\n") if m]
+    ok = 0
+    for m in matches:
+        good = m in o.sentences()
+        ok += good
+        # (the line opens with "\x1b[2K\r"; text mode hands the carriage return over as a newline, so the part behind it is compared)
+        want = ("\x1b[1;35m" if good else "\x1b[1;31m") + m + (" OK" if good else " ERR") + "\x1b[0m\t\tOK:" + str(ok) + "  ERR:"
+        assert want in out.stdout and "\x1b[2K" in out.stdout, (m, good)
     info = [l for l in lines if l.startswith("INFO ")][-1]
     assert f"dec={1 << dec} " in info and "bins=4096" in info and f"samples={len(iq)} " in info
     # every sentence callback asked the decoder for getLastSentence()/getRTTY() from inside the callback (no deadlock, right answers)
