@@ -1,5 +1,6 @@
+"""Quick parity check of the batch path on the GPU box: S streams of noise through three pipelined calls, decimated output of sampled streams bit for bit\nagainst the CPU oracle, with the ranges that differ (which stage-1 tiles are wrong) printed.  S=64 python tools/micro/quick_parity.py"""
 import sys, os
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import habdec_amd
 from oracle import pyoracle
