@@ -182,6 +182,7 @@ def physical_cores():
 STAGE1 = {64: "k_decimate<32,212,64>", 16: "k_decimate<8,54,256>", 4: "k_decimate<4,139,256>", 256: "k_decimate<64,348,64>"}
 STEP = {64: "k_step<32,212,2,69>", 256: "k_step<64,348,4,139>"}
 STEP_CU = {64: "k_step_cu<212,2,69>", 128: "k_step_cu<174,4,139>"}     # one workgroup per CU: loader + computing waves for stage 1, the tails in the others
+STAGE1_CU = {64: "k_stage1_cu<212>", 128: "k_stage1_cu<174>"}           # stage 1 alone in that shape (eight tile slots, six computing waves)
 PATHS = {0: "separate kernels", 1: "fused back end", 2: "stream tail kernel", 3: "step kernel (stage 1 + previous call's stream tails)"}
 
 
@@ -248,17 +249,19 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     if path == 3:
         kernel, alg_bytes = (STEP_CU if tm.get("step_variant") == 1 else STEP).get(w["D"], "k_step"), int(S * C * bytes_per_sample(w["D"]))
     else:
-        kernel, alg_bytes = STAGE1.get(w["D"], "k_decimate"), int(front_bytes)
+        kernel, alg_bytes = (STAGE1_CU if tm.get("step_variant") == 1 else STAGE1).get(w["D"], "k_decimate"), int(front_bytes)
     achieved = alg_bytes / (avg_front_ms * 1e-3) / 1e9
     traffic, prof = None, {}
     tf = ROOT / "profiles" / "traffic.json"
     if tf.exists():
         try:
-            prof = json.loads(tf.read_text()).get(name, {})
+            prof = json.loads(tf.read_text()).get(name + ("_sync" if sync else ""), {})
             traffic = prof.get("front_kernel_hbm_bytes_per_launch")
         except Exception:
             traffic, prof = None, {}
-    if prof.get("rocprof_avg_launch_ms") and prof.get("front_kernel") == kernel.replace(" ", ""):
+    if prof.get("front_kernel") != kernel.replace(" ", ""):
+        traffic, prof = None, {}                               # (the committed profile is of another kernel: say nothing rather than the wrong thing)
+    if prof.get("rocprof_avg_launch_ms"):
         # the committed rocprofv3 --kernel-trace --stats summary of the same command (tools/collect_profiles.py): the live figure must agree with it
         rp = {"rocprof_avg_launch_ms": prof["rocprof_avg_launch_ms"], "rocprof_launches": prof.get("rocprof_launches"), "rocprof_source": prof.get("stats_source")}
     else:
@@ -306,12 +309,12 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
             eng1.process_device(base + (i % ring_chunks) * S * C * 8, C, C)
             if i >= 4:
                 iso.append(eng1.timing()["ms_front"])
-        iso_bytes = eng1.timing()["front_bytes"]
+        iso_bytes, iso_cu = eng1.timing()["front_bytes"], eng1.timing().get("step_variant") == 1
         eng1.close()
         iso_ms = float(np.mean(iso))
         iso_bw = iso_bytes / (iso_ms * 1e-3) / 1e9
         tgt = res["roofline"] if not valu else res["roofline"]["stage1_hbm"]
-        tgt["isolated"] = {"kernel": STAGE1.get(w["D"], "k_decimate"), "algorithmic_bytes_per_launch": int(iso_bytes), "avg_launch_ms": round(iso_ms, 5),
+        tgt["isolated"] = {"kernel": (STAGE1_CU if iso_cu else STAGE1).get(w["D"], "k_decimate"), "algorithmic_bytes_per_launch": int(iso_bytes), "avg_launch_ms": round(iso_ms, 5),
                            "achieved": round(iso_bw, 1), "frac": round(iso_bw / HBM_PEAK_GBS, 4),
                            "frac_of_measured_copy_peak": round(iso_bw / HBM_COPY_GBS, 4),
                            "note": "stage 1 alone: synchronous calls (nothing else on the GPU), 24 launches after the timed region"}

@@ -1010,8 +1010,24 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         const uint32_t lin1 = (min_in == max_in && max_in) ? e->dec_wgs_per_cu * (e->qa_cus ? e->qa_cus : e->n_cus) : 0u;
         // (Stage 1 alone is HBM-bound: drawing runs costs it ~3 % -- more halo re-reads, 588 vs 576 MB per launch -- where the step launch gains
         // 4 %; measured on one box, alternating.  HD_CLAIM_ALONE=1 turns it on for experiments.)
-        const hd::StepClaim claim1 = (single || !lin1 || !e->claim_alone) ? hd::StepClaim{} : make_claim(lin1);
-        if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
+        // A /32 first stage over equally sized pushes: one workgroup per CU, LDS-DMA loader waves + computing waves (k_stage1_cu, stage1_ring.h)
+        bool s1_cu = false;
+        if (!single && lin1 && !e->no_cu_step && R1 == 32 && !any_zero1 && max_in % 2048u == 0 && hd::step_cu_tail_lds((int)R1, (int)T1)) {
+            const uint32_t ntiles1 = (max_n1 + 63) / 64;
+            uint32_t ring_run = e->ring_run >= 2 ? e->ring_run : 8u;
+            while (ring_run > 2 && (ntiles1 % ring_run || ((uint64_t)S * ntiles1 / ring_run) % (e->n_cus / 32u ? e->n_cus / 32u : 1u))) ring_run >>= 1;
+            const hd::StepClaim cl = make_claim(0, ring_run);
+            if (cl.ctr) {
+                if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
+                s1_cu = hd::launch_stage1_cu(qa, (int)R1, (int)T1, e->n_cus, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
+                                             max_in, cl, e->ring_gave_up.dev);
+                if (!s1_cu) --e->step_launches;                // (the counter sets alternate per launch that really draws: this one did not)
+            }
+        }
+        e->last_timing.step_variant = s1_cu ? 1u : 0u;
+        const hd::StepClaim claim1 = (s1_cu || single || !lin1 || !e->claim_alone) ? hd::StepClaim{} : make_claim(lin1);
+        if (sl.timed && !s1_cu) HD_HIP(hipEventRecord(sl.t1, qa));
+        if (!s1_cu)
         if (!hd::launch_decimate(qa, R1, T1, S, max_n1, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
                                  lean ? sl.h_call.dev : dcall, 0, single ? 1 : 0, e->fir_hist_cap, single ? feed : nullptr, lin1,
                                  nullptr, claim1.ctr ? max_in : 0u, claim1))

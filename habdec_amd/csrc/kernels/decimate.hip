@@ -582,7 +582,7 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char cu_lds[];
     unsigned char* ring = cu_lds;
-    RingCtl* ctl = reinterpret_cast<RingCtl*>(cu_lds + kRingSlots * ring_slot_bytes<T>());
+    RingCtl* ctl = reinterpret_cast<RingCtl*>(cu_lds + 2 * kRingNSL * ring_slot_bytes<T>());
     unsigned char* tails = cu_lds + ring_bytes<T>();
     if (threadIdx.x < kRingCtlBytes / 4) reinterpret_cast<uint32_t*>(ctl)[threadIdx.x] = (threadIdx.x == 2 || threadIdx.x == 3) ? 0xFFFFFFFFu : 0u;   // end[] = "not known yet"
     __syncthreads();
@@ -639,6 +639,40 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
         ring_consumer<T>(ra, ring, ctl, false, w);                       // the tail is done: one more wave for the tap loops
 #endif
     }
+}
+
+// Stage 1 ALONE in the same shape (synchronous delivery, the first half of a call whose tails run as a launch of their own): one
+// workgroup per CU, two LDS-DMA loader waves with four tile slots each -- without tails in the CU's LDS there is room for eight --
+// and six computing waves.  512 MiB of IQ in 104-108 us where the single-wave grid (k_decimate<32,212,64>) takes 118-123.
+template <int T>
+__global__ __launch_bounds__(512) void k_stage1_cu(const RingArgs ra)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char cu_lds[];
+    unsigned char* ring = cu_lds;
+    RingCtl* ctl = reinterpret_cast<RingCtl*>(cu_lds + 2 * kRingNSLAlone * ring_slot_bytes<T>());
+    if (threadIdx.x < kRingCtlBytes / 4) reinterpret_cast<uint32_t*>(ctl)[threadIdx.x] = (threadIdx.x == 2 || threadIdx.x == 3) ? 0xFFFFFFFFu : 0u;
+    __syncthreads();
+    // one loader per SIMD pair, the first computing wave beside a loader feeds the runs (roles as in k_step_cu; any placement fills every role)
+    const uint32_t simd = (__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4)) & 3u;
+    uint32_t rank = 0;
+    if ((threadIdx.x & 63u) == 0) rank = __hip_atomic_fetch_add(&ctl->simd_rank[simd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)rank);
+    uint32_t w = simd < 2u ? (rank ? 2u + simd : simd) : 4u + 2u * (simd - 2u) + rank;
+    if (rank < 2u && (threadIdx.x & 63u) == 0) (void)__hip_atomic_fetch_or(&ctl->roles_taken, 1u << w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    if (rank >= 2u) {
+        uint32_t pick = 0;
+        if ((threadIdx.x & 63u) == 0) {
+            for (;;) {
+                const uint32_t taken = __hip_atomic_load(&ctl->roles_taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pick = (uint32_t)__builtin_ctz(~taken);
+                if (!(__hip_atomic_fetch_or(&ctl->roles_taken, 1u << pick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & (1u << pick))) break;
+            }
+        }
+        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)pick);
+    }
+    if (w < 2) ring_loader<T, kRingNSLAlone>(ra, ring, ctl, w);
+    else ring_consumer<T, kRingNSLAlone>(ra, ring, ctl, w == 2, w);
 }
 
 // XCC ids seen by a grid of single-wave workgroups: the run counters of the step launches are per XCD and indexed by the hardware's id
@@ -783,6 +817,30 @@ bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2
     }
     HD_CU_CASE(212, 2, 69) HD_CU_CASE(174, 4, 139)
 #undef HD_CU_CASE
+    return false;
+}
+
+bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, const float2* in, size_t in_stride, const float2* hist_in, float2* hist_out,
+                      const float* taps, float2* out, size_t out_stride, uint32_t uniform_n, const StepClaim& claim, unsigned int* gave_up)
+{
+    if (ratio != 32 || !claim.ctr || !uniform_n || uniform_n % 2048u) return false;
+    RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, uniform_n / 2048u, claim, gave_up};
+#define HD_S1_CASE(T)                                                                                                                 \
+    if (ntaps == T) {                                                                                                                 \
+        constexpr uint32_t lds = (uint32_t)ring_bytes<T, kRingNSLAlone>();                                                            \
+        static_assert(lds <= 163840u, "eight tile slots must fit a CU's LDS");                                                        \
+        static bool attr_set[64] = {};                                                                                                \
+        int dev_ = 0;                                                                                                                 \
+        if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return false;                                                \
+        if (!attr_set[dev_]) {                                                                                                        \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_stage1_cu<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) return false; \
+            attr_set[dev_] = true;                                                                                                    \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((k_stage1_cu<T>), dim3(n_cus), dim3(512), lds, st, ra);                                                    \
+        return true;                                                                                                                  \
+    }
+    HD_S1_CASE(212) HD_S1_CASE(174)
+#undef HD_S1_CASE
     return false;
 }
 

@@ -43,13 +43,13 @@ constexpr int kRingRowBytes = 272;                  // 32 samples + one 16-byte 
 #ifndef HD_RING_NSL
 #define HD_RING_NSL 2
 #endif
-constexpr int kRingNSL = HD_RING_NSL;                 // tile slots per loader wave
-constexpr int kRingSlots = 2 * kRingNSL;
+constexpr int kRingNSL = HD_RING_NSL;                 // tile slots per loader wave in a step launch (beside four stream tails: what fits)
+constexpr int kRingNSLAlone = 4;                      // ... when stage 1 has the CU to itself (k_stage1_cu)
 constexpr int kRingCtlBytes = 256;
 constexpr uint32_t kRingSpinLimit = 1u << 22;   // polls before a waiting wave gives up (seconds; a correct run waits microseconds)
 template <int T> constexpr int ring_halo_rows() { return (T - 1 + 31) / 32; }
 template <int T> constexpr int ring_slot_bytes() { return (64 + ring_halo_rows<T>()) * kRingRowBytes; }
-template <int T> constexpr int ring_bytes() { return kRingSlots * ring_slot_bytes<T>() + kRingCtlBytes; }
+template <int T, int NSL = kRingNSL> constexpr int ring_bytes() { return 2 * NSL * ring_slot_bytes<T>() + kRingCtlBytes; }
 
 #ifdef HD_STAMP_RING   // diagnostic build only (tools/micro/ring_stamps.py): where the loader and the consumers of k_step_cu spend their cycles
 __device__ unsigned long long g_ring_stamps[512 * 8 * 8];
@@ -158,7 +158,7 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p)
 }
 
 // ---------------------------------------------------------------------------------------------------------------- a loader wave
-template <int T>
+template <int T, int NSL = kRingNSL>
 __device__ __forceinline__ void ring_loader(const RingArgs& a, unsigned char* __restrict__ ring, RingCtl* __restrict__ ctl, const uint32_t L)
 {
     constexpr int HR = ring_halo_rows<T>();
@@ -166,7 +166,7 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, unsigned char* __
     constexpr int NBODY = 17;                       // 64 rows x 17 chunks = 17 x 64 chunks
     constexpr int NHALO = (HR * 17 + 63) / 64;      // halo rows out of the stream itself (every tile but a stream's first)
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t ring_lds = lds_addr_of(ring) + (uint32_t)kRingNSL * L * (uint32_t)SLOT;
+    const uint32_t ring_lds = lds_addr_of(ring) + (uint32_t)NSL * L * (uint32_t)SLOT;
 
     // per-lane source offsets (bytes from the tile's first body row / first halo row)
     uint32_t boff[NBODY], hoff[NHALO], hist_off[HR];
@@ -192,20 +192,23 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, unsigned char* __
     bool have = false, ended = false, claimed = false;
     uint32_t s = 0, tile = 0, left = 0, my_run = 0;
     uint32_t issued = 0, landed = 0;                // my tiles
-    uint32_t cnt_new = 0;                           // vector-memory instructions of the newer of two tiles in flight (0: at most one in flight)
+    uint32_t inflight_instr = 0;                    // vector-memory instructions of my tiles in flight (at most three tiles: the counter holds 63)
+    unsigned long long fifo = 0;                    // ... per tile, oldest in the low byte
+    constexpr uint32_t kMaxFly = NSL >= 3 ? 3u : 2u;
     uint32_t idle_spins = 0;
     RSTAMP_DECL;
 
     for (;;) {
         RSTAMP(0);
         // ---- publish what has landed, without blocking: the wave's count of outstanding vector-memory instructions is readable
-        // (IB_STS.VM_CNT, low four bits in [3:0], high two in [23:22]); the older tile in flight has landed once no more than the
+        // (IB_STS.VM_CNT, low four bits in [3:0], high two in [23:22]); the oldest tile in flight has landed once no more than the
         // instructions issued after it are outstanding.
         while (issued != landed) {
             const uint32_t ib = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 7);
-            if (((ib & 15u) | (((ib >> 22) & 3u) << 4)) > cnt_new) break;
-            wait_vmcnt(cnt_new);                                       // (returns at once; an ordering point for the compiler)
-            cnt_new = 0;                                               // (what was the newer tile is now the only one in flight)
+            const uint32_t oldest = (uint32_t)(fifo & 0xFFu), younger = inflight_instr - oldest;
+            if (((ib & 15u) | (((ib >> 22) & 3u) << 4)) > younger) break;
+            wait_vmcnt(younger);                                       // (returns at once; an ordering point for the compiler)
+            inflight_instr -= oldest; fifo >>= 8;
             ++landed;
             if (lane == 0) __hip_atomic_store(&ctl->landed[L], landed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -230,16 +233,16 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, unsigned char* __
                 }
             }
         }
-        bool can = have && issued - landed < 2u;
-        if (can && issued >= (uint32_t)kRingNSL) {                     // my slot issued % NSL held tile issued - NSL: is its consumer finished?
-            const uint32_t dn = __hip_atomic_load(&ctl->slot_done[(uint32_t)kRingNSL * L + issued % (uint32_t)kRingNSL], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            can = dn == issued - (uint32_t)kRingNSL + 1u;
+        bool can = have && issued - landed < kMaxFly && inflight_instr + (uint32_t)(NBODY + (HR > NHALO ? HR : NHALO)) <= 63u;
+        if (can && issued >= (uint32_t)NSL) {                     // my slot issued % NSL held tile issued - NSL: is its consumer finished?
+            const uint32_t dn = __hip_atomic_load(&ctl->slot_done[(uint32_t)NSL * L + issued % (uint32_t)NSL], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            can = dn == issued - (uint32_t)NSL + 1u;
         }
         if (can) {
-            const uint32_t slot = issued % (uint32_t)kRingNSL;
+            const uint32_t slot = issued % (uint32_t)NSL;
             const uint32_t dst = ring_lds + slot * (uint32_t)SLOT;
             const unsigned char* body = reinterpret_cast<const unsigned char*>(a.in + (size_t)s * a.in_stride) + (size_t)tile * (64u * 256u);
-            if (lane == 0) ctl->desc[(uint32_t)kRingNSL * L + slot] = make_uint4(s, tile, 0u, 0u);
+            if (lane == 0) ctl->desc[(uint32_t)NSL * L + slot] = make_uint4(s, tile, 0u, 0u);
             uint32_t cnt = NBODY;
             if (tile == 0) {
                 const unsigned char* hb = reinterpret_cast<const unsigned char*>(a.hist_in + (size_t)s * (T - 1));
@@ -254,7 +257,8 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, unsigned char* __
                 cnt += NHALO;
             }
             glds16_x17(body, boff, dst + (uint32_t)(HR * kRingRowBytes));
-            cnt_new = issued == landed ? 0u : cnt;                     // instructions younger than the older tile in flight
+            fifo |= (unsigned long long)cnt << (8u * (issued - landed));
+            inflight_instr += cnt;
             ++issued;
             ++tile; --left;
             if (!left) have = false;
@@ -280,7 +284,7 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, unsigned char* __
 // in REGISTERS instead -- a loader wave has 256 of them and no other use for them: three tiles of 18 sixteen-byte loads per lane -- and copies a
 // tile into its LDS slot (ds_write_b128, the padded layout) only when the tile has arrived AND the slot is free.  The slots then hold only
 // tiles that are being summed or are ready to be; what is in flight costs no LDS at all.  Plain loads: the compiler counts them.
-template <int T>
+template <int T, int NSL = kRingNSL>
 __device__ __forceinline__ void ring_loader_regs(const RingArgs& a, unsigned char* __restrict__ ring, RingCtl* __restrict__ ctl, const uint32_t L)
 {
     constexpr int HR = ring_halo_rows<T>();
@@ -288,7 +292,7 @@ __device__ __forceinline__ void ring_loader_regs(const RingArgs& a, unsigned cha
     constexpr int NCH = (64 + HR) * 16;             // sixteen-byte chunks of a tile, halo rows first
     constexpr int NV = (NCH + 63) / 64;             // loads per lane
     const uint32_t lane = threadIdx.x & 63u;
-    unsigned char* my_slots = ring + (uint32_t)kRingNSL * L * (uint32_t)SLOT;
+    unsigned char* my_slots = ring + (uint32_t)NSL * L * (uint32_t)SLOT;
     const uint32_t xcd0 = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // XCC_ID
     const uint32_t xcd = xcd0 < a.claim.n_xcd ? xcd0 : a.claim.n_xcd - 1;
     const uint32_t runs = a.claim.runs_per_xcd, run_len = a.claim.run_len;
@@ -345,11 +349,11 @@ __device__ __forceinline__ void ring_loader_regs(const RingArgs& a, unsigned cha
         }
     };
     auto stash = [&](const float4 (&r)[NV], const Desc& d) {           // my next slot: wait until it is free, copy, publish
-        const uint32_t slot = landed % (uint32_t)kRingNSL;
-        if (landed >= (uint32_t)kRingNSL)
+        const uint32_t slot = landed % (uint32_t)NSL;
+        if (landed >= (uint32_t)NSL)
             for (uint32_t spin = 0;; ++spin) {
-                const uint32_t dn = __hip_atomic_load(&ctl->slot_done[(uint32_t)kRingNSL * L + slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (dn == landed - (uint32_t)kRingNSL + 1u) break;
+                const uint32_t dn = __hip_atomic_load(&ctl->slot_done[(uint32_t)NSL * L + slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (dn == landed - (uint32_t)NSL + 1u) break;
                 if (spin > kRingSpinLimit) { if (lane == 0) (void)__hip_atomic_fetch_add(a.gave_up, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -359,7 +363,7 @@ __device__ __forceinline__ void ring_loader_regs(const RingArgs& a, unsigned cha
             const uint32_t P = lane + 64u * it;
             if ((it + 1) * 64 <= NCH || P < (uint32_t)NCH) *reinterpret_cast<float4*>(dst + (P >> 4) * (uint32_t)kRingRowBytes + (P & 15u) * 16u) = r[it];
         }
-        if (lane == 0) ctl->desc[(uint32_t)kRingNSL * L + slot] = make_uint4(d.s, d.tile, 0u, 0u);
+        if (lane == 0) ctl->desc[(uint32_t)NSL * L + slot] = make_uint4(d.s, d.tile, 0u, 0u);
         ++landed;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) __hip_atomic_store(&ctl->landed[L], landed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -426,7 +430,7 @@ __device__ __forceinline__ void ring_mac16_asm(r_f32x2& acc, const r_f32x4 (&x)[
 #undef HD_ADD
 }
 
-template <int T>
+template <int T, int NSL = kRingNSL>
 __device__ __forceinline__ void ring_consumer(const RingArgs& a, const unsigned char* __restrict__ ring, RingCtl* __restrict__ ctl, const bool feeder,
                                               const uint32_t role /* the wave's role number in the workgroup (diagnostic builds: its row in the stamp table) */)
 {
@@ -499,7 +503,7 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const unsigned 
         }
         if (skip) continue;
         RSTAMP(0);
-        const uint32_t slot = (uint32_t)kRingNSL * L + seq % (uint32_t)kRingNSL;
+        const uint32_t slot = (uint32_t)NSL * L + seq % (uint32_t)NSL;
         const uint4 d = ctl->desc[slot];
         const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.x), tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y);
         const unsigned char* p = ring + slot * (uint32_t)SLOT + lane * (uint32_t)kRingRowBytes;

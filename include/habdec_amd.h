@@ -179,7 +179,8 @@ typedef struct hd_timing {
     uint64_t timed_calls;   /* how many calls carried the HIP-event timing so far (ms_* are those of the latest one) */
     uint32_t path;          /* how the most recent call was launched: 0 separate kernels, 1 fused back end (k_backend), 2 stream tail kernel
                              * (k_tail), 3 step kernel (k_step: stage 1 + the previous call's stream tails in one launch; ms_front is ITS duration) */
-    uint32_t step_variant;  /* path 3 only: 0 = single-wave workgroups (k_step), 1 = one workgroup per CU with an LDS-DMA loader wave (k_step_cu) */
+    uint32_t step_variant;  /* 1 = the kernel that touches full-rate IQ is one workgroup per CU with LDS-DMA loader waves (stage1_ring.h): k_step_cu on path 3,
+                             * k_stage1_cu (stage 1 alone) on paths 0-2; 0 = single-wave / classic workgroups (k_step, k_decimate) */
 } hd_timing;
 int hd_engine_timing(hd_engine* e, hd_timing* out);
 /* Bracket the kernels with HIP events on every `every`-th call (default 8; 0 = never; 1 = every call).  Each event record is

@@ -117,12 +117,18 @@ def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, s
     eng.close()
 
 
-def test_stage1_alone_drawing_its_tiles(monkeypatch, headline_ring):
-    """HD_CLAIM_ALONE=1: synchronous calls, stage 1 as a launch of its own with the per-XCD run counters (off by default: measured slower
-    than the fixed shares; the code path stays covered)."""
+@pytest.mark.parametrize("kernel", ["per_cu", "single_wave_drawn", "single_wave"])
+def test_stage1_alone_at_full_size(monkeypatch, headline_ring, kernel):
+    """Synchronous calls (what the Decoder facade makes): stage 1 as a launch of its own, then the stream tails.  "per_cu": one workgroup per CU
+    with LDS-DMA loader waves, eight tile slots and six computing waves (k_stage1_cu, the default for a /32 first stage); "single_wave_drawn":
+    k_decimate drawing runs from the per-XCD counters (HD_CLAIM_ALONE=1: measured slower than fixed shares, off by default; the path stays
+    covered); "single_wave": k_decimate with fixed shares."""
     import habdec_amd
     from oracle import pyoracle
-    monkeypatch.setenv("HD_CLAIM_ALONE", "1")
+    if kernel != "per_cu":
+        monkeypatch.setenv("HD_NO_CU_STEP", "1")
+    if kernel == "single_wave_drawn":
+        monkeypatch.setenv("HD_CLAIM_ALONE", "1")
     w, ring, ring_chunks = headline_ring
     S, fs = w["S"], w["fs"]
     check = [0, 127, 128, 511, 512, 775, 1023]
@@ -136,6 +142,7 @@ def test_stage1_alone_drawing_its_tiles(monkeypatch, headline_ring):
             assert same_bits(eng.decimated(s), o.array("last_decimated")), ("decimated", k, s)
             assert same_bits(eng.demodulated(s), o.array("last_demod")), ("demod", k, s)
             assert np.array_equal(eng.bits(s), o.bits()), ("bits", k, s)
+    assert eng.timing()["path"] == 2 and eng.timing()["step_variant"] == (1 if kernel == "per_cu" else 0)
     eng.close()
 
 

@@ -53,7 +53,7 @@ def main():
         wr = statistics.median(write.get(k, [0.0])) * KB
         table[k] = {"launches": len(fetch.get(k, [])), "fetch_bytes": round(fr), "write_bytes": round(wr), "hbm_bytes": round(fr + wr)}
     (dst / f"{rnd}_pmc_traffic.json").write_text(json.dumps(table, indent=1) + "\n")
-    front = max((k for k in table if k.startswith("k_decimate") or k.startswith("k_step")), key=lambda k: table[k]["hbm_bytes"])
+    front = max((k for k in table if k.startswith("k_decimate") or k.startswith("k_step") or k.startswith("k_stage1")), key=lambda k: table[k]["hbm_bytes"] * max(table[k]["launches"], 1))
     tf = dst / "traffic.json"
     cur = json.loads(tf.read_text()) if tf.exists() else {}
     st = next((r for r in rows if r[0] == front), None)      # the same kernel in the --kernel-trace --stats pass: bench.py reports it beside its live figure

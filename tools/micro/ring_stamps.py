@@ -5,7 +5,7 @@ import torch, bench, habdec_amd
 w = dict(bench.WORKLOADS["cfg4"]); S = 1024; C = w["C"]
 dev = torch.device("cuda", 0)
 ring, rc, _ = bench.generate_ring(torch, dev, w, S, 0, 1234)
-eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"], pipeline=True)
+eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"], pipeline=bool(int(os.environ.get("PIPE", "1"))))
 eng.set_timing(1)
 L = habdec_amd.lib(); f = L.hd_debug_ring_stamps; f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 for i in range(int(os.environ.get("NCALLS", "30"))):

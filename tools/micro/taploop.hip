@@ -5,6 +5,7 @@
 //   MODE 0: taps through the scalar cache (s_load), 16-slot chunks, next chunk's reads requested before the current one is summed
 //   MODE 1: taps from an LDS table with broadcast ds_read_b128 (in-order returns: counted waits), same chunking
 //   MODE 2: MODE 1 on two tiles at once (two independent sums per lane, 2 x 18 KB of LDS)
+//   MODE 3: MODE 0 with the sixteen-tap chunk scheduled by hand (ring_mac16_asm of stage1_ring.h): products three taps ahead of the adds
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -38,10 +39,34 @@ __device__ __forceinline__ void mac16v(f32x2& acc, const f32x4 (&x)[8], const f3
     }
 }
 
+// the hand-scheduled chunk of stage1_ring.h (products three taps ahead of the adds), taps as eight scalar pairs
+__device__ __forceinline__ void mac16_asm(f32x2& acc, const f32x4 (&x)[8], const f32x2 (&kp)[8])
+{
+    f32x2 t0, t1, t2, t3;
+#define HD_MUL_E(t, xi, ki) "v_pk_mul_f32 %" #t ", %" #xi ", %" #ki " op_sel_hi:[1,0]\n\t"
+#define HD_MUL_O(t, xi, ki) "v_pk_mul_f32 %" #t ", %" #xi ", %" #ki " op_sel:[0,1]\n\t"
+#define HD_ADD(t) "v_pk_add_f32 %0, %0, %" #t "\n\t"
+    asm volatile(
+        HD_MUL_E(1, 5, 21) HD_MUL_O(2, 6, 21) HD_MUL_E(3, 7, 22)
+        HD_ADD(1) HD_MUL_O(4, 8, 22) HD_ADD(2) HD_MUL_E(1, 9, 23) HD_ADD(3) HD_MUL_O(2, 10, 23) HD_ADD(4) HD_MUL_E(3, 11, 24)
+        HD_ADD(1) HD_MUL_O(4, 12, 24) HD_ADD(2) HD_MUL_E(1, 13, 25) HD_ADD(3) HD_MUL_O(2, 14, 25) HD_ADD(4) HD_MUL_E(3, 15, 26)
+        HD_ADD(1) HD_MUL_O(4, 16, 26) HD_ADD(2) HD_MUL_E(1, 17, 27) HD_ADD(3) HD_MUL_O(2, 18, 27) HD_ADD(4) HD_MUL_E(3, 19, 28)
+        HD_ADD(1) HD_MUL_O(4, 20, 28) HD_ADD(2) HD_ADD(3) "v_pk_add_f32 %0, %0, %4"
+        : "+v"(acc), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(x[0].xy), "v"(x[0].zw), "v"(x[1].xy), "v"(x[1].zw), "v"(x[2].xy), "v"(x[2].zw), "v"(x[3].xy), "v"(x[3].zw),
+          "v"(x[4].xy), "v"(x[4].zw), "v"(x[5].xy), "v"(x[5].zw), "v"(x[6].xy), "v"(x[6].zw), "v"(x[7].xy), "v"(x[7].zw),
+          "s"(kp[0]), "s"(kp[1]), "s"(kp[2]), "s"(kp[3]), "s"(kp[4]), "s"(kp[5]), "s"(kp[6]), "s"(kp[7]));
+#undef HD_MUL_E
+#undef HD_MUL_O
+#undef HD_ADD
+}
+
 template <int MODE>
-__global__ __launch_bounds__(64) void k(unsigned long long* out, float2* res, const float* __restrict__ taps /* NCH*16, zero outside [13,225) */, int iters)
+__global__ __launch_bounds__(64) void k(unsigned long long* out, float2* res, const float* __restrict__ taps_g /* NCH*16, zero outside [13,225) */, int iters)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    typedef const float __attribute__((address_space(4)))* ctaps_t;
+    const ctaps_t taps = (ctaps_t)(uintptr_t)taps_g;
     float2* tile = reinterpret_cast<float2*>(lds);
     constexpr int NT = MODE == 2 ? 2 : 1;
     float* tl = reinterpret_cast<float*>(lds + NT * TILE_BYTES);
@@ -79,6 +104,30 @@ __global__ __launch_bounds__(64) void k(unsigned long long* out, float2* res, co
             rd(xa, ka, 14);
             mac16<0, 16>(acc, xb, kb);
             mac16<0, 1>(acc, xa, ka);
+            total = total + acc;
+        } else if constexpr (MODE == 3) {
+            f32x2 acc = {0.f, 0.f};
+            f32x4 xa[8], xb[8]; f32x2 ka[8], kb[8];
+            auto rd = [&](f32x4 (&x)[8], f32x2 (&kk)[8], int c) {
+                const unsigned char* pc = p + coff(c);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x[q] = *reinterpret_cast<const f32x4*>(pc + 16 * q);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { kk[j].x = taps[c * 16 + 2 * j]; kk[j].y = taps[c * 16 + 2 * j + 1]; }
+            };
+            rd(xa, ka, 0); rd(xb, kb, 1);
+            acc = acc + xa[6].zw * ka[6].y; acc = acc + xa[7].xy * ka[7].x; acc = acc + xa[7].zw * ka[7].y;
+            int c = 1;
+#pragma unroll 1
+            for (; c + 1 < NCH - 1; c += 2) {
+                rd(xa, ka, c + 1);
+                mac16_asm(acc, xb, kb);
+                rd(xb, kb, c + 2);
+                mac16_asm(acc, xa, ka);
+            }
+            rd(xa, ka, 14);
+            mac16_asm(acc, xb, kb);
+            acc = acc + xa[0].xy * ka[0].x;
             total = total + acc;
         } else if constexpr (MODE == 1) {
             f32x2 acc = {0.f, 0.f};
@@ -170,5 +219,6 @@ int main()
     run<0>("taps via s_load", d_taps);
     run<1>("taps via LDS broadcast", d_taps);
     run<2>("LDS taps, two tiles per wave", d_taps);
+    run<3>("s_load taps, hand-scheduled", d_taps);
     return 0;
 }
