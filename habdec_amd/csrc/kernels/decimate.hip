@@ -614,17 +614,21 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
 #else
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #endif
+    // Tile slots: two per loader in the ring region, and -- as the tails finish -- the tails' LDS slices, two per loader (a slice is at least a
+    // slot long; without tails in the launch there are no slices).
+#ifndef HD_CU_NO_EXTRA_SLOTS
+    const bool slices = n_tail != 0 && tail_bytes >= (uint32_t)ring_slot_bytes<T>();
+#else
+    const bool slices = false;
+#endif
+    const RingGeom geom{ring, (uint32_t)kRingNSL, tails, slices ? 2u : 0u, tail_bytes};
     if (w < 2) {
 #ifdef HD_RING_LOADER_PRIO
         __builtin_amdgcn_s_setprio(HD_RING_LOADER_PRIO);
 #endif
-#ifndef HD_RING_REGS
-        ring_loader<T>(ra, ring, ctl, w);
-#else
-        ring_loader_regs<T>(ra, ring, ctl, w);       // (the same tiles staged through the loader's registers: measured equal, kept for A/B)
-#endif
+        ring_loader<T>(ra, geom, ctl, w);
     } else if (w < 4) {
-        ring_consumer<T>(ra, ring, ctl, w == 2, w);
+        ring_consumer<T>(ra, geom, ctl, w == 2, w);
     } else {
         __builtin_amdgcn_s_setprio(HD_STEP_PRIO);
         const uint32_t k = w - 4u, lane = threadIdx.x & 63u;
@@ -634,9 +638,12 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
         // this call's parameters live in mapped host memory; the tails of this call (next launch) read the device copy
         if (call_copy && lane < 4) reinterpret_cast<uint4*>(call_copy + s)[lane] = reinterpret_cast<const uint4*>(call + s)[lane];
         }
+        // my slice of LDS is free from here on: a tile slot for the loaders (every LDS access of the tail has completed: its results are stored)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&ctl->tail_free[k], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifndef HD_CU_NO_LATE_CONSUMERS
         __builtin_amdgcn_s_setprio(0);
-        ring_consumer<T>(ra, ring, ctl, false, w);                       // the tail is done: one more wave for the tap loops
+        ring_consumer<T>(ra, geom, ctl, false, w);                       // the tail is done: one more wave for the tap loops
 #endif
     }
 }
@@ -671,8 +678,9 @@ __global__ __launch_bounds__(512) void k_stage1_cu(const RingArgs ra)
         }
         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)pick);
     }
-    if (w < 2) ring_loader<T, kRingNSLAlone>(ra, ring, ctl, w);
-    else ring_consumer<T, kRingNSLAlone>(ra, ring, ctl, w == 2, w);
+    const RingGeom geom{ring, (uint32_t)kRingNSLAlone, nullptr, 0u, 0u};
+    if (w < 2) ring_loader<T>(ra, geom, ctl, w);
+    else ring_consumer<T>(ra, geom, ctl, w == 2, w);
 }
 
 // XCC ids seen by a grid of single-wave workgroups: the run counters of the step launches are per XCD and indexed by the hardware's id

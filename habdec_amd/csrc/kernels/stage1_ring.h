@@ -45,11 +45,11 @@ constexpr int kRingRowBytes = 272;                  // 32 samples + one 16-byte 
 #endif
 constexpr int kRingNSL = HD_RING_NSL;                 // tile slots per loader wave in a step launch (beside four stream tails: what fits)
 constexpr int kRingNSLAlone = 4;                      // ... when stage 1 has the CU to itself (k_stage1_cu)
-constexpr int kRingCtlBytes = 256;
+constexpr int kRingCtlBytes = 512;
 constexpr uint32_t kRingSpinLimit = 1u << 22;   // polls before a waiting wave gives up (seconds; a correct run waits microseconds)
 template <int T> constexpr int ring_halo_rows() { return (T - 1 + 31) / 32; }
 template <int T> constexpr int ring_slot_bytes() { return (64 + ring_halo_rows<T>()) * kRingRowBytes; }
-template <int T, int NSL = kRingNSL> constexpr int ring_bytes() { return 2 * NSL * ring_slot_bytes<T>() + kRingCtlBytes; }
+template <int T, int NSL = kRingNSL> constexpr int ring_bytes() { return 2 * NSL * ring_slot_bytes<T>() + kRingCtlBytes; }   // NSL ring slots per loader
 
 #ifdef HD_STAMP_RING   // diagnostic build only (tools/micro/ring_stamps.py): where the loader and the consumers of k_step_cu spend their cycles
 __device__ unsigned long long g_ring_stamps[512 * 8 * 8];
@@ -72,12 +72,24 @@ struct RingCtl {
     uint32_t run_head;      // runs the loaders have claimed (fetch-add)
     uint32_t _pad;
     uint32_t run_q[4];      // drawn run numbers (0xFFFFFFFF: no more)
-    uint32_t slot_done[8];  // per slot NSL L + l % NSL: 1 + l of the tile last finished in it
-    uint4 desc[8];          // per slot: stream, tile
+    uint32_t slot_done[8];  // per slot 4 L + j: 1 + l of the tile last finished in it
+    uint4 desc[16];         // per loader and tile number l & 7: stream, tile, local slot j, l.  (Eight entries for at most four tiles in a loader's
+                            // slots: tile l + 8 cannot be issued before tile l + 4 .. l + 7 have all been issued, i.e. four more slots were
+                            // free while l still held one -- and the consumer of l copies its entry the moment it sees l published.  The entry
+                            // carries l so that the impossible is detected, not assumed.)
     uint32_t simd_rank[4];  // waves of the workgroup that have arrived on each SIMD (role assignment, k_step_cu)
     uint32_t roles_taken;   // bit w: role w has a wave
+    uint32_t tail_free[4];  // tail slice k holds no tail any more (or never did): the loaders may land tiles in it
 };
 static_assert(sizeof(RingCtl) <= kRingCtlBytes, "ring control block");
+
+// Where a loader's tile slots are.  Each of the two loaders owns up to four: `nb` of them in the ring region proper, and -- inside a step launch --
+// `ne` more that are the LDS slices of stream tails: slice k becomes a slot when its tail is done (RingCtl::tail_free[k]; a slice is at least a
+// slot long).  Local slot j of loader L: j < nb: ring + (L * nb + j) * SLOT; else extra + (L * ne + j - nb) * extra_stride.
+struct RingGeom {
+    unsigned char* ring; uint32_t nb;
+    unsigned char* extra; uint32_t ne, extra_stride;
+};
 
 struct RingArgs {
     const float2* in; size_t in_stride;             // this call's IQ slab
@@ -158,15 +170,17 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p)
 }
 
 // ---------------------------------------------------------------------------------------------------------------- a loader wave
-template <int T, int NSL = kRingNSL>
-__device__ __forceinline__ void ring_loader(const RingArgs& a, unsigned char* __restrict__ ring, RingCtl* __restrict__ ctl, const uint32_t L)
+template <int T>
+__device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& geo, RingCtl* __restrict__ ctl, const uint32_t L)
 {
     constexpr int HR = ring_halo_rows<T>();
     constexpr int SLOT = ring_slot_bytes<T>();
     constexpr int NBODY = 17;                       // 64 rows x 17 chunks = 17 x 64 chunks
     constexpr int NHALO = (HR * 17 + 63) / 64;      // halo rows out of the stream itself (every tile but a stream's first)
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t ring_lds = lds_addr_of(ring) + (uint32_t)NSL * L * (uint32_t)SLOT;
+    const uint32_t base_lds = lds_addr_of(geo.ring) + L * geo.nb * (uint32_t)SLOT;
+    const uint32_t extra_lds = geo.ne ? lds_addr_of(geo.extra) + L * geo.ne * geo.extra_stride : 0u;
+    const uint32_t nslots = geo.nb + geo.ne;             // <= 4
 
     // per-lane source offsets (bytes from the tile's first body row / first halo row)
     uint32_t boff[NBODY], hoff[NHALO], hist_off[HR];
@@ -194,7 +208,8 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, unsigned char* __
     uint32_t issued = 0, landed = 0;                // my tiles
     uint32_t inflight_instr = 0;                    // vector-memory instructions of my tiles in flight (at most three tiles: the counter holds 63)
     unsigned long long fifo = 0;                    // ... per tile, oldest in the low byte
-    constexpr uint32_t kMaxFly = NSL >= 3 ? 3u : 2u;
+    const uint32_t max_fly = geo.nb >= 3u ? 3u : 2u;
+    uint32_t my_seq = 0xFFFFFFFFu;                  // lane j < nslots watches my local slot j: the tile in it (none)
     uint32_t idle_spins = 0;
     RSTAMP_DECL;
 
@@ -207,7 +222,11 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, unsigned char* __
             const uint32_t ib = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 7);
             const uint32_t oldest = (uint32_t)(fifo & 0xFFu), younger = inflight_instr - oldest;
             if (((ib & 15u) | (((ib >> 22) & 3u) << 4)) > younger) break;
-            wait_vmcnt(younger);                                       // (returns at once; an ordering point for the compiler)
+#ifndef HD_RING_NO_WAITCNT
+            wait_vmcnt(younger);                                       // (returns at once -- the counter has said so -- but it is the instruction whose completion semantics the hand-off relies on)
+#else
+            asm volatile("" ::: "memory");
+#endif
             inflight_instr -= oldest; fifo >>= 8;
             ++landed;
             if (lane == 0) __hip_atomic_store(&ctl->landed[L], landed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -233,16 +252,23 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, unsigned char* __
                 }
             }
         }
-        bool can = have && issued - landed < kMaxFly && inflight_instr + (uint32_t)(NBODY + (HR > NHALO ? HR : NHALO)) <= 63u;
-        if (can && issued >= (uint32_t)NSL) {                     // my slot issued % NSL held tile issued - NSL: is its consumer finished?
-            const uint32_t dn = __hip_atomic_load(&ctl->slot_done[(uint32_t)NSL * L + issued % (uint32_t)NSL], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            can = dn == issued - (uint32_t)NSL + 1u;
+        unsigned long long free_mask = 0;
+        if (have && issued - landed < max_fly && inflight_instr + (uint32_t)(NBODY + (HR > NHALO ? HR : NHALO)) <= 63u) {
+            // which of my slots are free?  (never used, or its consumer has finished; a tail's slice only once the tail is done)
+            bool ok = false;
+            if (lane < nslots) {
+                const uint32_t dn = __hip_atomic_load(&ctl->slot_done[4u * L + lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ok = my_seq == 0xFFFFFFFFu || dn == my_seq + 1u;
+                if (ok && lane >= geo.nb) ok = __hip_atomic_load(&ctl->tail_free[L * geo.ne + lane - geo.nb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
+            }
+            free_mask = __ballot(ok);
         }
-        if (can) {
-            const uint32_t slot = issued % (uint32_t)NSL;
-            const uint32_t dst = ring_lds + slot * (uint32_t)SLOT;
+        if (free_mask) {
+            const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(free_mask));
+            const uint32_t dst = slot < geo.nb ? base_lds + slot * (uint32_t)SLOT : extra_lds + (slot - geo.nb) * geo.extra_stride;
             const unsigned char* body = reinterpret_cast<const unsigned char*>(a.in + (size_t)s * a.in_stride) + (size_t)tile * (64u * 256u);
-            if (lane == 0) ctl->desc[(uint32_t)NSL * L + slot] = make_uint4(s, tile, 0u, 0u);
+            if (lane == 0) ctl->desc[8u * L + (issued & 7u)] = make_uint4(s, tile, slot, issued);
+            if (lane == slot) my_seq = issued;
             uint32_t cnt = NBODY;
             if (tile == 0) {
                 const unsigned char* hb = reinterpret_cast<const unsigned char*>(a.hist_in + (size_t)s * (T - 1));
@@ -276,109 +302,6 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, unsigned char* __
         RSTAMP(3);
     }
     RSTAMP_WRITE(L, issued);
-}
-
-// ------------------------------------------------------------------------------------------- a loader wave that stages through registers
-// The LDS-DMA loader above can only have in flight what has a slot to land in, and a CU that also hosts four stream tails has four slots:
-// two computing, two in flight -- half of what it takes to keep HBM busy (tools/micro/loader_bw.hip).  This variant keeps its tiles in flight
-// in REGISTERS instead -- a loader wave has 256 of them and no other use for them: three tiles of 18 sixteen-byte loads per lane -- and copies a
-// tile into its LDS slot (ds_write_b128, the padded layout) only when the tile has arrived AND the slot is free.  The slots then hold only
-// tiles that are being summed or are ready to be; what is in flight costs no LDS at all.  Plain loads: the compiler counts them.
-template <int T, int NSL = kRingNSL>
-__device__ __forceinline__ void ring_loader_regs(const RingArgs& a, unsigned char* __restrict__ ring, RingCtl* __restrict__ ctl, const uint32_t L)
-{
-    constexpr int HR = ring_halo_rows<T>();
-    constexpr int SLOT = ring_slot_bytes<T>();
-    constexpr int NCH = (64 + HR) * 16;             // sixteen-byte chunks of a tile, halo rows first
-    constexpr int NV = (NCH + 63) / 64;             // loads per lane
-    const uint32_t lane = threadIdx.x & 63u;
-    unsigned char* my_slots = ring + (uint32_t)NSL * L * (uint32_t)SLOT;
-    const uint32_t xcd0 = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // XCC_ID
-    const uint32_t xcd = xcd0 < a.claim.n_xcd ? xcd0 : a.claim.n_xcd - 1;
-    const uint32_t runs = a.claim.runs_per_xcd, run_len = a.claim.run_len;
-
-    struct Desc { uint32_t s, tile; bool valid; };
-    bool ended = false;
-    uint32_t s = 0, tile = 0, left = 0;
-    uint32_t landed = 0;
-    auto next_tile = [&]() -> Desc {                // the next tile of my sequence; blocks (bounded) until the feeder has drawn the next run
-        if (!left && !ended) {
-            uint32_t idx = 0;
-            if (lane == 0) idx = __hip_atomic_fetch_add(&ctl->run_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
-            for (uint32_t spin = 0;; ++spin) {
-                const uint32_t tail = __hip_atomic_load(&ctl->run_tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if ((int32_t)(tail - idx) > 0) break;
-                if (spin > kRingSpinLimit) { if (lane == 0) (void)__hip_atomic_fetch_add(a.gave_up, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ended = true; return Desc{0, 0, false}; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            const uint32_t rr = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->run_q[idx & 3u]);
-            if (rr < runs) {
-                const uint32_t g0 = (xcd * runs + rr) * run_len;
-                s = g0 / a.ntiles; tile = g0 - s * a.ntiles; left = run_len;
-            } else ended = true;
-        }
-        if (!left) return Desc{0, 0, false};
-        const Desc d{s, tile, true};
-        ++tile; --left;
-        return d;
-    };
-    auto load = [&](float4 (&r)[NV], const Desc& d) {
-        const float2* in_s = a.in + (size_t)d.s * a.in_stride;
-        if (d.tile) {                               // every tile but a stream's first: one scalar base, plain loads at immediate offsets
-            const unsigned char* base = reinterpret_cast<const unsigned char*>(in_s) + (size_t)d.tile * (64u * 256u) - HR * 256;
-            base = reinterpret_cast<const unsigned char*>(uniform_ptr(base));
-#pragma unroll
-            for (int it = 0; it < NV; ++it)
-                if ((it + 1) * 64 <= NCH || lane < (uint32_t)(NCH - it * 64)) r[it] = *reinterpret_cast<const float4*>(base + (lane + 64u * it) * 16u);
-        } else {                                    // the halo rows come out of the stage history (T-1 samples at odd 8-byte offsets)
-            const float2* hist_s = a.hist_in + (size_t)d.s * (T - 1);
-#pragma unroll
-            for (int it = 0; it < NV; ++it) {
-                const uint32_t P = lane + 64u * it;
-                if ((it + 1) * 64 <= NCH || P < (uint32_t)NCH) {
-                    const int x = ((int)(P >> 4) - HR) * 32 + (int)(P & 15u) * 2;       // stream sample of the chunk's first half
-                    if (x >= 0) r[it] = *reinterpret_cast<const float4*>(in_s + x);
-                    else {
-                        const int h = x + (T - 1);  // (x is even and T-1 odd: h + 1 <= T-1 - 1)
-                        const float2 lo = h >= 0 ? hist_s[h] : make_float2(0.f, 0.f), hi = h + 1 >= 0 ? hist_s[h + 1] : make_float2(0.f, 0.f);
-                        r[it] = make_float4(lo.x, lo.y, hi.x, hi.y);
-                    }
-                }
-            }
-        }
-    };
-    auto stash = [&](const float4 (&r)[NV], const Desc& d) {           // my next slot: wait until it is free, copy, publish
-        const uint32_t slot = landed % (uint32_t)NSL;
-        if (landed >= (uint32_t)NSL)
-            for (uint32_t spin = 0;; ++spin) {
-                const uint32_t dn = __hip_atomic_load(&ctl->slot_done[(uint32_t)NSL * L + slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (dn == landed - (uint32_t)NSL + 1u) break;
-                if (spin > kRingSpinLimit) { if (lane == 0) (void)__hip_atomic_fetch_add(a.gave_up, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        unsigned char* dst = my_slots + slot * (uint32_t)SLOT;
-#pragma unroll
-        for (int it = 0; it < NV; ++it) {
-            const uint32_t P = lane + 64u * it;
-            if ((it + 1) * 64 <= NCH || P < (uint32_t)NCH) *reinterpret_cast<float4*>(dst + (P >> 4) * (uint32_t)kRingRowBytes + (P & 15u) * 16u) = r[it];
-        }
-        if (lane == 0) ctl->desc[(uint32_t)NSL * L + slot] = make_uint4(d.s, d.tile, 0u, 0u);
-        ++landed;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&ctl->landed[L], landed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-
-    float4 r0[NV], r1[NV], r2[NV];
-    Desc d0 = next_tile(); if (d0.valid) load(r0, d0);
-    Desc d1 = next_tile(); if (d1.valid) load(r1, d1);
-    Desc d2 = next_tile(); if (d2.valid) load(r2, d2);
-    while (d0.valid || d1.valid || d2.valid) {
-        if (d0.valid) { stash(r0, d0); d0 = next_tile(); if (d0.valid) load(r0, d0); }
-        if (d1.valid) { stash(r1, d1); d1 = next_tile(); if (d1.valid) load(r1, d1); }
-        if (d2.valid) { stash(r2, d2); d2 = next_tile(); if (d2.valid) load(r2, d2); }
-    }
-    if (lane == 0) __hip_atomic_store(&ctl->end[L], landed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // -------------------------------------------------------------------------------------------------------------- a consumer wave
@@ -430,8 +353,8 @@ __device__ __forceinline__ void ring_mac16_asm(r_f32x2& acc, const r_f32x4 (&x)[
 #undef HD_ADD
 }
 
-template <int T, int NSL = kRingNSL>
-__device__ __forceinline__ void ring_consumer(const RingArgs& a, const unsigned char* __restrict__ ring, RingCtl* __restrict__ ctl, const bool feeder,
+template <int T>
+__device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom& geo, RingCtl* __restrict__ ctl, const bool feeder,
                                               const uint32_t role /* the wave's role number in the workgroup (diagnostic builds: its row in the stamp table) */)
 {
     constexpr int HR = ring_halo_rows<T>();
@@ -503,10 +426,15 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const unsigned 
         }
         if (skip) continue;
         RSTAMP(0);
-        const uint32_t slot = (uint32_t)NSL * L + seq % (uint32_t)NSL;
-        const uint4 d = ctl->desc[slot];
-        const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.x), tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y);
-        const unsigned char* p = ring + slot * (uint32_t)SLOT + lane * (uint32_t)kRingRowBytes;
+        const uint4 d = ctl->desc[8u * L + (seq & 7u)];
+        const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.x), tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y),
+                       slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z);
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)d.w) != seq) {   // (the entry was reused under this wave's feet: cannot happen, see RingCtl::desc)
+            if (lane == 0) (void)__hip_atomic_fetch_add(a.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        const unsigned char* p = (slot < geo.nb ? geo.ring + (L * geo.nb + slot) * (uint32_t)SLOT : geo.extra + (L * geo.ne + slot - geo.nb) * geo.extra_stride) +
+                                 lane * (uint32_t)kRingRowBytes;
 
         // the T-term sum in tap order: 16-slot chunks (half rows), the next chunk's samples and taps requested before the current one is summed
         r_f32x2 acc = {0.f, 0.f};
@@ -563,7 +491,7 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const unsigned 
 #endif
         RSTAMP(1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&ctl->slot_done[slot], seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_store(&ctl->slot_done[4u * L + slot], seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         a.out[(size_t)s * a.out_stride + (size_t)tile * 64u + lane] = make_float2(acc.x, acc.y);
         if (tile + 1 == a.ntiles) {                 // the stream's last tile: carry the last T-1 inputs (Decimator.h:140-143)
             const float2* in_s = a.in + (size_t)s * a.in_stride;
