@@ -132,6 +132,9 @@ struct hd_engine {
     uint32_t step_run = 0;     // HD_STEP_RUN: tiles per drawn run (default 4, minimum 2)
     bool no_cu_step = false;   // HD_NO_CU_STEP: step launches as single-wave workgroups (k_step) instead of one workgroup per CU (k_step_cu)
     uint32_t ring_run = 0;     // HD_RING_RUN: tiles per drawn run of k_step_cu's loader (default 8)
+    uint32_t ring_loaders = 1; // HD_RING_LOADERS: LDS-DMA waves per CU in a step launch (1 or 2; one leaves SIMD 1 two computing waves: 0.157 against 0.160 ms per launch)
+    uint32_t s1_loaders = 2;   // HD_S1_LOADERS: ... when stage 1 is a launch of its own
+    uint32_t s1_waves = 8;     // HD_S1_WAVES: waves per workgroup of k_stage1_cu (8 .. 16)
     PinBuf<unsigned int> ring_gave_up;     // mapped host word the waves of k_step_cu bump when a bounded wait runs out (never in a correct run)
     uint64_t step_launches = 0;
     DevBuf<unsigned int> step_ctr;         // two sets of per-XCD run counters ([2][16][32] u32), alternating per step launch
@@ -317,6 +320,9 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     if (const char* v = getenv("HD_STEP_RUN")) e->step_run = (uint32_t)atoi(v);
     e->no_cu_step = getenv("HD_NO_CU_STEP") != nullptr;
     if (const char* v = getenv("HD_RING_RUN")) e->ring_run = (uint32_t)atoi(v);
+    if (const char* v = getenv("HD_RING_LOADERS")) e->ring_loaders = atoi(v) == 1 ? 1u : 2u;
+    if (const char* v = getenv("HD_S1_LOADERS")) e->s1_loaders = atoi(v) == 1 ? 1u : 2u;
+    if (const char* v = getenv("HD_S1_WAVES")) e->s1_waves = (uint32_t)atoi(v);
     if (const char* v = getenv("HD_STEP_WGS")) e->step_wgs = (uint32_t)atoi(v);
     if (const char* v = getenv("HD_TAIL_LANES")) e->tail_lanes = atoi(v);
     if (const char* v = getenv("HD_TAIL_MAX_N2")) e->tail_max_n2 = (uint32_t)strtoul(v, nullptr, 0);
@@ -965,7 +971,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             if (cu_exp & 2) cl.runs_per_xcd = 0;
             launched = hd::launch_step_cu(qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, e->n_cus, iq, stride,
                                           e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, prev.ta,
-                                          (prev.valid && !(cu_exp & 1)) ? S : 0u, max_in, cl, (tb + 15u) & ~15u, e->ring_gave_up.dev);
+                                          (prev.valid && !(cu_exp & 1)) ? S : 0u, max_in, cl, (tb + 15u) & ~15u, e->ring_gave_up.dev, e->ring_loaders);
             e->last_timing.step_variant = launched ? 1u : 0u;
         }
         if (!launched)
@@ -1007,7 +1013,11 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         const bool single = nst == 1;
         float2* out1 = single ? fcur : d1;
         const size_t out1_stride = single ? e->fbuf_stride : e->n1_cap;
-        const uint32_t lin1 = (min_in == max_in && max_in) ? e->dec_wgs_per_cu * (e->qa_cus ? e->qa_cus : e->n_cus) : 0u;
+        // (a /64 workgroup holds 36.7 KB of LDS and ~400 VGPRs: four fit a CU, and six per CU would be a launch of one round and a half --
+        // measured at 10 MS/s, /256: 1.73 against 1.84 ms per step)
+        static const bool wgs_env = getenv("HD_DEC_WGS_PER_CU") != nullptr;
+        const uint32_t wgs_cu = (R1 == 64 && !wgs_env && e->dec_wgs_per_cu > 4u) ? 4u : e->dec_wgs_per_cu;
+        const uint32_t lin1 = (min_in == max_in && max_in) ? wgs_cu * (e->qa_cus ? e->qa_cus : e->n_cus) : 0u;
         // (Stage 1 alone is HBM-bound: drawing runs costs it ~3 % -- more halo re-reads, 588 vs 576 MB per launch -- where the step launch gains
         // 4 %; measured on one box, alternating.  HD_CLAIM_ALONE=1 turns it on for experiments.)
         // A /32 first stage over equally sized pushes: one workgroup per CU, LDS-DMA loader waves + computing waves (k_stage1_cu, stage1_ring.h)
@@ -1020,7 +1030,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             if (cl.ctr) {
                 if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
                 s1_cu = hd::launch_stage1_cu(qa, (int)R1, (int)T1, e->n_cus, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
-                                             max_in, cl, e->ring_gave_up.dev);
+                                             max_in, cl, e->ring_gave_up.dev, e->s1_loaders, e->s1_waves);
                 if (!s1_cu) --e->step_launches;                // (the counter sets alternate per launch that really draws: this one did not)
             }
         }

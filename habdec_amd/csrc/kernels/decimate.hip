@@ -578,7 +578,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // while the tails hold half of the CU's wave slots, and what runs where does not depend on the dispatcher.
 template <int T, int D2, int T2>
 __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const StreamCall* __restrict__ call, StreamCall* __restrict__ call_copy,
-                                                 const TailArgs ta, const uint32_t n_tail, const uint32_t n_streams, const uint32_t tail_bytes)
+                                                 const TailArgs ta, const uint32_t n_tail, const uint32_t n_streams, const uint32_t tail_bytes,
+                                                 const uint32_t n_loaders /* 2: a loader on SIMD 0 and on SIMD 1; 1: SIMD 1 computes with both of its waves */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char cu_lds[];
     unsigned char* ring = cu_lds;
@@ -621,14 +622,14 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
 #else
     const bool slices = false;
 #endif
-    const RingGeom geom{ring, (uint32_t)kRingNSL, tails, slices ? 2u : 0u, tail_bytes};
-    if (w < 2) {
+    const RingGeom geom{ring, (uint32_t)kRingNSL * (3u - n_loaders), tails, slices ? 2u * (3u - n_loaders) : 0u, tail_bytes, n_loaders};
+    if (w < n_loaders) {
 #ifdef HD_RING_LOADER_PRIO
         __builtin_amdgcn_s_setprio(HD_RING_LOADER_PRIO);
 #endif
         ring_loader<T>(ra, geom, ctl, w);
     } else if (w < 4) {
-        ring_consumer<T>(ra, geom, ctl, w == 2, w);
+        ring_consumer<T>(ra, geom, ctl, w == 2, w);                      // (the wave beside loader 0 draws the runs)
     } else {
         __builtin_amdgcn_s_setprio(HD_STEP_PRIO);
         const uint32_t k = w - 4u, lane = threadIdx.x & 63u;
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
 // workgroup per CU, two LDS-DMA loader waves with four tile slots each -- without tails in the CU's LDS there is room for eight --
 // and six computing waves.  512 MiB of IQ in 104-108 us where the single-wave grid (k_decimate<32,212,64>) takes 118-123.
 template <int T>
-__global__ __launch_bounds__(512) void k_stage1_cu(const RingArgs ra)
+__global__ __launch_bounds__(1024) void k_stage1_cu(const RingArgs ra, const uint32_t n_loaders)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char cu_lds[];
     unsigned char* ring = cu_lds;
@@ -678,8 +679,8 @@ __global__ __launch_bounds__(512) void k_stage1_cu(const RingArgs ra)
         }
         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)pick);
     }
-    const RingGeom geom{ring, (uint32_t)kRingNSLAlone, nullptr, 0u, 0u};
-    if (w < 2) ring_loader<T>(ra, geom, ctl, w);
+    const RingGeom geom{ring, (uint32_t)kRingNSLAlone * (3u - n_loaders), nullptr, 0u, 0u, n_loaders};
+    if (w < n_loaders) ring_loader<T>(ra, geom, ctl, w);
     else ring_consumer<T>(ra, geom, ctl, w == 2, w);
 }
 
@@ -805,8 +806,9 @@ uint32_t step_cu_tail_lds(int ratio, int ntaps)
 
 bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, uint32_t n_streams, uint32_t n_cus, const float2* in, size_t in_stride,
                     const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
-                    StreamCall* call_copy, const TailArgs& ta, uint32_t n_tail, uint32_t uniform_n, const StepClaim& claim, uint32_t tail_bytes, unsigned int* gave_up)
+                    StreamCall* call_copy, const TailArgs& ta, uint32_t n_tail, uint32_t uniform_n, const StepClaim& claim, uint32_t tail_bytes, unsigned int* gave_up, uint32_t n_loaders)
 {
+    if (n_loaders != 1u) n_loaders = 2u;
     if (ratio != 32 || !claim.ctr || !uniform_n || uniform_n % 2048u) return false;
     RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, uniform_n / 2048u, claim, gave_up};
 #define HD_CU_CASE(T, D2, T2)                                                                                                         \
@@ -820,7 +822,7 @@ bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_cu<T, D2, T2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) return false; \
             attr_set[dev_] = true;                                                                                                    \
         }                                                                                                                             \
-        hipLaunchKernelGGL((k_step_cu<T, D2, T2>), dim3(n_cus > (n_streams + 3u) / 4u ? n_cus : (n_streams + 3u) / 4u), dim3(512), lds, st, ra, call, call_copy, ta, n_tail, n_streams, tail_bytes); \
+        hipLaunchKernelGGL((k_step_cu<T, D2, T2>), dim3(n_cus > (n_streams + 3u) / 4u ? n_cus : (n_streams + 3u) / 4u), dim3(512), lds, st, ra, call, call_copy, ta, n_tail, n_streams, tail_bytes, n_loaders); \
         return true;                                                                                                                  \
     }
     HD_CU_CASE(212, 2, 69) HD_CU_CASE(174, 4, 139)
@@ -829,8 +831,10 @@ bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2
 }
 
 bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, const float2* in, size_t in_stride, const float2* hist_in, float2* hist_out,
-                      const float* taps, float2* out, size_t out_stride, uint32_t uniform_n, const StepClaim& claim, unsigned int* gave_up)
+                      const float* taps, float2* out, size_t out_stride, uint32_t uniform_n, const StepClaim& claim, unsigned int* gave_up, uint32_t n_loaders, uint32_t n_waves)
 {
+    if (n_loaders != 1u) n_loaders = 2u;
+    if (n_waves < 8u || n_waves > 16u) n_waves = 8u;
     if (ratio != 32 || !claim.ctr || !uniform_n || uniform_n % 2048u) return false;
     RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, uniform_n / 2048u, claim, gave_up};
 #define HD_S1_CASE(T)                                                                                                                 \
@@ -844,7 +848,7 @@ bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, cons
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_stage1_cu<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) return false; \
             attr_set[dev_] = true;                                                                                                    \
         }                                                                                                                             \
-        hipLaunchKernelGGL((k_stage1_cu<T>), dim3(n_cus), dim3(512), lds, st, ra);                                                    \
+        hipLaunchKernelGGL((k_stage1_cu<T>), dim3(n_cus), dim3(64u * n_waves), lds, st, ra, n_loaders);                                                    \
         return true;                                                                                                                  \
     }
     HD_S1_CASE(212) HD_S1_CASE(174)

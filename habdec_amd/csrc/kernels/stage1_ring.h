@@ -89,6 +89,7 @@ static_assert(sizeof(RingCtl) <= kRingCtlBytes, "ring control block");
 struct RingGeom {
     unsigned char* ring; uint32_t nb;
     unsigned char* extra; uint32_t ne, extra_stride;
+    uint32_t nl;            // loader waves: 2, or 1 (which then owns every slot: nb + ne <= 8, and all sixteen descriptor entries)
 };
 
 struct RingArgs {
@@ -180,7 +181,8 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t base_lds = lds_addr_of(geo.ring) + L * geo.nb * (uint32_t)SLOT;
     const uint32_t extra_lds = geo.ne ? lds_addr_of(geo.extra) + L * geo.ne * geo.extra_stride : 0u;
-    const uint32_t nslots = geo.nb + geo.ne;             // <= 4
+    const uint32_t nslots = geo.nb + geo.ne;             // <= 4 (two loaders), <= 8 (one)
+    const uint32_t dmask = geo.nl == 1u ? 15u : 7u;      // descriptor entries per loader - 1
 
     // per-lane source offsets (bytes from the tile's first body row / first halo row)
     uint32_t boff[NBODY], hoff[NHALO], hist_off[HR];
@@ -267,7 +269,7 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
             const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(free_mask));
             const uint32_t dst = slot < geo.nb ? base_lds + slot * (uint32_t)SLOT : extra_lds + (slot - geo.nb) * geo.extra_stride;
             const unsigned char* body = reinterpret_cast<const unsigned char*>(a.in + (size_t)s * a.in_stride) + (size_t)tile * (64u * 256u);
-            if (lane == 0) ctl->desc[8u * L + (issued & 7u)] = make_uint4(s, tile, slot, issued);
+            if (lane == 0) ctl->desc[8u * L + (issued & dmask)] = make_uint4(s, tile, slot, issued);
             if (lane == slot) my_seq = issued;
             uint32_t cnt = NBODY;
             if (tile == 0) {
@@ -396,7 +398,7 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
                 __hip_atomic_store(&ctl->run_tail, fed + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             ++fed;
-            if (v == 0xFFFFFFFFu && ++sentinels == 2u) feeding = false;                    // one "no more" for each loader
+            if (v == 0xFFFFFFFFu && ++sentinels == geo.nl) feeding = false;                // one "no more" for each loader
         }
     };
 
@@ -406,14 +408,14 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
         uint32_t g = 0;
         if (lane == 0) g = __hip_atomic_fetch_add(&ctl->taken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
-        const uint32_t L = g & 1u, seq = g >> 1;
+        const uint32_t L = geo.nl == 1u ? 0u : (g & 1u), seq = geo.nl == 1u ? g : (g >> 1);
         bool skip = false;
         for (uint32_t spin = 0;; ++spin) {
             const uint32_t l = __hip_atomic_load(&ctl->landed[L], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if ((int32_t)(l - seq) > 0) break;
             const uint32_t e = __hip_atomic_load(&ctl->end[L], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (seq >= e) {                         // this loader never issues tile seq; the other one may still have some
-                const uint32_t e2 = __hip_atomic_load(&ctl->end[L ^ 1u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t e2 = geo.nl == 1u ? e : __hip_atomic_load(&ctl->end[L ^ 1u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (seq >= e2 && !feeding) { RSTAMP(0); RSTAMP_WRITE(my_wave, n_done); return; }
                 if (seq < e2) { skip = true; break; }
             }
@@ -426,7 +428,7 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
         }
         if (skip) continue;
         RSTAMP(0);
-        const uint4 d = ctl->desc[8u * L + (seq & 7u)];
+        const uint4 d = ctl->desc[8u * L + (seq & (geo.nl == 1u ? 15u : 7u))];
         const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.x), tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y),
                        slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z);
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)d.w) != seq) {   // (the entry was reused under this wave's feet: cannot happen, see RingCtl::desc)

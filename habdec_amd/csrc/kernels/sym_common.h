@@ -28,15 +28,19 @@ __device__ __forceinline__ SymState state_after_push(SymState st, const SymbolPa
 // samples (then the R+3 right-window samples) once with 16-byte LDS reads and adds each sample to every one of its
 // four accumulators whose window contains it.  Each accumulator still receives exactly its own R samples in index
 // order, so the sums are bit-identical to std::accumulate, with 1/16 of the LDS instructions of the scalar form.
-constexpr int kAvgPos = 4;                                  // positions per lane
-constexpr int kAvgSpan = kAvgLanes * kAvgPos;               // positions per workgroup (1024)
+#ifndef HD_SYM_POS
+#define HD_SYM_POS 8     // (8: half the LDS reads per position and four add chains per lane; /4 at 512 kHz: 0.868 against 0.898 ms per step)
+#endif
+constexpr int kAvgPos = HD_SYM_POS;                         // positions per lane of k_symbols (4 or 8)
+constexpr int kAvgSpan = kAvgLanes * kAvgPos;               // positions per workgroup and sweep
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // acc[j] = w[j] + w[j+1] + ... + w[j+R-1] for j = 0..3, each in index order.  Interior samples feed all four sums:
 // two v_pk_add_f32 per sample.
-__device__ __forceinline__ void window_sums(const float* __restrict__ w, uint32_t R, float acc[kAvgPos])
+__device__ __forceinline__ void window_sums(const float* __restrict__ w, uint32_t R, float acc[4])
 {
+    constexpr int kAvgPos = 4;
     f32x2 a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f};
     const uint32_t total = R + kAvgPos - 1;                 // samples touched: w[0 .. R+3)
     {   // head chunk: element u feeds accumulators j <= u (R >= 4 always)

@@ -33,6 +33,13 @@ extern "C" void hd_debug_sym_stamps(unsigned long long* host, size_t n) { (void)
 #else
 #define STAMP(i) do { } while (0)
 #endif
+#ifdef HD_STAMP_SWEEP   // (with HD_STAMP) where a sweep of phase A spends its cycles: staging / window sums / flags, summed over the call's sweeps into stamps 6 and 7
+#define SWEEP_DECL unsigned long long sw_t = __builtin_amdgcn_s_memtime(), sw_acc[3] = {0, 0, 0}
+#define SWEEP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); sw_acc[i] += t_ - sw_t; sw_t = t_; } while (0)
+#else
+#define SWEEP_DECL do { } while (0)
+#define SWEEP(i) do { } while (0)
+#endif
 constexpr int kSymLanes = 256;
 constexpr uint32_t kRunStrip = 512;                       // samples per run-sum step
 
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     // flag(p) = sgn(W(p-R)/R) != sgn(W(p)/R).
     float* wl = win + ((kAvgSpan + R + 16 + 3) & ~3u);      // W of [c0 - R, c0 + span)
     const uint32_t wn = kAvgSpan + R + 8;
-    constexpr int WB = 6, LB = 2, MB = 2;                   // loads per lane issued back to back (covers R <= 504, 32768 searchable positions)
+    constexpr int WB = kAvgPos == 8 ? 10 : 6, LB = 2, MB = 2;                   // loads per lane issued back to back (covers R <= 504, 32768 searchable positions)
     unsigned long long first_word = 0ull;                   // mask word holding position c0, as earlier calls left it
     {
         const uint32_t c0 = st.cached;
@@ -133,7 +140,9 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     STAMP(1);
     bool staged = true;
     uint32_t sweeps = 0, wl_c0 = st.cached;                 // wl holds W of [wl_c0 - R, wl_c0 + kAvgSpan) after the last sweep
+    SWEEP_DECL;
     for (uint32_t c0 = st.cached; (int32_t)(pend - c0) > 0; c0 += kAvgSpan) {
+        SWEEP(2);
         const uint32_t wb0 = c0 & ~63u, wsh = c0 & 63u;    // sweeps start wherever the previous call stopped: words are shared
         if (!staged) {
             __syncthreads();                                // previous sweep's LDS consumers are done
@@ -151,11 +160,12 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
         ++sweeps; wl_c0 = c0;
         if (tid < kAvgSpan / 64 + 1) words[tid] = 0ull;
         __syncthreads();
+        SWEEP(0);
         const uint32_t p0 = c0 + tid * kAvgPos;
         const bool any = (int32_t)(pend - p0) > 0;
         float wp[kAvgPos];
         if (any) {
-            window_sums(win + tid * kAvgPos, R, wp);
+            if constexpr (kAvgPos == 8) window_sums8(win + tid * kAvgPos, R, wp); else window_sums(win + tid * kAvgPos, R, wp);
 #pragma unroll
             for (int j = 0; j < kAvgPos; ++j) {
                 wl[R + tid * kAvgPos + j] = wp[j];
@@ -163,6 +173,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
             }
         }
         __syncthreads();
+        SWEEP(1);
         if (any) {
             unsigned int bits = 0;
             // sgn(W/R) == sgn(W) unless the quotient underflows to zero: |W| / R < 2^-149 (only then pay for the division)
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
                 const uint32_t bp = wsh + tid * kAvgPos;    // bit position of p0 relative to the sweep's first word
                 const uint32_t sh = bp & 63u;
                 atomicOr(&words[bp >> 6], (unsigned long long)bits << sh);
-                if (sh > 60u) atomicOr(&words[(bp >> 6) + 1], (unsigned long long)bits >> (64u - sh));
+                if (sh > 64u - kAvgPos) atomicOr(&words[(bp >> 6) + 1], (unsigned long long)bits >> (64u - sh));
             }
         }
         __syncthreads();
@@ -380,7 +391,9 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
         st.held = h - last;
         sym[s] = st;
         hdr->nbits = nbits; hdr->held_after = st.held; hdr->nflips = nfl; hdr->overflow = overflow; hdr->uncached = end - st.cached; hdr->demod_n = 0xFFFFFFFFu;
-#ifdef HD_STAMP
+#if defined(HD_STAMP) && defined(HD_STAMP_SWEEP)
+        g_sym_stamps[s * 8 + 6] = sw_acc[0]; g_sym_stamps[s * 8 + 7] = sw_acc[1];
+#elif defined(HD_STAMP)
         g_sym_stamps[s * 8 + 6] = nfl; g_sym_stamps[s * 8 + 7] = nfl ? flips[nfl - 1] : 0;
 #endif
     }
@@ -397,7 +410,7 @@ void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t
     fl_cap = (fl_cap + 63u) & ~63u;
     if (fl_cap > kMaxFlipsPerCall) fl_cap = kMaxFlipsPerCall;
     const size_t lds = (size_t)(ring_cap / 64) * 8 + (size_t)fl_cap * 8 +
-                       (size_t)(((kAvgSpan + max_R + 16 + 3) & ~3u) + ((kAvgSpan + max_R + 3) & ~3u)) * 4;
+                 (size_t)(((kAvgSpan + max_R + 16 + 3) & ~3u) + ((kAvgSpan + max_R + 3) & ~3u)) * 4;
     hipLaunchKernelGGL(k_symbols, dim3(n_streams), dim3(kSymLanes), lds, st, tail, ring_cap, sym, flipmask, weight, sp, call, slots,
                        slot_words, flips_dbg, flips_cap, fl_cap);
 }

@@ -22,6 +22,7 @@ for i in range(NC):
         if i in (NC // 3, NC - 2):
             for j in np.argsort(-tot)[:4]: print('call', i, 'stream', int(j), 'total', int(tot[j]), 'phases', d[j].astype(int).tolist(), 'nflips', int(st[j, 6]), 'last flip', int(st[j, 7]))
             print('   nflips histogram over streams:', np.bincount(st[:, 6].astype(int))[:8].tolist())
+if os.environ.get("SWEEP"): print("sweep parts: staging, window sums (cycles, mean over streams of the last call):", st[:, 6].mean().round(0), st[:, 7].mean().round(0))
 print("phases [A0 mask image, A1 windows, B search, C run sums, D]: mean cycles", (ph_mean / n).round(0).tolist(), " max", ph_max.tolist())
 print("per-stream total cycles p50/p90/p99/max (mean over calls):", np.mean(tot_p, axis=0).round(0).tolist())
 print("first-start to last-end span, cycles (mean over calls):", np.mean(span).round(0))
