@@ -182,7 +182,7 @@ def physical_cores():
 STAGE1 = {64: "k_decimate<32,212,64>", 16: "k_decimate<8,54,256>", 4: "k_decimate<4,139,256>", 256: "k_decimate<64,348,64>"}
 STEP = {64: "k_step<32,212,2,69>", 256: "k_step<64,348,4,139>"}
 STEP_CU = {64: "k_step_cu<212,2,69>", 128: "k_step_cu<174,4,139>"}     # one workgroup per CU: loader + computing waves for stage 1, the tails in the others
-STAGE1_CU = {64: "k_stage1_cu<212>", 128: "k_stage1_cu<174>"}           # stage 1 alone in that shape (eight tile slots, six computing waves)
+STAGE1_CU = {64: "k_stage1_cu<212,32>", 128: "k_stage1_cu<174,32>", 16: "k_stage1_cu<54,8>"}   # stage 1 alone in that shape (eight tile slots, computing waves beside the loader)
 PATHS = {0: "separate kernels", 1: "fused back end", 2: "stream tail kernel", 3: "step kernel (stage 1 + previous call's stream tails)"}
 
 

@@ -133,7 +133,7 @@ struct hd_engine {
     bool no_cu_step = false;   // HD_NO_CU_STEP: step launches as single-wave workgroups (k_step) instead of one workgroup per CU (k_step_cu)
     uint32_t ring_run = 0;     // HD_RING_RUN: tiles per drawn run of k_step_cu's loader (default 8)
     uint32_t ring_loaders = 1; // HD_RING_LOADERS: LDS-DMA waves per CU in a step launch (1 or 2; one leaves SIMD 1 two computing waves: 0.157 against 0.160 ms per launch)
-    uint32_t s1_loaders = 2;   // HD_S1_LOADERS: ... when stage 1 is a launch of its own
+    uint32_t s1_loaders = 1;   // HD_S1_LOADERS: ... when stage 1 is a launch of its own (/32: no difference; /8: 0.350 against 0.360 ms per step)
     uint32_t s1_waves = 8;     // HD_S1_WAVES: waves per workgroup of k_stage1_cu (8 .. 16)
     PinBuf<unsigned int> ring_gave_up;     // mapped host word the waves of k_step_cu bump when a bounded wait runs out (never in a correct run)
     uint64_t step_launches = 0;
@@ -933,10 +933,12 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     auto make_claim = [&](uint32_t lin_wgs /* stage 1 as a launch of its own: the workgroup count of its linear split (which needs four tiles per workgroup); 0 = step launch */,
                           uint32_t run_len_cu = 0 /* != 0: runs for k_step_cu's loader */) {
         hd::StepClaim claim{};
-        const uint32_t ntiles = (max_n1 + 63) / 64, n_xcd = e->n_cus / 32u, run_len = run_len_cu ? run_len_cu : e->step_run >= 2 ? e->step_run : 4u;   // (a run must hold the tile in front of which the next draw is issued: at least two; four re-read fewer halos than two)
+        // (tiles: 64 outputs of a single-wave /32 or /64 first stage; 2048 input samples -- 64 lanes x one row of 32 -- for the per-CU ring kernels)
+        const uint32_t ntiles = run_len_cu ? max_in / 2048u : (max_n1 + 63) / 64, n_xcd = e->n_cus / 32u, run_len = run_len_cu ? run_len_cu : e->step_run >= 2 ? e->step_run : 4u;   // (a run must hold the tile in front of which the next draw is issued: at least two; four re-read fewer halos than two)
         const uint64_t runs = (uint64_t)S * ntiles / run_len;
-        if (!e->no_claim && nst == 2 && (R1 == 32 || R1 == 64) && min_in == max_in && max_in && !any_zero1 && n_xcd && e->n_cus % 32u == 0 && n_xcd <= 16 &&
-            ntiles % run_len == 0 && runs % n_xcd == 0 && max_n1 % 64 == 0 && !e->qa_cus && (uint64_t)S * ntiles < (1ull << 32) && (uint64_t)ntiles * S >= 4ull * lin_wgs) {   // (the two counter sets alternate: a launch that takes one must really run that way)
+        const bool shape_ok = run_len_cu ? (hd::stage1_cu_supported((int)R1, (int)T1) && max_in % 2048u == 0) : ((R1 == 32 || R1 == 64) && max_n1 % 64 == 0);
+        if (!e->no_claim && nst == 2 && shape_ok && min_in == max_in && max_in && !any_zero1 && n_xcd && e->n_cus % 32u == 0 && n_xcd <= 16 &&
+            ntiles && ntiles % run_len == 0 && runs % n_xcd == 0 && !e->qa_cus && (uint64_t)S * ntiles < (1ull << 32) && (uint64_t)ntiles * S >= 4ull * lin_wgs) {   // (the two counter sets alternate: a launch that takes one must really run that way)
             claim.ctr = e->step_ctr.p + (size_t)(e->step_launches & 1u) * 16 * 32;
             claim.ctr_next = e->step_ctr.p + (size_t)((e->step_launches & 1u) ^ 1u) * 16 * 32;
             claim.n_xcd = n_xcd; claim.runs_per_xcd = (uint32_t)(runs / n_xcd); claim.run_len = run_len;
@@ -1022,8 +1024,8 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         // 4 %; measured on one box, alternating.  HD_CLAIM_ALONE=1 turns it on for experiments.)
         // A /32 first stage over equally sized pushes: one workgroup per CU, LDS-DMA loader waves + computing waves (k_stage1_cu, stage1_ring.h)
         bool s1_cu = false;
-        if (!single && lin1 && !e->no_cu_step && R1 == 32 && !any_zero1 && max_in % 2048u == 0 && hd::step_cu_tail_lds((int)R1, (int)T1)) {
-            const uint32_t ntiles1 = (max_n1 + 63) / 64;
+        if (!single && min_in == max_in && max_in && !e->no_cu_step && !any_zero1 && max_in % 2048u == 0 && hd::stage1_cu_supported((int)R1, (int)T1)) {
+            const uint32_t ntiles1 = max_in / 2048u;
             uint32_t ring_run = e->ring_run >= 2 ? e->ring_run : 8u;
             while (ring_run > 2 && (ntiles1 % ring_run || ((uint64_t)S * ntiles1 / ring_run) % (e->n_cus / 32u ? e->n_cus / 32u : 1u))) ring_run >>= 1;
             const hd::StepClaim cl = make_claim(0, ring_run);

@@ -652,8 +652,8 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
 // Stage 1 ALONE in the same shape (synchronous delivery, the first half of a call whose tails run as a launch of their own): one
 // workgroup per CU, two LDS-DMA loader waves with four tile slots each -- without tails in the CU's LDS there is room for eight --
 // and six computing waves.  512 MiB of IQ in 104-108 us where the single-wave grid (k_decimate<32,212,64>) takes 118-123.
-template <int T>
-__global__ __launch_bounds__(1024) void k_stage1_cu(const RingArgs ra, const uint32_t n_loaders)
+template <int T, int D>
+__global__ __launch_bounds__(D == 32 ? 1024 : 512) void k_stage1_cu(const RingArgs ra, const uint32_t n_loaders)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char cu_lds[];
     unsigned char* ring = cu_lds;
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(1024) void k_stage1_cu(const RingArgs ra, const uin
     }
     const RingGeom geom{ring, (uint32_t)kRingNSLAlone * (3u - n_loaders), nullptr, 0u, 0u, n_loaders};
     if (w < n_loaders) ring_loader<T>(ra, geom, ctl, w);
-    else ring_consumer<T>(ra, geom, ctl, w == 2, w);
+    else ring_consumer<T, D>(ra, geom, ctl, w == 2, w);
 }
 
 // XCC ids seen by a grid of single-wave workgroups: the run counters of the step launches are per XCD and indexed by the hardware's id
@@ -753,7 +753,10 @@ static void launch_one(hipStream_t st, uint32_t n_streams, uint32_t max_out, con
     uint32_t per = 1;
     while (per < 16 && (uint64_t)((ntiles + 2 * per - 1) / (2 * per)) * n_streams >= 2048) per *= 2;
     dim3 grid((ntiles + per - 1) / per, n_streams);
-    hipLaunchKernelGGL((k_decimate<D, T, TO>), grid, dim3(TO), 0, st, in, in_stride, hist_in, hist_out, taps, out, out_stride, call,
+    // (extra dynamic LDS lowers how many of these workgroups a CU takes -- room for the other queue's kernels; HD_DEC_LDS_PAD, first stages only)
+    static const uint32_t pad_env = getenv("HD_DEC_LDS_PAD") ? (uint32_t)atoi(getenv("HD_DEC_LDS_PAD")) : 0u;
+    const uint32_t pad = (stage == 0 && !final_stage) ? pad_env : 0u;
+    hipLaunchKernelGGL((k_decimate<D, T, TO>), grid, dim3(TO), pad, st, in, in_stride, hist_in, hist_out, taps, out, out_stride, call,
                        stage, final_stage, fir_hist_cap, per, fft_in, n_streams, 0u, (StreamCall*)nullptr, 0u, StepClaim{});
 }
 
@@ -830,28 +833,33 @@ bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2
     return false;
 }
 
+bool stage1_cu_supported(int ratio, int ntaps)
+{
+    return (ratio == 32 && (ntaps == 212 || ntaps == 174)) || (ratio == 8 && ntaps == 54);
+}
+
 bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, const float2* in, size_t in_stride, const float2* hist_in, float2* hist_out,
                       const float* taps, float2* out, size_t out_stride, uint32_t uniform_n, const StepClaim& claim, unsigned int* gave_up, uint32_t n_loaders, uint32_t n_waves)
 {
     if (n_loaders != 1u) n_loaders = 2u;
     if (n_waves < 8u || n_waves > 16u) n_waves = 8u;
-    if (ratio != 32 || !claim.ctr || !uniform_n || uniform_n % 2048u) return false;
+    if (!claim.ctr || !uniform_n || uniform_n % 2048u) return false;
     RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, uniform_n / 2048u, claim, gave_up};
-#define HD_S1_CASE(T)                                                                                                                 \
-    if (ntaps == T) {                                                                                                                 \
+#define HD_S1_CASE(D, T)                                                                                                              \
+    if (ratio == D && ntaps == T) {                                                                                                   \
         constexpr uint32_t lds = (uint32_t)ring_bytes<T, kRingNSLAlone>();                                                            \
         static_assert(lds <= 163840u, "eight tile slots must fit a CU's LDS");                                                        \
         static bool attr_set[64] = {};                                                                                                \
         int dev_ = 0;                                                                                                                 \
         if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return false;                                                \
         if (!attr_set[dev_]) {                                                                                                        \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_stage1_cu<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) return false; \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_stage1_cu<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) return false; \
             attr_set[dev_] = true;                                                                                                    \
         }                                                                                                                             \
-        hipLaunchKernelGGL((k_stage1_cu<T>), dim3(n_cus), dim3(64u * n_waves), lds, st, ra, n_loaders);                                                    \
+        hipLaunchKernelGGL((k_stage1_cu<T, D>), dim3(n_cus), dim3(64u * (D == 32 ? n_waves : 8u)), lds, st, ra, n_loaders);           \
         return true;                                                                                                                  \
     }
-    HD_S1_CASE(212) HD_S1_CASE(174)
+    HD_S1_CASE(32, 212) HD_S1_CASE(32, 174) HD_S1_CASE(8, 54)
 #undef HD_S1_CASE
     return false;
 }

@@ -355,7 +355,7 @@ __device__ __forceinline__ void ring_mac16_asm(r_f32x2& acc, const r_f32x4 (&x)[
 #undef HD_ADD
 }
 
-template <int T>
+template <int T, int D = 32>
 __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom& geo, RingCtl* __restrict__ ctl, const bool feeder,
                                               const uint32_t role /* the wave's role number in the workgroup (diagnostic builds: its row in the stamp table) */)
 {
@@ -364,7 +364,8 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
     constexpr int JS = HR * 32 - (T - 1);           // slot of tap 0, counted from column 0 of the lane's first row
     constexpr int NS = JS + T;                      // taps sit on slots [JS, NS)
     constexpr int C0 = JS / 16, C1 = (NS - 1) / 16; // first and last 16-slot chunk that carries taps
-    static_assert(C1 - C0 >= 3, "filter shorter than four chunks");
+    static_assert(D != 32 || C1 - C0 >= 3, "filter shorter than four chunks");
+    static_assert(D == 32 || D == 16 || D == 8, "a lane's row of 32 samples is 32 / D outputs");
     const uint32_t lane = threadIdx.x & 63u;
     typedef const float __attribute__((address_space(4)))* ctaps_t;
     const ctaps_t taps = (ctaps_t)(uintptr_t)a.taps - JS;                                   // taps[slot]
@@ -438,6 +439,7 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
         const unsigned char* p = (slot < geo.nb ? geo.ring + (L * geo.nb + slot) * (uint32_t)SLOT : geo.extra + (L * geo.ne + slot - geo.nb) * geo.extra_stride) +
                                  lane * (uint32_t)kRingRowBytes;
 
+        if constexpr (D == 32) {
         // the T-term sum in tap order: 16-slot chunks (half rows), the next chunk's samples and taps requested before the current one is summed
         r_f32x2 acc = {0.f, 0.f};
         r_f32x4 xa[8], xb[8];
@@ -499,6 +501,56 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
             const float2* in_s = a.in + (size_t)s * a.in_stride;
             float2* hout = a.hist_out + (size_t)s * (T - 1);
             for (uint32_t j = lane; j < (uint32_t)(T - 1); j += 64u) hout[j] = in_s[a.n - (T - 1) + j];
+        }
+        } else {
+        // Smaller ratios: the lane's row of 32 samples is OPL = 32 / D adjacent outputs, output q taking the window that starts D * q
+        // slots further on -- OPL independent sums (each its own T products in ascending tap order), one pass over the lane's
+        // (OPL - 1) * D + T slots.  The filter is short here (54 taps at /8): every tap sits in a scalar register for the whole launch,
+        // and the chunk loop is unrolled with compile-time ranges (which taps of which output a 16-slot chunk carries).
+        constexpr int OPL = 32 / D;
+        constexpr int NSW = (OPL - 1) * D + T;          // slots a lane reads: [JS, JS + NSW)
+        constexpr int CW1 = (JS + NSW - 1) / 16;        // last chunk
+        static_assert(T <= 64, "the taps are held in scalar registers");
+        float k[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) k[t] = taps[JS + t];
+        r_f32x2 acc[OPL];
+#pragma unroll
+        for (int q = 0; q < OPL; ++q) acc[q] = (r_f32x2){0.f, 0.f};
+        r_f32x4 xw[2][8];
+        auto rdw = [&](r_f32x4 (&x)[8], const int c) {
+            const unsigned char* pc = p + coff(c);
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) x[q8] = *reinterpret_cast<const r_f32x4*>(pc + 16 * q8);
+        };
+        rdw(xw[0], C0);
+        if constexpr (CW1 > C0) rdw(xw[1], C0 + 1);
+#pragma unroll
+        for (int c = C0; c <= CW1; ++c) {
+            const r_f32x4 (&x)[8] = xw[(c - C0) & 1];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int slot = 16 * c + j;
+                const r_f32x2 smp = (j & 1) ? x[j >> 1].zw : x[j >> 1].xy;
+#pragma unroll
+                for (int q = 0; q < OPL; ++q) {
+                    const int t = slot - JS - D * q;
+                    if (t >= 0 && t < T) acc[q] = acc[q] + smp * k[t];
+                }
+            }
+            if (c + 2 <= CW1) rdw(xw[(c - C0) & 1], c + 2);
+        }
+        RSTAMP(1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&ctl->slot_done[4u * L + slot], seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        float2* dst = a.out + (size_t)s * a.out_stride + ((size_t)tile * 64u + lane) * OPL;      // (16-byte aligned: the stride is even)
+#pragma unroll
+        for (int q = 0; q < OPL; q += 2) *reinterpret_cast<float4*>(dst + q) = make_float4(acc[q].x, acc[q].y, acc[q + 1].x, acc[q + 1].y);
+        if (tile + 1 == a.ntiles) {                 // the stream's last tile: carry the last T-1 inputs (Decimator.h:140-143)
+            const float2* in_s = a.in + (size_t)s * a.in_stride;
+            float2* hout = a.hist_out + (size_t)s * (T - 1);
+            for (uint32_t j = lane; j < (uint32_t)(T - 1); j += 64u) hout[j] = in_s[a.n - (T - 1) + j];
+        }
         }
     }
 }

@@ -6,7 +6,7 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k(unsigned long long* out, float seed, int iters)
+__global__ __launch_bounds__(1024) void k(unsigned long long* out, float seed, int iters)
 {
     f32x2 a0 = {seed, seed + 1}, a1 = {seed + 2, seed + 3}, a2 = {seed + 4, seed + 5}, a3 = {seed + 6, seed + 7};
     f32x2 x0 = {1.0f + seed, 1.00001f}, x1 = {0.5f, seed}, x2 = {seed, 2.f}, x3 = {3.f, seed};
@@ -78,10 +78,19 @@ void run(const char* name, int per_iter_instrs)
     unsigned long long* d; hipMalloc(&d, 16);
     for (int threads : {64, 256, 512, 1024}) {    // 1 wave on one SIMD; 1, 2, 4 waves per SIMD (one workgroup per CU)
         const int iters = 2000;
-        k<MODE><<<256, threads>>>(d, 0.001f, iters); hipDeviceSynchronize();
-        k<MODE><<<256, threads>>>(d, 0.001f, iters); hipDeviceSynchronize();
-        unsigned long long c; hipMemcpy(&c, d, 8, hipMemcpyDeviceToHost);
-        printf("%-44s %4d threads/CU: %6.2f cycles per instruction per wave\n", name, threads, (double)c / ((double)iters * 8 * per_iter_instrs));
+        (void)hipMemset(d, 0, 16);
+        k<MODE><<<256, threads>>>(d, 0.001f, iters); (void)hipDeviceSynchronize();
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, 0);
+        k<MODE><<<256, threads>>>(d, 0.001f, iters);
+        (void)hipEventRecord(e1, 0); (void)hipDeviceSynchronize();
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        const hipError_t err = hipGetLastError();
+        unsigned long long c; (void)hipMemcpy(&c, d, 8, hipMemcpyDeviceToHost);
+        // wall clock: instructions one SIMD executed = iters * 8 * per_iter * (waves per SIMD)
+        const double wps = threads >= 256 ? threads / 256.0 : 1.0;
+        printf("%-44s %4d threads/CU: %6.2f s_memtime ticks per instruction per wave | kernel %.3f ms -> %.2f ns per instruction per SIMD (%s)\n", name, threads,
+               (double)c / ((double)iters * 8 * per_iter_instrs), ms, ms * 1e6 / ((double)iters * 8 * per_iter_instrs * wps), hipGetErrorString(err));
     }
     hipFree(d);
 }
