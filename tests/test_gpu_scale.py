@@ -186,11 +186,14 @@ def test_linear_split_and_step_kernels_of_the_other_single_wave_stages(monkeypat
     eng.close()
 
 
-@pytest.mark.parametrize("factor,fs,ungated", [(16, 2.5e6, False), (4, 2.048e6, True)])
-def test_classic_grids_of_the_256_lane_first_stages_at_1024_streams(factor, fs, ungated):
-    """/16 (<8,54,256> + <2,69,256>) and /4 (<4,139,256>) at the batch size the bench uses: 1024 streams x 65536 samples per call, every
-    stream its own delayed copy of one signal, sampled streams against the oracle bit for bit."""
+@pytest.mark.parametrize("factor,fs,ungated,per_cu", [(16, 2.5e6, False, True), (16, 2.5e6, False, False), (4, 2.048e6, True, False)])
+def test_first_stages_of_the_small_ratios_at_1024_streams(monkeypatch, factor, fs, ungated, per_cu):
+    """/16 (/8 54 taps -- as k_stage1_cu<54,8>, one workgroup per CU, and as the classic grid k_decimate<8,54,256> -- + <2,69,256>) and
+    /4 (<4,139,256>) at the batch size the bench uses: 1024 streams x 65536 samples per call, every stream its own delayed copy of one
+    signal, sampled streams against the oracle bit for bit."""
     torch = pytest.importorskip("torch")
+    if factor == 16 and not per_cu:
+        monkeypatch.setenv("HD_NO_CU_STEP", "1")
     import habdec_amd
     from oracle import pyoracle
     S = 1024
@@ -214,6 +217,7 @@ def test_classic_grids_of_the_256_lane_first_stages_at_1024_streams(factor, fs, 
             assert same_bits(eng.demodulated(s), o.array("last_demod")), (k, s)
             assert np.array_equal(eng.bits(s), o.bits()), (k, s)
             assert eng.symbol_backlog(s) == o.symex_held(), (k, s)
+    assert eng.timing()["step_variant"] == (1 if per_cu else 0)
     eng.close()
 
 
