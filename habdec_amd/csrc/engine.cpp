@@ -392,6 +392,10 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         // [0, n_cus / 32) must show up in a chip-filling grid and no other may.  A CU mask or a partition mode that breaks that
         // turns the draws off (fixed shares: slower, never wrong).
         const uint32_t n_xcd = e->n_cus / 32u;
+        // (the allocations above clear their memory on the null stream, which a non-blocking stream does not wait for: without this
+        // the clearing of step_ctr could land on top of the probe's answer -- seen in one test run of three as a silent fall-back to
+        // fixed shares)
+        HD_HIP(hipDeviceSynchronize());
         const uint32_t seen = hd::probe_xcc_mask(e->qa, e->n_cus, e->step_ctr.p + 2 * 16 * 32);
         if (n_xcd > 16 || seen != (n_xcd >= 32 ? 0xFFFFFFFFu : (1u << n_xcd) - 1u)) e->no_claim = true;
     } else

@@ -320,7 +320,7 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
         if constexpr (OPL == 1 && D >= 32 && (D % 16) == 0) {
             // Single-wave first stages (/32, /64): 16-slot chunks (never across a row pad), the next chunk's LDS reads and taps requested
             // before the current chunk is summed (two register images, rolled loop over chunk pairs), products ahead of the adds.
-            constexpr int CH = 16, LA = HD_DEC_LA;
+            constexpr int CH = 16;
             constexpr int NS = T + JS;                          // slots [JS, NS) carry taps [0, T)
             constexpr int NCH = NS / CH;                        // full chunks; chunk 0 starts at slot JS
             static_assert(NCH >= 3, "filter shorter than three chunks");
@@ -523,7 +523,7 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
 }
 
 template <int D, int T, int TO>
-__global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_decimate(const float2* __restrict__ in, size_t in_stride,
+__global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(D == 64 ? 1 : 2, 2))) void k_decimate(const float2* __restrict__ in, size_t in_stride,
                                                    const float2* __restrict__ hist_in, float2* __restrict__ hist_out,
                                                    const float* __restrict__ taps,
                                                    float2* __restrict__ out, size_t out_stride,
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // and finish after a fraction of the launch, the hardware dispatcher hands their slots to stage-1 workgroups as they free up, and the
 // HBM-bound stage-1 waves that are resident from the start keep the memory system busy meanwhile.  No second queue, no event waits.
 template <int D, int T, int D2, int T2>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_step(const float2* __restrict__ in, size_t in_stride,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 64 ? 1 : 2, 2))) void k_step(const float2* __restrict__ in, size_t in_stride,
                                                    const float2* __restrict__ hist_in, float2* __restrict__ hist_out,
                                                    const float* __restrict__ taps,
                                                    float2* __restrict__ out, size_t out_stride,
@@ -571,10 +571,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                             blockIdx.x - n_tail, 0u, gridDim.x - n_tail, tile4, uniform_n, claim);
 }
 
-// The step launch as ONE workgroup per CU (512 threads, all of the CU's LDS), roles by wave: waves 0-1 stream this call's stage-1 tiles
-// into LDS slots with LDS-DMA, waves 2-3 compute them (stage1_ring.h), waves 4-7 run the previous call's stream tails -- four
-// streams per CU at 1024 streams, each in its own slice of LDS -- leave the device copy of their streams' parameter blocks for the
-// next launch, and then join the computing waves.  Compared with k_step (single-wave workgroups, dispatcher-scheduled) the loads of stage 1 never stop
+// The step launch as ONE workgroup per CU (512 threads, all of the CU's LDS), roles by wave: role 0 (and role 1 with two loaders) streams
+// this call's stage-1 tiles into LDS slots with LDS-DMA, roles up to 3 compute them (stage1_ring.h), roles 4-7 run the previous call's
+// stream tails -- four streams per CU at 1024 streams, each in its own slice of LDS -- leave the device copy of their streams' parameter
+// blocks for the next launch, and then join the computing waves.  Compared with k_step (single-wave workgroups, dispatcher-scheduled) the loads of stage 1 never stop
 // while the tails hold half of the CU's wave slots, and what runs where does not depend on the dispatcher.
 template <int T, int D2, int T2>
 __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const StreamCall* __restrict__ call, StreamCall* __restrict__ call_copy,

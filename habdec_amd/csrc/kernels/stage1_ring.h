@@ -6,9 +6,9 @@
 // In the single-wave stage-1 workgroup (decimate_body) a wave is EITHER issuing the next tile's loads OR computing: its tile time is the
 // sum of an issue burst, the data's flight, an LDS store pass and the tap loop, the tile in flight sits in 72 VGPRs, and beside the
 // stream tails of a step launch -- which hold half of a CU's wave slots for the first half of the launch -- the four stage-1 waves left
-// on a CU pull a third of the CU's share of HBM.  Here TWO waves per CU do nothing but keep loads in flight: LDS-DMA
-// (global_load_lds_dwordx4: 64 lanes x 16 bytes straight into LDS, no VGPR destination, no ds_write) into two tile slots each, a tile
-// issued as soon as its slot is free and published through an LDS word once the wave's vector-memory counter says it has landed
+// on a CU pull a third of the CU's share of HBM.  Here ONE wave per CU (two: RingGeom::nl) does nothing but keep loads in flight: LDS-DMA
+// (global_load_lds_dwordx4: 64 lanes x 16 bytes straight into LDS, no VGPR destination, no ds_write) into its tile slots, a tile
+// issued as soon as a slot is free and published through an LDS word once the wave's vector-memory counter says it has landed
 // (tools/micro/loader_bw.hip: one such wave per CU streams 5.5 TB/s over the chip, two 6.2); the other waves take published tiles in
 // order and spend their time in the tap loop.  Loads in flight no longer depend on what the computing waves are doing, and a tile in
 // flight costs no registers.
@@ -22,12 +22,12 @@
 // first output's stride) are two more -- or, for a stream's first tile, HR dword-wide LDS-DMA rows out of the stage history, whose
 // samples sit at odd 8-byte offsets.
 //
-// Protocol (LDS words, RingCtl).  Loader L (0, 1) numbers its tiles l = 0, 1, ... and puts tile l into its slot l & 1: it waits until
-// slot_done says the consumer of tile l - 2 is finished, writes desc = (stream, tile), issues the DMA, and bumps landed[L] when
-// IB_STS.VM_CNT shows the tile has arrived.  Consumers draw g = taken++ (tile g >> 1 of loader g & 1), sleep until it is published,
-// compute, and store l + 1 into slot_done.  Runs of tiles come from the per-XCD counters of the step launches (StepClaim, launch.h):
-// the first consumer wave draws them -- a returning atomic, which a wave without DMA in flight can simply wait for -- and feeds both
-// loaders through run_q.  end[L] tells consumers how many tiles a loader had in all.  No s_barrier after the start: the stream tails in
+// Protocol (LDS words, RingCtl).  Loader L numbers its tiles l = 0, 1, ... and puts tile l into any of its slots that is free (never
+// used, or slot_done says the consumer of the tile last put there is finished), writes desc = (stream, tile, slot, l), issues the DMA,
+// and bumps landed[L] when IB_STS.VM_CNT shows the tile has arrived.  Consumers draw g = taken++ (with two loaders: tile g >> 1 of
+// loader g & 1), sleep until it is published, compute, and store l + 1 into slot_done.  Runs of tiles come from the per-XCD counters of the step launches (StepClaim, launch.h):
+// the first consumer wave draws them -- a returning atomic, which a wave without DMA in flight can simply wait for -- and feeds the
+// loader(s) through run_q.  end[L] tells consumers how many tiles a loader had in all.  No s_barrier after the start: the stream tails in
 // the workgroup's other waves never take part; every wait is bounded and reported (RingArgs::gave_up).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -371,7 +371,9 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
     const ctaps_t taps = (ctaps_t)(uintptr_t)a.taps - JS;                                   // taps[slot]
     auto coff = [](int c) { return (c >> 1) * kRingRowBytes + (c & 1) * 128; };
     RSTAMP_DECL;
+#ifdef HD_STAMP_RING
     uint32_t n_done = 0;
+#endif
     const uint32_t my_wave = role; (void)my_wave;
     // The feeding consumer also draws the runs for both loaders from this XCD's counter (StepClaim, launch.h) -- a returning atomic the
     // compiler counts and waits for, which a wave without DMA in flight can afford -- and keeps two of them ready in ctl->run_q.
