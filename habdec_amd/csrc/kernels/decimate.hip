@@ -31,15 +31,22 @@
 #define HD_DEC_LA 4        // products this many taps ahead of the sum in the single-wave first stages
 #endif
 
+#ifndef HD_DEC_MAXW
+#define HD_DEC_MAXW 4     // most waves per SIMD the 256-lane stages are compiled for (their registers and LDS decide what they get: 3-4)
+#endif
+
 namespace hd {
 
-#ifdef HD_STAMP_DEC   // diagnostic build only (tools/micro/dec_stamps.py): phase clocks of the D = 32 kernel, per workgroup
+#ifdef HD_STAMP_DEC   // diagnostic build only (tools/micro/dec_stamps.py): phase clocks of the D = HD_STAMP_DEC_D (default 32) kernel, per workgroup
+#ifndef HD_STAMP_DEC_D
+#define HD_STAMP_DEC_D 32
+#endif
 __device__ unsigned long long g_dec_stamps[4096 * 8];
 extern "C" void hd_debug_dec_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dec_stamps), n * 8); }
 #define DSTAMP_DECL unsigned long long ds_t = __builtin_amdgcn_s_memtime(), ds_acc[4] = {0, 0, 0, 0}; const unsigned long long ds_r0 = __builtin_amdgcn_s_memrealtime(); unsigned long long ds_r1 = 0
-#define DSTAMP(i) do { if (D == 32) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ds_acc[i] += t_ - ds_t; ds_t = t_; } } while (0)
-#define DSTAMP_ARRIVED() do { if (D == 32) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DSTAMP(0); if (!ds_r1) ds_r1 = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#define DSTAMP_WRITE() do { if (D == 32 && threadIdx.x == 0) { const uint32_t w_ = by * gdx + bx; if (w_ < 4096) { \
+#define DSTAMP(i) do { if (D == HD_STAMP_DEC_D) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ds_acc[i] += t_ - ds_t; ds_t = t_; } } while (0)
+#define DSTAMP_ARRIVED() do { if (D == HD_STAMP_DEC_D) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DSTAMP(0); if (!ds_r1) ds_r1 = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define DSTAMP_WRITE() do { if (D == HD_STAMP_DEC_D && threadIdx.x == 0) { const uint32_t w_ = by * gdx + bx; if (w_ < 4096) { \
         unsigned long long* g_ = g_dec_stamps + w_ * 8; g_[0] = ds_r0; g_[1] = ds_r1; g_[2] = __builtin_amdgcn_s_memrealtime(); \
         g_[3] = ds_acc[0]; g_[4] = ds_acc[1]; g_[5] = ds_acc[2]; g_[6] = ds_acc[3]; g_[7] = count; } } } while (0)
 #else
@@ -523,7 +530,7 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
 }
 
 template <int D, int T, int TO>
-__global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(D == 64 ? 1 : 2, 2))) void k_decimate(const float2* __restrict__ in, size_t in_stride,
+__global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(D == 64 ? 1 : 2, TO == 64 ? 2 : HD_DEC_MAXW))) void k_decimate(const float2* __restrict__ in, size_t in_stride,
                                                    const float2* __restrict__ hist_in, float2* __restrict__ hist_out,
                                                    const float* __restrict__ taps,
                                                    float2* __restrict__ out, size_t out_stride,
@@ -752,6 +759,8 @@ static void launch_one(hipStream_t st, uint32_t n_streams, uint32_t max_out, con
     // 256 CUs x ~4 resident workgroups; keep >= ~2048 workgroups when the batch allows it.
     uint32_t per = 1;
     while (per < 16 && (uint64_t)((ntiles + 2 * per - 1) / (2 * per)) * n_streams >= 2048) per *= 2;
+    static const uint32_t per_env = getenv("HD_DEC_PER") ? (uint32_t)atoi(getenv("HD_DEC_PER")) : 0u;    // (experiments: tiles per workgroup of the classic grid)
+    if (per_env) per = per_env;
     dim3 grid((ntiles + per - 1) / per, n_streams);
     // (extra dynamic LDS lowers how many of these workgroups a CU takes -- room for the other queue's kernels; HD_DEC_LDS_PAD, first stages only)
     static const uint32_t pad_env = getenv("HD_DEC_LDS_PAD") ? (uint32_t)atoi(getenv("HD_DEC_LDS_PAD")) : 0u;

@@ -36,7 +36,7 @@ def headline_ring():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("shares", ["drawn", "drawn2", "fixed", "deep", "rocfft", "single_wave", "regs_run4"])
+@pytest.mark.parametrize("shares", ["drawn", "drawn2", "fixed", "deep", "rocfft", "single_wave", "regs_run4", "two_loaders"])
 def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, shares):
     """shares: which step kernel serves the batch and how its stage-1 tiles are handed out -- k_step_cu (one workgroup per CU: LDS-DMA loader
     waves + computing waves, runs of eight tiles drawn from per-XCD counters: the default; "regs_run4": runs of four), or the single-wave
@@ -54,6 +54,8 @@ def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, s
         monkeypatch.setenv("HD_NO_CU_STEP", "1")
     if shares == "regs_run4":                                # k_step_cu with four-tile runs (more run changes, more halo rows out of the history path)
         monkeypatch.setenv("HD_RING_RUN", "4")
+    if shares == "two_loaders":                              # k_step_cu with an LDS-DMA wave on SIMD 0 and on SIMD 1, two slots each (the default is one loader)
+        monkeypatch.setenv("HD_RING_LOADERS", "2")
     w, ring, ring_chunks = headline_ring
     S, fs = w["S"], w["fs"]
     # 7/8 of the streams are within +-200 Hz, every 8th is far off: sample both kinds (and the first / last stream of XCD blocks)
@@ -117,7 +119,7 @@ def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, s
     eng.close()
 
 
-@pytest.mark.parametrize("kernel", ["per_cu", "single_wave_drawn", "single_wave"])
+@pytest.mark.parametrize("kernel", ["per_cu", "per_cu_two_loaders_12_waves", "single_wave_drawn", "single_wave"])
 def test_stage1_alone_at_full_size(monkeypatch, headline_ring, kernel):
     """Synchronous calls (what the Decoder facade makes): stage 1 as a launch of its own, then the stream tails.  "per_cu": one workgroup per CU
     with LDS-DMA loader waves, eight tile slots and six computing waves (k_stage1_cu, the default for a /32 first stage); "single_wave_drawn":
@@ -125,8 +127,11 @@ def test_stage1_alone_at_full_size(monkeypatch, headline_ring, kernel):
     covered); "single_wave": k_decimate with fixed shares."""
     import habdec_amd
     from oracle import pyoracle
-    if kernel != "per_cu":
+    if not kernel.startswith("per_cu"):
         monkeypatch.setenv("HD_NO_CU_STEP", "1")
+    if kernel == "per_cu_two_loaders_12_waves":
+        monkeypatch.setenv("HD_S1_LOADERS", "2")
+        monkeypatch.setenv("HD_S1_WAVES", "12")
     if kernel == "single_wave_drawn":
         monkeypatch.setenv("HD_CLAIM_ALONE", "1")
     w, ring, ring_chunks = headline_ring
@@ -142,7 +147,7 @@ def test_stage1_alone_at_full_size(monkeypatch, headline_ring, kernel):
             assert same_bits(eng.decimated(s), o.array("last_decimated")), ("decimated", k, s)
             assert same_bits(eng.demodulated(s), o.array("last_demod")), ("demod", k, s)
             assert np.array_equal(eng.bits(s), o.bits()), ("bits", k, s)
-    assert eng.timing()["path"] == 2 and eng.timing()["step_variant"] == (1 if kernel == "per_cu" else 0)
+    assert eng.timing()["path"] == 2 and eng.timing()["step_variant"] == (1 if kernel.startswith("per_cu") else 0)
     eng.close()
 
 

@@ -1,10 +1,11 @@
 import sys, ctypes, numpy as np
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import torch, bench, habdec_amd
-w = dict(bench.WORKLOADS["cfg4"]); S = 1024; C = w["C"]
+import os
+w = dict(bench.WORKLOADS[os.environ.get("WL", "cfg4")]); S = 1024; C = w["C"]
 dev = torch.device("cuda", 0)
 ring = torch.randn((8, S, C, 2), device=dev) * 0.3
-eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"])
+eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"], lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"])
 eng.set_timing(1)
 L = habdec_amd.lib(); f = L.hd_debug_dec_stamps; f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 for i in range(12):
