@@ -134,27 +134,25 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
         const uint32_t nblk = T / 16u;
         fd_f32x4 w[10], wn[10];
         float k[16], kn[16];
-        if (nblk) {
+        auto load_block = [&](fd_f32x4 (&ww)[10], float (&kk)[16], const uint32_t b) {
+            const fd_f32x4* pn = p + 8u * b;
 #pragma unroll
-            for (int i = 0; i < 10; ++i) w[i] = p[i];
+            for (int i = 0; i < 10; ++i) ww[i] = pn[i];
+            const ctaps_t tn = tp + 16u * b;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) k[j] = tp[j];
-        }
-        for (uint32_t b = 0; b < nblk; ++b) {
-            if (b + 1 < nblk) {
-                const fd_f32x4* pn = p + 8u * (b + 1u);
-#pragma unroll
-                for (int i = 0; i < 10; ++i) wn[i] = pn[i];
-                const ctaps_t tn = tp + 16u * (b + 1u);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) kn[j] = tn[j];
-            }
+            for (int j = 0; j < 16; ++j) kk[j] = tn[j];
+        };
+        if (nblk) load_block(w, k, 0u);
+        // two blocks per trip, the two register images taking turns: the block after next is requested into the image just used up, so
+        // nothing is copied between trips (a one-block loop moved ten 16-byte pairs and sixteen taps per 128 packed operations)
+        uint32_t b = 0;
+        for (; b + 2u <= nblk; b += 2u) {
+            load_block(wn, kn, b + 1u);
             fir_block16(acc, w, k);
-#pragma unroll
-            for (int i = 0; i < 10; ++i) w[i] = wn[i];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) k[j] = kn[j];
+            load_block(w, k, b + 2u < nblk ? b + 2u : nblk - 1u);      // (unconditional: the last trip re-reads the last block, unused)
+            fir_block16(acc, wn, kn);
         }
+        if (b < nblk) fir_block16(acc, w, k);                       // an odd count: the last block sits in the first image
         for (uint32_t t = nblk * 16u; t < T; ++t) {                 // the taps behind the last whole block, one at a time
             const float kt = tp[t];
             const float2* x = lds + (uint32_t)kFirOut * threadIdx.x + t;

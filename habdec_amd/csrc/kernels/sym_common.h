@@ -51,16 +51,24 @@ __device__ __forceinline__ void window_sums(const float* __restrict__ w, uint32_
         a01 = a01 + (f32x2){x.w, x.w}; a23 = a23 + (f32x2){x.w, x.w};
     }
     uint32_t e = 4;
-    float4 x = *reinterpret_cast<const float4*>(w + 4);    // one chunk ahead: the next 16-byte read is in flight during the adds
-    for (; e + 4 <= R; e += 4) {                            // interior: every element feeds all four
-        const float4 nx = *reinterpret_cast<const float4*>(w + e + 4);   // (callers pad their windows: a chunk past the last one is readable)
-        __builtin_amdgcn_sched_barrier(0);
+    // one chunk ahead: the next 16-byte read is in flight during the adds; two register images take turns (two chunks per trip), so no
+    // chunk is copied from "next" to "current" between trips
+    auto feed4 = [&](const float4 x) {                      // interior: every element feeds all four
         a01 = a01 + (f32x2){x.x, x.x}; a23 = a23 + (f32x2){x.x, x.x};
         a01 = a01 + (f32x2){x.y, x.y}; a23 = a23 + (f32x2){x.y, x.y};
         a01 = a01 + (f32x2){x.z, x.z}; a23 = a23 + (f32x2){x.z, x.z};
         a01 = a01 + (f32x2){x.w, x.w}; a23 = a23 + (f32x2){x.w, x.w};
-        x = nx;
+    };
+    float4 xa = *reinterpret_cast<const float4*>(w + 4), xb;
+    for (; e + 8 <= R; e += 8) {                            // xa holds elements e .. e+3
+        xb = *reinterpret_cast<const float4*>(w + e + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        feed4(xa);
+        xa = *reinterpret_cast<const float4*>(w + e + 8);  // (callers pad their windows: a chunk past the last one is readable)
+        __builtin_amdgcn_sched_barrier(0);
+        feed4(xb);
     }
+    if (e + 4 <= R) { feed4(xa); e += 4; }
     float acc0 = a01.x, acc1 = a01.y, acc2 = a23.x, acc3 = a23.y;
     for (; e < total; e += 4) {                             // tail chunks: element e+u feeds accumulators with e+u < j + R
         const float4 x = *reinterpret_cast<const float4*>(w + e);
@@ -98,16 +106,22 @@ __device__ __forceinline__ void window_sums8(const float* __restrict__ w, uint32
         }
         f32x2 a01 = {s[0], s[1]}, a23 = {s[2], s[3]}, a45 = {s[4], s[5]}, a67 = {s[6], s[7]};
         uint32_t e = 8;
-        float4 x = w4[2];
-        for (; e + 4 <= R; e += 4) {                        // interior: every element feeds all eight
-            const float4 nx = w4[(e >> 2) + 1];
-            __builtin_amdgcn_sched_barrier(0);
+        auto feed8 = [&](const float4 x) {                  // interior: every element feeds all eight
             a01 = a01 + (f32x2){x.x, x.x}; a23 = a23 + (f32x2){x.x, x.x}; a45 = a45 + (f32x2){x.x, x.x}; a67 = a67 + (f32x2){x.x, x.x};
             a01 = a01 + (f32x2){x.y, x.y}; a23 = a23 + (f32x2){x.y, x.y}; a45 = a45 + (f32x2){x.y, x.y}; a67 = a67 + (f32x2){x.y, x.y};
             a01 = a01 + (f32x2){x.z, x.z}; a23 = a23 + (f32x2){x.z, x.z}; a45 = a45 + (f32x2){x.z, x.z}; a67 = a67 + (f32x2){x.z, x.z};
             a01 = a01 + (f32x2){x.w, x.w}; a23 = a23 + (f32x2){x.w, x.w}; a45 = a45 + (f32x2){x.w, x.w}; a67 = a67 + (f32x2){x.w, x.w};
-            x = nx;
+        };
+        float4 xa = w4[2], xb;                              // two images taking turns, one chunk ahead (no copies between trips)
+        for (; e + 8 <= R; e += 8) {                        // xa holds elements e .. e+3
+            xb = w4[(e >> 2) + 1];
+            __builtin_amdgcn_sched_barrier(0);
+            feed8(xa);
+            xa = w4[(e >> 2) + 2];
+            __builtin_amdgcn_sched_barrier(0);
+            feed8(xb);
         }
+        if (e + 4 <= R) { feed8(xa); e += 4; }
         s[0] = a01.x; s[1] = a01.y; s[2] = a23.x; s[3] = a23.y; s[4] = a45.x; s[5] = a45.y; s[6] = a67.x; s[7] = a67.y;
         for (; e < R; ++e) {                                // R % 4 elements that still feed all eight
             const float xe = w[e];
