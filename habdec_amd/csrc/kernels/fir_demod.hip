@@ -20,6 +20,19 @@
 
 namespace hd {
 
+#ifdef HD_STAMP_FIR   // diagnostic build only (tools/micro/fir_stamps.py): per-workgroup clocks of k_fir_demod
+__device__ unsigned long long g_fir_stamps[8192 * 8];
+extern "C" void hd_debug_fir_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fir_stamps), n * 8); }
+#define FSTAMP_DECL unsigned long long fs_t = __builtin_amdgcn_s_memtime(), fs_acc[4] = {0, 0, 0, 0}; const unsigned long long fs_r0 = __builtin_amdgcn_s_memrealtime()
+#define FSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); fs_acc[i] += t_ - fs_t; fs_t = t_; } while (0)
+#define FSTAMP_WRITE() do { const uint32_t w_ = blockIdx.y * gridDim.x + blockIdx.x; if (threadIdx.x == 64 && w_ < 8192) { unsigned long long* g_ = g_fir_stamps + w_ * 8; \
+        g_[0] = fs_r0; g_[1] = __builtin_amdgcn_s_memrealtime(); for (int i_ = 0; i_ < 4; ++i_) g_[2 + i_] = fs_acc[i_]; g_[6] = 1; } } while (0)
+#else
+#define FSTAMP_DECL do { } while (0)
+#define FSTAMP(i) do { } while (0)
+#define FSTAMP_WRITE() do { } while (0)
+#endif
+
 constexpr int kFirLanes = 256;
 constexpr int kFirOut = 4;                       // adjacent outputs per lane
 constexpr int kFirTile = kFirOut * kFirLanes;    // outputs computed per tile
@@ -59,6 +72,7 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
 {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];   // [kFirTile + T + kFirSlack] inputs, then reused for outputs
     const uint32_t s = blockIdx.y;
+    FSTAMP_DECL;
     const StreamCall c = call[s];
     const uint32_t m = c.fir_m, T = c.fir_taps;
     const uint32_t Tp = c.fir_taps_prev ? c.fir_taps_prev : T;     // tap count of the previous run
@@ -87,6 +101,7 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && m == 0) carry_out[s] = carry_in[s];   // idle stream: carry passes through
     if (!m || !T) return;
+    FSTAMP(0);
     const long i0 = (long)blockIdx.x * kFirAdvance - kFirOut;      // output index of lane 0's first output (may be -4)
     if (i0 + kFirOut >= (long)m) return;
     const long b0 = (long)fir_hist_cap - (long)(T - 1) + i0;       // buffer index of tile-local sample 0
@@ -119,6 +134,7 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
         for (int u = 0; u < LB; ++u) if (j0 + u * kFirLanes < need) lds[j0 + u * kFirLanes] = v[u];
     }
     __syncthreads();
+    FSTAMP(1);
 
     typedef const float __attribute__((address_space(4)))* ctaps_t;
     const ctaps_t tp = (ctaps_t)(uintptr_t)(taps + (size_t)s * taps_stride);   // per stream, wave-uniform: scalar loads
@@ -163,6 +179,7 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
             for (int q = 0; q < kFirOut; ++q) acc[q] = acc[q] + pr[q];
         }
     }
+    FSTAMP(2);
     __syncthreads();                       // everyone is done reading inputs: reuse LDS for the outputs
     if (active) {
         reinterpret_cast<float4*>(lds)[2u * threadIdx.x] = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
@@ -204,6 +221,8 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
         kc.re = y.x; kc.im = y.y;
         carry_out[s] = kc;
     }
+    FSTAMP(3);
+    FSTAMP_WRITE();
 }
 
 // Spectrum input collection (reference Decoder.h:467-473): append the HEAD of this call's decimated chunk.
