@@ -226,6 +226,45 @@ def test_first_stages_of_the_small_ratios_at_1024_streams(monkeypatch, factor, f
     eng.close()
 
 
+@pytest.mark.parametrize("factor,fs,S,CH,lowpass", [(16, 2.5e6, 8, 16384, 3000.0), (16, 2.5e6, 24, 4096, 3000.0), (64, 2.048e6, 8, 16384, None), (64, 2.048e6, 40, 4096, None), (64, 2.048e6, 3, 4096, None)])
+def test_per_cu_first_stage_with_few_tiles(factor, fs, S, CH, lowpass):
+    """k_stage1_cu with far fewer tiles than the chip has waves: a handful of streams and short pushes (8, 2 or 1 tile of 2048 samples per stream
+    and call, runs of 8, 2 or -- where even that does not divide among the XCDs -- the fall-back to the classic grid), most CUs finding no run at
+    all.  Synchronous calls, EVERY stream compared with the oracle after every call."""
+    torch = pytest.importorskip("torch")
+    import habdec_amd
+    from oracle import pyoracle
+    text = synth.make_sentence("FEW", "1,52.1,21.4,100")
+    iq1 = synth.fsk_iq_for_text(text, fs, 300, 8, 2, sigma=0.08, seed=41, idle_before=4, idle_after=6)
+    nch = min(6, (len(iq1) - 4096) // CH)
+    assert nch >= 4
+    shifts = (np.arange(S) * 97) % 4096
+    base = torch.from_numpy(np.ascontiguousarray(iq1).view(np.float32).reshape(-1, 2)).cuda()
+    slab = torch.empty((nch, S, CH, 2), dtype=torch.float32, device="cuda")
+    for s in range(S):
+        slab[:, s] = base[int(shifts[s]):int(shifts[s]) + nch * CH].view(nch, CH, 2)
+    kw = dict(lowpass_bw_hz=lowpass) if lowpass else {}
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=CH, sampling_rate=fs, decimation=factor, **kw)
+    orcs = [pyoracle.Decoder("oracle", factor=factor, lowpass_bw=lowpass) for _ in range(S)]
+    variants = []
+    for k in range(nch):
+        eng.process_device(slab[k].data_ptr(), CH, CH)
+        variants.append(eng.timing()["step_variant"])
+        for s, o in enumerate(orcs):
+            o(iq1[int(shifts[s]) + k * CH: int(shifts[s]) + (k + 1) * CH], fs)
+            assert same_bits(eng.decimated(s), o.array("last_decimated")), (k, s)
+            assert same_bits(eng.demodulated(s), o.array("last_demod")), (k, s)
+            assert np.array_equal(eng.bits(s), o.bits()), (k, s)
+    # the first call of a stream restarts its history (classic grid); after that the per-CU kernel serves every call whose tiles can be cut into
+    # runs of 8, 4 or 2 that divide evenly among the 8 XCDs (engine.cpp: make_claim) -- otherwise the classic grid stays
+    ntiles, run = CH // 2048, 8
+    while run > 2 and (ntiles % run or (S * ntiles // run) % 8):
+        run //= 2
+    per_cu = ntiles % run == 0 and (S * ntiles // run) % 8 == 0
+    assert variants[0] == 0 and all(v == (1 if per_cu else 0) for v in variants[1:]), (variants, per_cu)
+    eng.close()
+
+
 def test_two_engines_in_one_process_on_two_threads():
     """"one engine + HIP stream + host thread per device".  Two engines (different plans) fed concurrently by two host
     threads must give what the same engines give when run one after the other -- nothing in the library is shared between engines
