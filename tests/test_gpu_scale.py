@@ -292,8 +292,7 @@ def test_step_launches_with_few_tiles_or_more_streams_than_tail_waves(S, CH):
         for s in check:
             ci, n, c0, c1 = eng.demod_checksum(s)
             if ci in want and ci not in seen[s]:
-                # (no checksum where the tail did not serve the call: a call without discriminator output, and an engine's very first call,
-                # which is planned before the symbol parameters are known to the layout and runs the separate kernels)
+                # (no checksum: a call without discriminator output; and (0, None) is what the read-out says before anything was delivered)
                 if n is None and (want[ci][s][0] == 0 or ci == 0):
                     continue
                 assert (n, c0, c1) == want[ci][s], ("discriminator checksum", ci, s)
