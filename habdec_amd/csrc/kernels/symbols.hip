@@ -328,20 +328,22 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
             const float4* s4 = reinterpret_cast<const float4*>(sb);
             uint32_t i = 0;
             if (cnt >= 32) {
+                // 32 samples per block through wave-uniform 16-byte reads (broadcast), the next block in flight under this block's 32 adds; two
+                // register images take turns, so nothing is copied between blocks (one VALU move per add otherwise: the chain itself cannot get
+                // shorter, but its instructions compete with the other workgroups' window sums for the vector pipe)
                 float4 c[8], n[8];
+                auto ld = [&](float4 (&x)[8], const uint32_t at) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) c[u] = s4[u];                   // wave-uniform addresses: broadcast reads
-                for (; i + 64 <= cnt; i += 32) {
+                    for (int u = 0; u < 8; ++u) x[u] = s4[(at >> 2) + u];
+                };
+                auto adds = [&](const float4 (&x)[8]) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) n[u] = s4[((i + 32) >> 2) + u];   // next 32 samples in flight ...
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { acc = acc + c[u].x; acc = acc + c[u].y; acc = acc + c[u].z; acc = acc + c[u].w; }   // ... under these 32 adds
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) c[u] = n[u];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { acc = acc + c[u].x; acc = acc + c[u].y; acc = acc + c[u].z; acc = acc + c[u].w; }
-                i += 32;
+                    for (int u = 0; u < 8; ++u) { acc = acc + x[u].x; acc = acc + x[u].y; acc = acc + x[u].z; acc = acc + x[u].w; }
+                };
+                ld(c, 0u);                                                  // invariant: c holds samples [i, i + 32), i + 32 <= cnt
+                for (; i + 96 <= cnt; i += 64) { ld(n, i + 32); adds(c); ld(c, i + 64); adds(n); }
+                if (i + 64 <= cnt) { ld(n, i + 32); adds(c); adds(n); i += 64; }
+                else { adds(c); i += 32; }
             }
             for (; i < cnt; ++i) acc = acc + sb[i];
             __builtin_amdgcn_wave_barrier();

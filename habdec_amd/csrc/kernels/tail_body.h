@@ -793,20 +793,20 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
             const float4* s4 = reinterpret_cast<const float4*>(sb);
             uint32_t i = 0;
             if (cnt >= 32) {
+                // (two register images taking turns: no copy of the block in flight into the current one -- symbols.hip, phase C)
                 float4 cc[8], nn[8];
+                auto ld = [&](float4 (&x)[8], const uint32_t at) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) cc[u] = s4[u];
-                for (; i + 64 <= cnt; i += 32) {
+                    for (int u = 0; u < 8; ++u) x[u] = s4[(at >> 2) + u];
+                };
+                auto adds = [&](const float4 (&x)[8]) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) nn[u] = s4[((i + 32) >> 2) + u];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { acc = acc + cc[u].x; acc = acc + cc[u].y; acc = acc + cc[u].z; acc = acc + cc[u].w; }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) cc[u] = nn[u];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { acc = acc + cc[u].x; acc = acc + cc[u].y; acc = acc + cc[u].z; acc = acc + cc[u].w; }
-                i += 32;
+                    for (int u = 0; u < 8; ++u) { acc = acc + x[u].x; acc = acc + x[u].y; acc = acc + x[u].z; acc = acc + x[u].w; }
+                };
+                ld(cc, 0u);                                                 // invariant: cc holds samples [i, i + 32), i + 32 <= cnt
+                for (; i + 96 <= cnt; i += 64) { ld(nn, i + 32); adds(cc); ld(cc, i + 64); adds(nn); }
+                if (i + 64 <= cnt) { ld(nn, i + 32); adds(cc); adds(nn); i += 64; }
+                else { adds(cc); i += 32; }
             }
             for (; i < cnt; ++i) acc = acc + sb[i];
             __builtin_amdgcn_wave_barrier();
