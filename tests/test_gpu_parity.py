@@ -147,6 +147,24 @@ def test_chain_identical_to_oracle(hd, name):
     assert eng.sentences_ok() == sum(len(o.sentences()) for o in orcs)
 
 
+@pytest.mark.parametrize("path", ["tail", "separate"])
+@pytest.mark.parametrize("baud", [2000, 1300, 1200, 900, 750])
+def test_short_symbols_small_averaging_windows(hd, monkeypatch, baud, path):
+    """Symbols of 16 .. 43 decimated samples (32 kHz): averaging half-windows R = 4, 6, 6, 8, 10 -- below and around the eight positions a lane of
+    the window-sum code owns (its plain-loop branch for R < 8, one-chunk interiors, R not a multiple of four), through the stream tail and
+    through k_symbols.  The 5 kHz low-pass lets the keying through; what is decoded is compared, whatever it is worth."""
+    from oracle import pyoracle
+    if path == "separate":
+        monkeypatch.setenv("HD_NO_TAIL", "1")
+        monkeypatch.setenv("HD_NO_FUSE", "1")
+    fs = 2.048e6
+    iq, sent = make_streams(2, fs, baud, 8, 2, seed0=300 + baud, repeat=3)
+    eng, orcs, stats = run_both(hd, pyoracle, iq, fs, factor=64, baud=baud, bits=8, stops=2, lowpass_bw=5000.0, spectrum=False)
+    assert stats["demod_mismatch"] == 0, stats
+    assert eng.timing()["path"] == (2 if path == "tail" else 0)
+    assert sum(len(o.text("chars_log")) for o in orcs) > 20
+
+
 @pytest.mark.parametrize("spectrum_by", ["tail", "rocfft", "wave_launch"])
 def test_cfg4_50baud_7N2_with_offsets_and_afc(hd, monkeypatch, spectrum_by):
     """configs[3] shape on few streams: /64, 50 baud 7N2, per-stream carrier offsets; AFC outputs every call.  The spectrum of a completed
