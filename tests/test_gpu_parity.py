@@ -45,6 +45,18 @@ def power_close(gp, op):
     return bool(np.max(np.abs(mg - mo)) <= 2e-5 and np.max(np.abs(gp[strong] - op[strong])) <= 5e-3)
 
 
+@pytest.mark.parametrize("baud", [50, 110])
+def test_long_averaging_windows_at_512_kHz(hd, baud):
+    """/4 with the gate lifted and slow keying: symbols of 10240 / 4655 decimated samples, averaging half-windows R = 2560 / 1163 -- longer than a
+    sweep of k_symbols covers with its batched loads (the plain-loop staging), and a backlog that lives right under the reference's 30000-sample vent
+    (three symbols at 50 baud are 30720 samples: the vent fires on the way, SymbolExtractor.h:116-124)."""
+    from oracle import pyoracle
+    S, fs = 2, 2.048e6
+    iq, _ = make_streams(S, fs, baud, 7, 2, 40, seed0=61, texts=["$$A,1*", "$$B,2*"])
+    eng, orcs, stats = run_both(hd, pyoracle, iq, fs, factor=4, baud=baud, bits=7, stops=2, ungated=True, check_every=5, spectrum=False)
+    assert stats["demod_total"] > 0 and stats["demod_mismatch"] == 0
+
+
 def make_streams(S, fs, baud, bits, stops, nchunks=None, *, sigma=0.08, f0=None, seed0=0, texts=None, repeat=2):
     """S continuous streams; stream s carries its own short sentence `repeat` times.  nchunks=None sizes the
     streams so that every sentence (plus trailing idle) fits."""
