@@ -657,8 +657,9 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
 }
 
 // Stage 1 ALONE in the same shape (synchronous delivery, the first half of a call whose tails run as a launch of their own): one
-// workgroup per CU, two LDS-DMA loader waves with four tile slots each -- without tails in the CU's LDS there is room for eight --
-// and six computing waves.  512 MiB of IQ in 104-108 us where the single-wave grid (k_decimate<32,212,64>) takes 118-123.
+// workgroup per CU, an LDS-DMA loader wave (n_loaders = 2: two, four slots each) with eight tile slots -- without tails in the CU's LDS there is
+// room for eight -- and computing waves in all the others.  512 MiB of IQ in 107-112 us where the single-wave grid (k_decimate<32,212,64>) takes
+// 118-123.  D = 8: the same kernel for the /8 first stage of /16 plans (ring_consumer: four outputs per lane row).
 template <int T, int D>
 __global__ __launch_bounds__(D == 32 ? 1024 : 512) void k_stage1_cu(const RingArgs ra, const uint32_t n_loaders)
 {

@@ -83,7 +83,7 @@ struct RingCtl {
 };
 static_assert(sizeof(RingCtl) <= kRingCtlBytes, "ring control block");
 
-// Where a loader's tile slots are.  Each of the two loaders owns up to four: `nb` of them in the ring region proper, and -- inside a step launch --
+// Where a loader's tile slots are.  One loader owns them all (up to eight); each of two loaders owns up to four: `nb` of them in the ring region proper, and -- inside a step launch --
 // `ne` more that are the LDS slices of stream tails: slice k becomes a slot when its tail is done (RingCtl::tail_free[k]; a slice is at least a
 // slot long).  Local slot j of loader L: j < nb: ring + (L * nb + j) * SLOT; else extra + (L * ne + j - nb) * extra_stride.
 struct RingGeom {
@@ -375,7 +375,7 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
     uint32_t n_done = 0;
 #endif
     const uint32_t my_wave = role; (void)my_wave;
-    // The feeding consumer also draws the runs for both loaders from this XCD's counter (StepClaim, launch.h) -- a returning atomic the
+    // The feeding consumer also draws the runs for the loader(s) from this XCD's counter (StepClaim, launch.h) -- a returning atomic the
     // compiler counts and waits for, which a wave without DMA in flight can afford -- and keeps two of them ready in ctl->run_q.
     bool feeding = feeder;
     uint32_t fed = 0, sentinels = 0;

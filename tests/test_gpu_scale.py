@@ -122,7 +122,7 @@ def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, s
 @pytest.mark.parametrize("kernel", ["per_cu", "per_cu_two_loaders_12_waves", "single_wave_drawn", "single_wave"])
 def test_stage1_alone_at_full_size(monkeypatch, headline_ring, kernel):
     """Synchronous calls (what the Decoder facade makes): stage 1 as a launch of its own, then the stream tails.  "per_cu": one workgroup per CU
-    with LDS-DMA loader waves, eight tile slots and six computing waves (k_stage1_cu, the default for a /32 first stage); "single_wave_drawn":
+    with an LDS-DMA loader wave, eight tile slots and seven computing waves (k_stage1_cu, the default for a /32 first stage; two loaders and twelve waves: the second variant); "single_wave_drawn":
     k_decimate drawing runs from the per-XCD counters (HD_CLAIM_ALONE=1: measured slower than fixed shares, off by default; the path stays
     covered); "single_wave": k_decimate with fixed shares."""
     import habdec_amd
