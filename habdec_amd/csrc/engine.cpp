@@ -131,6 +131,8 @@ struct hd_engine {
     bool no_claim = false;     // HD_NO_CLAIM: step launches with fixed shares of tiles (A/B measurements)
     uint32_t step_run = 0;     // HD_STEP_RUN: tiles per drawn run (default 4, minimum 2)
     bool no_cu_step = false;   // HD_NO_CU_STEP: step launches as single-wave workgroups (k_step) instead of one workgroup per CU (k_step_cu)
+    uint32_t last_step_slots = 0;   // tile slots of the last k_step_cu launch (diagnostic)
+    bool cu_slots4 = false;         // HD_CU_SLOTS=4: never five tile slots in a step launch (A/B measurements)
     uint32_t ring_run = 0;     // HD_RING_RUN: tiles per drawn run of k_step_cu's loader (default 8)
     uint32_t ring_loaders = 1; // HD_RING_LOADERS: LDS-DMA waves per CU in a step launch (1 or 2; one leaves SIMD 1 two computing waves: 0.157 against 0.160 ms per launch)
     uint32_t s1_loaders = 1;   // HD_S1_LOADERS: ... when stage 1 is a launch of its own (/32: no difference; /8: 0.350 against 0.360 ms per step)
@@ -321,6 +323,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     e->no_cu_step = getenv("HD_NO_CU_STEP") != nullptr;
     if (const char* v = getenv("HD_RING_RUN")) e->ring_run = (uint32_t)atoi(v);
     if (const char* v = getenv("HD_RING_LOADERS")) e->ring_loaders = atoi(v) == 1 ? 1u : 2u;
+    if (const char* v = getenv("HD_CU_SLOTS")) e->cu_slots4 = atoi(v) == 4;
     if (const char* v = getenv("HD_S1_LOADERS")) e->s1_loaders = atoi(v) == 1 ? 1u : 2u;
     if (const char* v = getenv("HD_S1_WAVES")) e->s1_waves = (uint32_t)atoi(v);
     if (const char* v = getenv("HD_STEP_WGS")) e->step_wgs = (uint32_t)atoi(v);
@@ -529,6 +532,9 @@ int hd_engine_timing(hd_engine* e, hd_timing* out)
     *out = e->last_timing;
     return HD_OK;
 }
+
+// diagnostic (not in include/habdec_amd.h): tile slots the last k_step_cu launch ran with (4 or 5; 0 = none yet)
+extern "C" unsigned int hd_debug_step_slots(hd_engine* e) { return e ? e->last_step_slots : 0u; }
 
 // diagnostic (not in include/habdec_amd.h): the two sets of per-XCD run counters of the step launches, [2][16] (after a device-wide wait)
 extern "C" int hd_debug_step_counters(hd_engine* e, unsigned int* out32)
@@ -953,6 +959,13 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     if (step) {
         // One launch: [tails of the previous call | this call's stage 1].  Stage 1 reads its parameters from the mapped host block and
         // leaves the device copy the tails (next launch) and the spectrum commit read.
+        // Five tile slots instead of four where the tails' windows fit what that leaves (one loader; the compact 64-lane carve of tail.hip at 161
+        // taps and R = 160 fits with a few dozen bytes to spare): this call's tails are laid out for it now, the launch that runs them decides.
+        const uint32_t cu_tail5 = (e->ring_loaders == 1u && !e->cu_slots4) ? hd::step_cu_tail_lds((int)R1, (int)T1, 5u) : 0u;
+        if (cu_tail5 && !e->no_cu_step) {
+            hd::TailArgs ta5{};
+            if (hd::tail_layout(ta5, 64, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, cu_tail5)) ta_step = ta5;
+        }
         fill_tail(ta_step);
         hd_engine::PendingTail prev = e->pend;
         hd_engine::CallSlot* ps = prev.valid ? &e->slot[prev.slot] : nullptr;
@@ -973,11 +986,13 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         if (want_cu && claim.ctr) {
             const uint32_t tb = std::max(ta_step.lds_bytes, prev.valid ? prev.ta.lds_bytes : 0u);
             static const int cu_exp = getenv("HD_CU_EXP") ? atoi(getenv("HD_CU_EXP")) : 0;   // timing experiments only (results wrong): 1 = no tails, 2 = no stage 1
+            const uint32_t n_slots = (cu_tail5 && ((tb + 15u) & ~15u) <= cu_tail5) ? 5u : 4u;
             hd::StepClaim cl = claim;
             if (cu_exp & 2) cl.runs_per_xcd = 0;
             launched = hd::launch_step_cu(qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, e->n_cus, iq, stride,
                                           e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, prev.ta,
-                                          (prev.valid && !(cu_exp & 1)) ? S : 0u, max_in, cl, (tb + 15u) & ~15u, e->ring_gave_up.dev, e->ring_loaders);
+                                          (prev.valid && !(cu_exp & 1)) ? S : 0u, max_in, cl, (tb + 15u) & ~15u, e->ring_gave_up.dev, e->ring_loaders, n_slots);
+            if (launched) e->last_step_slots = n_slots;
             e->last_timing.step_variant = launched ? 1u : 0u;
         }
         if (!launched)

@@ -586,12 +586,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 64 ? 1 
 template <int T, int D2, int T2>
 __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const StreamCall* __restrict__ call, StreamCall* __restrict__ call_copy,
                                                  const TailArgs ta, const uint32_t n_tail, const uint32_t n_streams, const uint32_t tail_bytes,
-                                                 const uint32_t n_loaders /* 2: a loader on SIMD 0 and on SIMD 1; 1: SIMD 1 computes with both of its waves */)
+                                                 const uint32_t n_loaders /* 2: a loader on SIMD 0 and on SIMD 1; 1: SIMD 1 computes with both of its waves */,
+                                                 const uint32_t n_slots /* tile slots in the ring region: 4, or (one loader, tails that fit beside them) 5 */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char cu_lds[];
     unsigned char* ring = cu_lds;
-    RingCtl* ctl = reinterpret_cast<RingCtl*>(cu_lds + 2 * kRingNSL * ring_slot_bytes<T>());
-    unsigned char* tails = cu_lds + ring_bytes<T>();
+    RingCtl* ctl = reinterpret_cast<RingCtl*>(cu_lds + n_slots * ring_slot_bytes<T>());
+    unsigned char* tails = cu_lds + n_slots * ring_slot_bytes<T>() + kRingCtlBytes;
     if (threadIdx.x < kRingCtlBytes / 4) reinterpret_cast<uint32_t*>(ctl)[threadIdx.x] = (threadIdx.x == 2 || threadIdx.x == 3) ? 0xFFFFFFFFu : 0u;   // end[] = "not known yet"
     __syncthreads();
     // Roles by SIMD, not by wave number.  A 512-thread workgroup at 256 VGPRs puts exactly two waves on each of the CU's four SIMDs; which two
@@ -629,7 +630,8 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
 #else
     const bool slices = false;
 #endif
-    const RingGeom geom{ring, (uint32_t)kRingNSL * (3u - n_loaders), tails, slices ? 2u * (3u - n_loaders) : 0u, tail_bytes, n_loaders};
+    const uint32_t nb_ = n_slots / n_loaders, ne_ = slices ? (4u / n_loaders < 8u / n_loaders - nb_ ? 4u / n_loaders : 8u / n_loaders - nb_) : 0u;   // (a loader watches at most 8 / n_loaders slots)
+    const RingGeom geom{ring, nb_, tails, ne_, tail_bytes, n_loaders};
     if (w < n_loaders) {
 #ifdef HD_RING_LOADER_PRIO
         __builtin_amdgcn_s_setprio(HD_RING_LOADER_PRIO);
@@ -809,24 +811,26 @@ bool launch_step(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, u
     return false;
 }
 
-uint32_t step_cu_tail_lds(int ratio, int ntaps)
+uint32_t step_cu_tail_lds(int ratio, int ntaps, uint32_t n_slots)
 {
-    auto lim = [](int rb) { const uint32_t left = rb < 163840 ? (163840u - (uint32_t)rb) / 4u : 16u; return (left < kStepLdsBytes ? left : kStepLdsBytes) & ~15u; };
-    if (ratio == 32 && ntaps == 212) return lim(ring_bytes<212>());
-    if (ratio == 32 && ntaps == 174) return lim(ring_bytes<174>());
+    auto lim = [&](int slot) { const uint32_t rb = n_slots * (uint32_t)slot + (uint32_t)kRingCtlBytes, left = rb < 163840u ? (163840u - rb) / 4u : 16u; return (left < kStepLdsBytes ? left : kStepLdsBytes) & ~15u; };
+    if (n_slots != 4u && n_slots != 5u) return 0;
+    if (ratio == 32 && ntaps == 212) return lim(ring_slot_bytes<212>());
+    if (ratio == 32 && ntaps == 174) return lim(ring_slot_bytes<174>());
     return 0;
 }
 
 bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, uint32_t n_streams, uint32_t n_cus, const float2* in, size_t in_stride,
                     const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
-                    StreamCall* call_copy, const TailArgs& ta, uint32_t n_tail, uint32_t uniform_n, const StepClaim& claim, uint32_t tail_bytes, unsigned int* gave_up, uint32_t n_loaders)
+                    StreamCall* call_copy, const TailArgs& ta, uint32_t n_tail, uint32_t uniform_n, const StepClaim& claim, uint32_t tail_bytes, unsigned int* gave_up, uint32_t n_loaders, uint32_t n_slots)
 {
     if (n_loaders != 1u) n_loaders = 2u;
+    if (n_slots != 5u || n_loaders != 1u) n_slots = 2u * (uint32_t)kRingNSL;
     if (ratio != 32 || !claim.ctr || !uniform_n || uniform_n % 2048u) return false;
     RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, uniform_n / 2048u, claim, gave_up};
 #define HD_CU_CASE(T, D2, T2)                                                                                                         \
     if (ntaps == T && ratio2 == D2 && ntaps2 == T2) {                                                                                 \
-        const uint32_t lds = (uint32_t)ring_bytes<T>() + (n_tail ? 4u * tail_bytes : 0u);                                             \
+        const uint32_t lds = n_slots * (uint32_t)ring_slot_bytes<T>() + (uint32_t)kRingCtlBytes + (n_tail ? 4u * tail_bytes : 0u);        \
         if (lds > 163840u) return false;                                                                                              \
         static bool attr_set[64] = {};                             /* per device: the attribute belongs to the function on the current device */ \
         int dev_ = 0;                                                                                                                 \
@@ -835,7 +839,7 @@ bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_cu<T, D2, T2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) return false; \
             attr_set[dev_] = true;                                                                                                    \
         }                                                                                                                             \
-        hipLaunchKernelGGL((k_step_cu<T, D2, T2>), dim3(n_cus > (n_streams + 3u) / 4u ? n_cus : (n_streams + 3u) / 4u), dim3(512), lds, st, ra, call, call_copy, ta, n_tail, n_streams, tail_bytes, n_loaders); \
+        hipLaunchKernelGGL((k_step_cu<T, D2, T2>), dim3(n_cus > (n_streams + 3u) / 4u ? n_cus : (n_streams + 3u) / 4u), dim3(512), lds, st, ra, call, call_copy, ta, n_tail, n_streams, tail_bytes, n_loaders, n_slots); \
         return true;                                                                                                                  \
     }
     HD_CU_CASE(212, 2, 69) HD_CU_CASE(174, 4, 139)

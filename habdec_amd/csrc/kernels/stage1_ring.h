@@ -45,7 +45,7 @@ constexpr int kRingRowBytes = 272;                  // 32 samples + one 16-byte 
 #endif
 constexpr int kRingNSL = HD_RING_NSL;                 // tile slots per loader wave in a step launch (beside four stream tails: what fits)
 constexpr int kRingNSLAlone = 4;                      // ... when stage 1 has the CU to itself (k_stage1_cu)
-constexpr int kRingCtlBytes = 512;
+constexpr int kRingCtlBytes = 384;                 // (372 bytes of RingCtl; every 16 bytes count when a fifth tile slot has to fit beside four tails)
 constexpr uint32_t kRingSpinLimit = 1u << 22;   // polls before a waiting wave gives up (seconds; a correct run waits microseconds)
 template <int T> constexpr int ring_halo_rows() { return (T - 1 + 31) / 32; }
 template <int T> constexpr int ring_slot_bytes() { return (64 + ring_halo_rows<T>()) * kRingRowBytes; }

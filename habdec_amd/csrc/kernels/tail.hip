@@ -28,8 +28,12 @@ bool tail_layout(TailArgs& a, int lanes, int ratio2, int ntaps2, uint32_t max_ta
     const uint32_t NT = (uint32_t)lanes, P = NT * (uint32_t)tail_op(lanes), B = 2 * P + pend_max;
     const uint32_t XN = (uint32_t)(ntaps2 - 1) + P * (uint32_t)ratio2;
     const uint32_t H = max_taps ? max_taps - 1 : 0;
-    uint32_t off = kTailHdrBytes + (((XN + 4 + 1) & ~1u) + 2 * NT + 2) * 8;
-    a.f_off = off; off += ((H + B + 16 + 1) & ~1u) * 8;
+    // 64 lanes: the compact carve (tail_body.h: kCompact) -- the discriminator's exchange array lives in the part of the stage-1 image that is dead
+    // while the low-pass runs, and the read-ahead slack behind X and F is the next region (values read there are never used).  It is what lets
+    // four tails sit beside FIVE stage-1 tile slots in a CU's LDS (decimate.hip: k_step_cu).
+    const bool compact = lanes == 64;
+    uint32_t off = kTailHdrBytes + (compact ? ((XN + 1) & ~1u) : ((XN + 4 + 1) & ~1u) + 2 * NT + 2) * 8;
+    a.f_off = off; off += ((H + B + (compact ? 0u : 16u) + 1) & ~1u) * 8;
     a.v_off = off; off += ((max_R + B + 16 + 3) & ~3u) * 4;
     a.ws_off = off; off += ((max_R + B + 8 + 3) & ~3u) * 4;
     a.words_off = off; off += (kWidePos * NT / 64 + 2) * 8;

@@ -114,7 +114,13 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
 
     uint32_t* sh = reinterpret_cast<uint32_t*>(lds);                    // [0] nfl [1] overflow [2] frontier [3] carry sum [4] flagged
     float2* X = reinterpret_cast<float2*>(lds + kTailHdrBytes);
-    float2* Y = X + ((XN + 4 + 1) & ~1);                                // [0]: predecessor of this pass's first output; [1 + l], [1 + NT + l]: lane l's last outputs
+    // Y[0]: predecessor of this pass's first output; Y[1 + l], Y[1 + NT + l]: lane l's last outputs.  One wave per stream (kCompact): Y sits INSIDE the
+    // stage-1 image, behind the stage-2 history -- that part of X is dead from the end of a piece's stage 2 until the next piece is stored, which is
+    // when the low-pass passes run; the carry Y[0] outlives a piece and is kept in the header (sh[8..9]) between rounds.
+    constexpr bool kCompact = NT == 64;
+    static_assert(!kCompact || 2 * NT + 2 <= XCH, "the exchange array must fit the dead part of the stage-1 image");
+    float2* Y = kCompact ? X + ((T2 - 1 + 1) & ~1) : X + ((XN + 4 + 1) & ~1);
+    float2* carryY = reinterpret_cast<float2*>(sh + 8);
     float2* F = reinterpret_cast<float2*>(lds + a.f_off);               // low-pass input window, F[0] = input index fbase
     float* V = reinterpret_cast<float*>(lds + a.v_off);                 // discriminator output from position c0 on
     float* WS = reinterpret_cast<float*>(lds + a.ws_off);               // window sums of [c0 - R, c0), then the new ones
@@ -248,7 +254,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         }
 #pragma unroll
         for (int u = 0; u < HB; ++u) { const uint32_t k = tid + u * NT; if (k < (uint32_t)(T2 - 1)) X[k] = th[u]; }
-        if (tid == 0) Y[0] = make_float2(kin.re, kin.im);
+        if (tid == 0) { if (kCompact) carryY[0] = make_float2(kin.re, kin.im); else Y[0] = make_float2(kin.re, kin.im); }
     }
     vcnt = take0;
     tb_sync<NT>();
@@ -476,6 +482,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
             const uint32_t i_hi = (pc + 1 == npieces) ? m : min(m, (pb + o0 + po) & ~1u);
             const f32x4* hk = reinterpret_cast<const f32x4*>(TP);
             float2* Yl = Y;                                              // Yl[0]: predecessor of the pass's first output; Yl[1 + l], Yl[1 + NT + l]: lane l's last outputs
+            if (kCompact) { if (tid == 0) Yl[0] = carryY[0]; }            // (visible to lane 0 itself, its only reader, and ordered by the sync behind the tap loop)
             const uint32_t c0v = c0;                                     // (the symbol extractor's position c0 does not move inside the passes)
             for (uint32_t i0 = i_done; i0 < i_hi; i0 += 8 * NT) {
                 const uint32_t live = min((uint32_t)(8 * NT), i_hi - i0);
@@ -583,7 +590,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
                 tb_sync<NT>();                                          // Yl is read above; its carry slot and the next pass rewrite it
                 {   // the pass's last output becomes the next pass's predecessor
                     const uint32_t lo = live - 1, lw = lo / (4u * NT), ll = (lo % (4u * NT)) >> 2;
-                    if (tid == ll) Yl[0] = Yl[1 + lw * NT + tid];
+                    if (tid == ll) { const float2 cy = Yl[1 + lw * NT + tid]; Yl[0] = cy; if (kCompact) carryY[0] = cy; }
                 }
             }
             i_done = i_hi;

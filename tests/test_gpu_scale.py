@@ -36,7 +36,7 @@ def headline_ring():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("shares", ["drawn", "drawn2", "fixed", "deep", "rocfft", "single_wave", "regs_run4", "two_loaders"])
+@pytest.mark.parametrize("shares", ["drawn", "drawn2", "fixed", "deep", "rocfft", "single_wave", "regs_run4", "two_loaders", "four_slots"])
 def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, shares):
     """shares: which step kernel serves the batch and how its stage-1 tiles are handed out -- k_step_cu (one workgroup per CU: LDS-DMA loader
     waves + computing waves, runs of eight tiles drawn from per-XCD counters: the default; "regs_run4": runs of four), or the single-wave
@@ -56,6 +56,8 @@ def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, s
         monkeypatch.setenv("HD_RING_RUN", "4")
     if shares == "two_loaders":                              # k_step_cu with an LDS-DMA wave on SIMD 0 and on SIMD 1, two slots each (the default is one loader)
         monkeypatch.setenv("HD_RING_LOADERS", "2")
+    if shares == "four_slots":                               # one loader, four tile slots (the default since the tails' compact LDS carve is five)
+        monkeypatch.setenv("HD_CU_SLOTS", "4")
     w, ring, ring_chunks = headline_ring
     S, fs = w["S"], w["fs"]
     # 7/8 of the streams are within +-200 Hz, every 8th is far off: sample both kinds (and the first / last stream of XCD blocks)
@@ -103,6 +105,10 @@ def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, s
     assert eng.timing()["path"] == 3
     # which step kernel: one workgroup per CU (loader + computing waves, stage1_ring.h) unless switched off or the runs are not drawn
     assert eng.timing()["step_variant"] == (0 if shares in ("fixed", "single_wave") else 1), shares
+    # ... and with how many tile slots: five beside the compact 64-lane tails when one loader serves them, four with two loaders
+    import ctypes
+    slots = habdec_amd.lib().hd_debug_step_slots; slots.restype = ctypes.c_uint; slots.argtypes = [ctypes.c_void_p]
+    assert slots(eng.h) == (0 if shares in ("fixed", "single_wave") else 4 if shares in ("two_loaders", "four_slots") else 5), (shares, slots(eng.h))
     in_launch = min(len(v) for v in seen.values())           # calls whose tails rode in a step launch and were compared before the final flush
     assert in_launch >= n_free - 4, in_launch
     eng.flush()
