@@ -1,0 +1,44 @@
+"""The register / scratch claims of DESIGN.md, checked from the compiler's own metadata (no GPU needed: hipcc cross-compiles a device-only listing).
+
+k_step_cu and k_stage1_cu must not spill and must keep the occupancy their launch shapes assume: two waves per SIMD for the 512-thread step workgroup
+(<= 256 VGPRs), four for the 1024-thread-capable stage-1 workgroup (<= 128)."""
+import re
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "habdec_amd" / "csrc"
+
+
+def kernel_table(src: Path, tmp: Path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available")
+    out = tmp / (src.stem + ".s")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
+           "-I", str(ROOT / "include"), "-I", str(CSRC), "-x", "hip", "--cuda-device-only", "-S", str(src), "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+    txt = out.read_text()
+    meta = txt[txt.index("amdhsa.kernels:"):]
+    table = {}
+    for blk in re.split(r"\n  - \.agpr_count", meta)[1:]:
+        g = lambda k: re.search(r"\.%s:\s+(\S+)" % k, blk).group(1)
+        name = subprocess.run(["c++filt", g("name")], capture_output=True, text=True).stdout.strip()
+        name = re.sub(r"\(.*", "", name).replace("void hd::", "").replace("hd::", "").replace(" ", "")
+        table[name] = dict(vgpr=int(g("vgpr_count")), spill=int(g("vgpr_spill_count")), scratch=int(g("private_segment_fixed_size")))
+    return table
+
+
+def test_step_and_stage1_kernels_do_not_spill(tmp_path):
+    t = kernel_table(CSRC / "kernels" / "decimate.hip", tmp_path)
+    for k in ("k_step_cu<212,2,69>", "k_step_cu<174,4,139>"):
+        assert t[k]["spill"] == 0 and t[k]["scratch"] == 0 and t[k]["vgpr"] <= 256, (k, t[k])
+    for k in ("k_stage1_cu<212,32>", "k_stage1_cu<174,32>"):
+        assert t[k]["spill"] == 0 and t[k]["scratch"] == 0 and t[k]["vgpr"] <= 128, (k, t[k])
+    k = "k_stage1_cu<54,8>"
+    assert t[k]["spill"] == 0 and t[k]["scratch"] == 0 and t[k]["vgpr"] <= 256, (k, t[k])
+    # the single-wave fallback of the step launch is allowed its two spilled registers (12 bytes of scratch), no more
+    assert t["k_step<32,212,2,69>"]["spill"] <= 2 and t["k_step<32,212,2,69>"]["scratch"] <= 12, t["k_step<32,212,2,69>"]
