@@ -36,12 +36,19 @@ def _stale() -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = False, variant: str | None = None) -> Path:
+    """`variant` (or HD_BUILD_VARIANT): an experiment build beside the product library -- objects in build/<variant>/, the library in
+    gpurun_in/variants/libhd_<variant>.so (tools/micro/ab_step.py loads several of them into one process); flags from HD_EXTRA_FLAGS."""
+    variant = variant or os.environ.get("HD_BUILD_VARIANT") or None
+    target = OUT
+    if variant:
+        target = HERE.parent / "gpurun_in" / "variants" / f"libhd_{variant}.so"
+        target.parent.mkdir(parents=True, exist_ok=True)
+    elif not force and not _stale():
         return OUT
     objs = []
-    build_dir = HERE / "build"
-    build_dir.mkdir(exist_ok=True)
+    build_dir = HERE / "build" / variant if variant else HERE / "build"
+    build_dir.mkdir(parents=True, exist_ok=True)
     extra = os.environ.get("HD_EXTRA_FLAGS", "").split()
     common = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
               # (the atomic optimiser rewrites lane 0's ticket draw in the step kernel into a form that needs the old value at once: the wave
@@ -66,10 +73,10 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             print(out)
     if bad:
         raise RuntimeError("hipcc failed")
-    link = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(OUT)] + objs + \
+    link = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(target)] + objs + \
         ["-L/opt/rocm/lib", "-lrocfft", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.run(link, check=True)
-    return OUT
+    return target
 
 
 def build_facade_demo() -> Path:

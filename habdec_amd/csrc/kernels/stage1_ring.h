@@ -145,10 +145,15 @@ __device__ __forceinline__ void glds4(const void* base, uint32_t off, uint32_t l
 __device__ __forceinline__ void glds16_x17(const void* base, const uint32_t (&off)[17], uint32_t lds_dst)
 {
     unsigned keep, scc_keep;                      // (s_add_u32 writes SCC, which compiler code around the statement may hold live: saved and restored)
-#define HD_G1(n) "global_load_lds_dwordx4 %" #n ", %19\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+#ifdef HD_GLDS_NT                                // cache policy of the body rows' LDS-DMA: " nt" for once-read bytes (the halo rows, which the previous tile of
+#define HD_GLDS_BODY_POLICY " nt"                // the run has just brought into this XCD's L2, stay on the default policy)
+#else
+#define HD_GLDS_BODY_POLICY ""
+#endif
+#define HD_G1(n) "global_load_lds_dwordx4 %" #n ", %19" HD_GLDS_BODY_POLICY "\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
     asm volatile("s_cselect_b32 %1, 1, 0\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %20\n\ts_nop 0\n\t"
                  HD_G1(2) HD_G1(3) HD_G1(4) HD_G1(5) HD_G1(6) HD_G1(7) HD_G1(8) HD_G1(9) HD_G1(10) HD_G1(11) HD_G1(12) HD_G1(13) HD_G1(14) HD_G1(15) HD_G1(16) HD_G1(17)
-                 "global_load_lds_dwordx4 %18, %19\n\ts_mov_b32 m0, %0\n\ts_cmp_lg_u32 %1, 0"
+                 "global_load_lds_dwordx4 %18, %19" HD_GLDS_BODY_POLICY "\n\ts_mov_b32 m0, %0\n\ts_cmp_lg_u32 %1, 0"
                  : "=&s"(keep), "=&s"(scc_keep)
                  : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]), "v"(off[8]), "v"(off[9]),
                    "v"(off[10]), "v"(off[11]), "v"(off[12]), "v"(off[13]), "v"(off[14]), "v"(off[15]), "v"(off[16]), "s"(base), "s"(lds_dst)

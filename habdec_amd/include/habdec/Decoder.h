@@ -77,31 +77,43 @@ public:
 
     size_t setupDecimationStagesFactor(const size_t factor)
     {
+        // reference Decoder.h:268-332, including its edges: out of [1, 256] leaves the plan alone and returns the current factor (:272-276);
+        // inside that range the plan is cleared FIRST (:281-284), so a factor without a table -- 1, or anything that is not a power of
+        // two -- leaves "no stages, factor 1" behind and returns 0 (:317-319); a supported factor prints its stages (:324-329).
         if (factor < 1 || factor > 256) { std::cout << "Unsupported decimation factor: " << factor << std::endl; return getDecimationFactor(); }
-        if (factor & (factor - 1)) { std::cout << "Unsupported decimation factor: " << factor << std::endl; return 0; }
         std::lock_guard<std::mutex> l(mtx_);
-        factor_ = (int)factor;
+        const char* stages = stage_names(factor);
+        factor_ = stages ? (int)factor : 1;
         drop_engine();                                       // new stage plan: histories restart (the reference clears its stages too)
+        if (!stages) { std::cout << "Unsupported decimation factor: " << factor << std::endl; return 0; }
+        std::cout << "Decoder::setupDecimationStagesFactor Decimation Stages: " << stages << std::endl;
         std::cout << "Decoder::setupDecimationStagesFactor Post Decimation Sampling Rate = " << getDecimatedSamplingRate()
                   << ", decimation factor = " << factor_ << std::endl;
         return factor_;
     }
     size_t setupDecimationStagesBW(const double max_rate)
     {
-        // reference Decoder.h:336-412: the smallest power-of-two division (2 .. 256) that brings the rate to max_rate or below; the
-        // reference would stack a SECOND such division when even /256 is not enough -- a plan of more than two stages, which the
-        // engine does not have: that request is refused (message, current plan kept).
+        // reference Decoder.h:336-412: the smallest power-of-two division (2 .. 256) that brings the rate to max_rate or below -- none at
+        // all when the input rate already is (no stages, factor 1, returns 1).  The reference would stack a SECOND such division when
+        // even /256 is not enough -- a plan of more than two stages, which the engine does not have: that request is refused (message,
+        // current plan kept).
         if (!input_rate_) return 0;
-        double r = input_rate_;
-        if (!(r > max_rate)) return setupDecimationStagesFactor(1);
-        int div = 2;
-        for (; div < 256; div *= 2)
-            if (r / div <= max_rate) break;
-        if (r / div > max_rate) {
-            std::cout << "Decoder::setupDecimationStagesBW more than /256 needed for " << max_rate << " Hz: unsupported, keeping /" << factor_ << std::endl;
-            return 0;
+        const double r = input_rate_;
+        int div = 1;
+        if (r > max_rate) {
+            for (div = 2; div < 256; div *= 2)
+                if (r / div <= max_rate) break;
+            if (r / div > max_rate) {
+                std::cout << "Decoder::setupDecimationStagesBW more than /256 needed for " << max_rate << " Hz: unsupported, keeping /" << factor_ << std::endl;
+                return 0;
+            }
         }
-        return setupDecimationStagesFactor((size_t)div);
+        std::lock_guard<std::mutex> l(mtx_);
+        factor_ = div;
+        drop_engine();
+        std::cout << "Decoder::setupDecimationStagesBW Decimation Stages: " << (div > 1 ? stage_names((size_t)div) : "") << std::endl;
+        std::cout << "Decoder::setupDecimationStagesBW Post Decimation Sampling Rate = " << r / div << ", decimation factor = " << factor_ << std::endl;
+        return factor_;
     }
 
     // ---- results
@@ -243,6 +255,15 @@ private:
         auto* d = static_cast<Decoder*>(self);
         d->pending_chars_.append(chars, n);
         if (d->live_print_) { std::cout.write(chars, (std::streamsize)n); std::cout.flush(); }
+    }
+    // "/32/2": the stages of a supported total factor as the reference prints them (Decoder.h:286-316, :324-327); nullptr where it has no table
+    static const char* stage_names(size_t factor)
+    {
+        switch (factor) {
+            case 256: return "/64/4"; case 128: return "/32/4"; case 64: return "/32/2"; case 32: return "/16/2";
+            case 16: return "/8/2"; case 8: return "/8"; case 4: return "/4"; case 2: return "/2";
+            default: return nullptr;
+        }
     }
     void note_no_input() const { std::cout << "FirFilter::LP_BlackmanHarris No Input set." << std::endl; }
     void drop_engine() { if (engine_) { hd_engine_destroy(engine_); engine_ = nullptr; } }
