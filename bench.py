@@ -3,6 +3,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg1|cfg2|cfg3|cfg5] [--streams S]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N --threads        # ONE process: an engine + a host thread per device; no torchrun, no RCCL
 
 A "step" is one pushSamples()+operator()() round for every stream of the batch (reference
 code/websocketServer/main.cpp:240-245): S streams x C IQ samples already resident in HBM go through the whole
@@ -142,7 +143,7 @@ def cpu_baseline(w, host_iq, chunks, C, lookup_mode=1):
     inside the library), each fed the chunk sequence the GPU consumed on its stream, repeated with fresh decoders.  The thread count
     is calibrated first -- all logical CPUs, half, a quarter, ... for about a second each (containers often grant fewer cores than
     os.cpu_count() shows, and then more threads only get in each other's way) -- and the best one runs the ~12 s measurement.
-    Returns (MS/s, threads used, sample description, per-stream first-pass logs, calibration table)."""
+    Returns (MS/s, threads used, sample description, calibration table)."""
     from oracle import pyoracle
     kw = dict(fs=w["fs"], factor=w["D"], baud=w["baud"], bits=w["bits"], stops=w["stops"], lowpass_bw=w["lp_bw"],
               lowpass_trans=w["lp_trans"], mathh_context=lookup_mode, ungated=w["ungated"])
@@ -157,12 +158,63 @@ def cpu_baseline(w, host_iq, chunks, C, lookup_mode=1):
         table[n] = n * rep * per_pass / dt / 1e6
     best = max(table, key=table.get)
     repeats = int(min(max(round(12.0 * table[best] * 1e6 / (best * per_pass)), 1), 5000))
-    dt, logs_best = pyoracle.bench_run(host_iq[:best], chunks, C, repeats, **kw)
-    _, logs = pyoracle.bench_run(host_iq, chunks, C, 1, **kw)             # first-pass results of every sampled stream, for the self-check
+    dt, _ = pyoracle.bench_run(host_iq[:best], chunks, C, repeats, **kw)
     total = best * repeats * per_pass
     sample = (f"{best} streams x {len(chunks)} chunks of {C} samples x {repeats} repeats = {total / 1e6:.0f} MS in {dt:.1f} s; one oracle decoder per "
               f"thread, {best} threads; single-thread rate {per_pass / t_one / 1e6:.1f} MS/s")
-    return total / dt / 1e6, best, sample, logs, {str(k): round(v, 1) for k, v in table.items()}
+    return total / dt / 1e6, best, sample, {str(k): round(v, 1) for k, v in table.items()}
+
+
+def oracle_sample_check(w, eng, ring, chunks, C, streams, lookup_mode=1):
+    """The self-check every bench line carries: the oracle decodes the chunk sequence the engine consumed on a few streams (one pass, one
+    thread per stream) and the engine's symbols produced, characters and sentences per stream must equal the oracle's."""
+    from oracle import pyoracle
+    kw = dict(fs=w["fs"], factor=w["D"], baud=w["baud"], bits=w["bits"], stops=w["stops"], lowpass_bw=w["lp_bw"],
+              lowpass_trans=w["lp_trans"], mathh_context=lookup_mode, ungated=w["ungated"])
+    nuse = max(chunks) + 1
+    host_iq = [ring[:nuse, s].cpu().numpy().view(np.complex64).reshape(-1) for s in streams]
+    _, logs = pyoracle.bench_run(host_iq, chunks, C, 1, **kw)
+    gpu_sent = [eng.take_sentences(s) for s in streams]
+    gpu_chars = [eng.take_chars(s) for s in streams]
+    gpu_bits = [eng.bits_total(s) for s in streams]
+    n_chars, n_bits = int(sum(len(x.chars) for x in logs)), int(sum(x.bits for x in logs))
+    same = gpu_sent == [list(x) for x in logs] and gpu_chars == [x.chars for x in logs] and gpu_bits == [x.bits for x in logs]
+    return {"gpu_matches_oracle_on_sample": (bool(same) if n_bits else None),
+            "compared": "per stream: symbols produced, characters emitted, sentences -- GPU engine vs oracle over warm-up + timed steps",
+            "streams_in_sample": [int(x) for x in streams] if len(streams) <= 8 else len(streams),
+            "bits_in_sample": n_bits, "chars_in_sample": n_chars, "sentences_in_sample": int(sum(len(x) for x in logs))}
+
+
+def box_identity(torch, dev):
+    """What this box's GPU delivers right now, so that a kernel time can be attributed (boxes of the pool differ by +-6 %): clocks as rocm-smi
+    reports them, and a 20 ms calibration pass -- a 1 GiB device-to-device copy, the access pattern of the guide's 6.29 TB/s float4 copy figure."""
+    out = {"gpu": torch.cuda.get_device_name(dev)}
+    try:
+        n = 1 << 28
+        a = torch.empty(n, dtype=torch.float32, device=dev); b = torch.empty_like(a)
+        a.fill_(1.0); b.copy_(a); torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.device(dev):
+            e0.record()
+            for _ in range(10):
+                b.copy_(a)
+            e1.record(); torch.cuda.synchronize(dev)
+        out["copy_GBps"] = round(10 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        out["copy_note"] = "1 GiB torch device-to-device copy x10 (read + write bytes), measured after the timed region"
+        del a, b
+    except Exception as ex:                      # (never let the calibration take the line down)
+        out["copy_GBps"] = None; out["copy_note"] = f"calibration failed: {ex}"
+    try:
+        import subprocess
+        js = json.loads(subprocess.run(["rocm-smi", "-d", str(dev.index or 0), "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout)
+        card = next(iter(js.values()))
+        for k, v in card.items():
+            kl = k.lower()
+            if "sclk" in kl and "level" in kl: out["sclk"] = v
+            if "mclk" in kl and "level" in kl: out["mclk"] = v
+    except Exception:
+        pass
+    return out
 
 
 def physical_cores():
@@ -186,55 +238,107 @@ STAGE1_CU = {64: "k_stage1_cu<212,32>", 128: "k_stage1_cu<174,32>", 16: "k_stage
 PATHS = {0: "separate kernels", 1: "fused back end", 2: "stream tail kernel", 3: "step kernel (stage 1 + previous call's stream tails)"}
 
 
-def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync, cpu_leg):
-    """Time K steps of one workload (after W warm-up steps) and describe the result; rank 0 gets the full dictionary."""
+class Shard:
+    """One GPU's share of the job: its engine, its HBM-resident ring of push slabs and its step loop (streams are independent: nothing is shared)."""
+
+    def __init__(self, torch, w, S, device_index, rank, sync):
+        import habdec_amd
+        self.torch, self.S, self.C, self.dev = torch, S, w["C"], torch.device("cuda", device_index)
+        # (the engine first -- allocations, rocFFT plan, code objects: host-side work during which the GPU idles -- then the synthetic ring, whose
+        # generation keeps the GPU busy right up to the warm-up steps)
+        self.eng = habdec_amd.Engine(n_streams=S, max_chunk=w["C"], sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"],
+                                     rtty_stops=w["stops"], lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"],
+                                     device=device_index, pipeline=0 if sync else int(os.environ.get("HD_BENCH_PIPELINE", "2")))
+        self.ring, self.ring_chunks, self.texts = generate_ring(torch, self.dev, w, S, rank, seed=1234 + rank)
+        self.eng.set_timing(3)     # HIP-event brackets on every 3rd call (each record is a barrier packet worth microseconds of queue time; 3, not 4: every 4th
+                                   # launch carries the streams' spectra, and the sample must see light and heavy launches in their true proportion)
+        self.base = self.ring.data_ptr()
+        self.front_ms, self.total_ms, self.host_us = [], [], []
+
+    def step(self, i):
+        self.eng.process_device(self.base + (i % self.ring_chunks) * self.S * self.C * 8, self.C, self.C)
+
+    def warm(self, W):
+        for i in range(W):
+            self.step(i)
+        self.eng.flush()
+
+    def timed(self, W, K, every=1):
+        """K steps and the flush that delivers the last step's text; `every`: how often the loop asks the engine for its timing record (a thread
+        per device shares the interpreter with its siblings: there the loop body is the bare C call on two steps out of three)."""
+        eng = self.eng
+        seen = eng.timing()["timed_calls"]
+        for i in range(W, W + K):
+            self.step(i)
+            if every == 1 or (i - W) % every == every - 1:
+                t = eng.timing()
+                if t["timed_calls"] != seen:          # (a call that carried the HIP-event brackets)
+                    seen = t["timed_calls"]
+                    self.front_ms.append(t["ms_front"])
+                    self.total_ms.append(t["ms_total"])
+                self.host_us.append((t["host_enqueue_us"], t["host_wait_us"], t["host_text_us"]))
+        self.t_loop = time.perf_counter()
+        eng.flush()          # the last step's text is delivered inside the timed region
+        self.torch.cuda.synchronize(self.dev)
+        self.t_end = time.perf_counter()
+
+
+def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync, cpu_leg, threads=0):
+    """Time K steps of one workload (after W warm-up steps) and describe the result; rank 0 gets the full dictionary.
+    cpu_leg: "full" = the CPU baseline (oracle timed on the host cores) + the self-check; "check" = the self-check alone (a few streams through
+    the oracle, compared with the engine's output: every line carries it); threads = N > 0: one process, a Shard + host thread per device."""
+    import threading
     import habdec_amd
     w = dict(WORKLOADS[name])
     S = S or w["S"]
     C = w["C"]
-    # (the engine first -- allocations, rocFFT plan, code objects: host-side work during which the GPU idles -- then the synthetic ring, whose
-    # generation keeps the GPU busy right up to the warm-up steps)
-    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"],
-                            rtty_stops=w["stops"], lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"],
-                            device=local_rank, pipeline=0 if sync else int(os.environ.get("HD_BENCH_PIPELINE", "2")))
-    ring, ring_chunks, texts = generate_ring(torch, dev, w, S, rank, seed=1234 + rank)
-    K = K or ring_chunks
-    eng.set_timing(3)          # HIP-event brackets on every 3rd call (each record is a barrier packet worth microseconds of queue time; 3, not 4: every 4th
-                               # launch carries the streams' spectra, and the sample must see light and heavy launches in their true proportion)
-    base = ring.data_ptr()
+    if threads:
+        world = threads
+        shards = [None] * threads
 
-    def step(i):
-        eng.process_device(base + (i % ring_chunks) * S * C * 8, C, C)
+        def make(d):
+            shards[d] = Shard(torch, w, S, d, d, sync)
+        th = [threading.Thread(target=make, args=(d,)) for d in range(threads)]
+        for t in th: t.start()
+        for t in th: t.join()
+        if any(x is None for x in shards):
+            raise SystemExit("bench.py --threads: a device's engine or ring could not be built")
+    else:
+        shards = [Shard(torch, w, S, local_rank, rank, sync)]
+    sh = shards[0]
+    eng, ring, ring_chunks, texts = sh.eng, sh.ring, sh.ring_chunks, sh.texts
+    K = K or ring_chunks
+    base = sh.base
 
     def barrier():
         if dist is not None:
             dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
+        for x in shards:
+            torch.cuda.synchronize(x.dev)
 
-    for i in range(W):
-        step(i)
-    eng.flush()
-    front_ms, total_ms, host_us = [], [], []
+    for x in shards:
+        x.warm(W)
     barrier()
     t0 = time.perf_counter()
-    seen = eng.timing()["timed_calls"]
-    for i in range(W, W + K):
-        step(i)
-        t = eng.timing()
-        if t["timed_calls"] != seen:          # (a call that carried the HIP-event brackets)
-            seen = t["timed_calls"]
-            front_ms.append(t["ms_front"])
-            total_ms.append(t["ms_total"])
-        host_us.append((t["host_enqueue_us"], t["host_wait_us"], t["host_text_us"]))
-    t_loop = time.perf_counter()
-    eng.flush()          # the last step's text is delivered inside the timed region
+    if threads > 1:
+        th = [threading.Thread(target=x.timed, args=(W, K, 3)) for x in shards]
+        for t in th: t.start()
+        for t in th: t.join()
+    else:
+        sh.timed(W, K)
     barrier()
     dt = time.perf_counter() - t0
-    drain_ms = (time.perf_counter() - t_loop) * 1e3
+    if threads > 1:
+        dt = max(x.t_end for x in shards) - t0      # (the slowest device's region: MAX over shards, as job_time does over ranks)
+    drain_ms = (sh.t_end - sh.t_loop) * 1e3
     dt = job_time(dist, dt, dev)
+    front_ms, total_ms, host_us = sh.front_ms, sh.total_ms, sh.host_us
     tm = eng.timing()
     front_bytes, path = tm["front_bytes"], tm.get("path", 0)
     sentences_ok = eng.sentences_ok()
+    for x in shards[1:]:
+        x.eng.close()
+        x.ring = None
     if rank != 0:
         eng.close()
         return None
@@ -263,7 +367,8 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
         traffic, prof = None, {}                               # (the committed profile is of another kernel: say nothing rather than the wrong thing)
     if prof.get("rocprof_avg_launch_ms"):
         # the committed rocprofv3 --kernel-trace --stats summary of the same command (tools/collect_profiles.py): the live figure must agree with it
-        rp = {"rocprof_avg_launch_ms": prof["rocprof_avg_launch_ms"], "rocprof_launches": prof.get("rocprof_launches"), "rocprof_source": prof.get("stats_source")}
+        rp = {"rocprof_avg_launch_ms": prof["rocprof_avg_launch_ms"], "rocprof_launches": prof.get("rocprof_launches"), "rocprof_source": prof.get("stats_source"),
+              "frac_rocprof": round(alg_bytes / (prof["rocprof_avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     else:
         rp = {}
     valu = w["D"] == 4                                      # configs[2]: the FIR chain's multiply-adds bind, not HBM
@@ -318,24 +423,23 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
                            "achieved": round(iso_bw, 1), "frac": round(iso_bw / HBM_PEAK_GBS, 4),
                            "frac_of_measured_copy_peak": round(iso_bw / HBM_COPY_GBS, 4),
                            "note": "stage 1 alone: synchronous calls (nothing else on the GPU), 24 launches after the timed region"}
-    if cpu_leg:
+    res["box"] = box_identity(torch, dev)
+    chunks = [i % ring_chunks for i in range(W + K)]
+    if cpu_leg == "full":
         nproc = os.cpu_count() or 1
         nthreads = int(min(nproc, S))
-        chunks = [i % ring_chunks for i in range(W + K)]
         nuse = min(ring_chunks, W + K)                         # (the chunks the run touched: no need to bring the whole ring over)
         host_iq = [ring[:nuse, s].cpu().numpy().view(np.complex64).reshape(-1) for s in range(nthreads)]
-        v, c, sample, logs, calib = cpu_baseline(w, host_iq, chunks, C)
-        gpu_sent = [eng.take_sentences(s) for s in range(nthreads)]
-        gpu_chars = [eng.take_chars(s) for s in range(nthreads)]
-        gpu_bits = [eng.bits_total(s) for s in range(nthreads)]
-        n_chars, n_bits = int(sum(len(x.chars) for x in logs)), int(sum(x.bits for x in logs))
-        same = gpu_sent == [list(x) for x in logs] and gpu_chars == [x.chars for x in logs] and gpu_bits == [x.bits for x in logs]
+        v, c, sample, calib = cpu_baseline(w, host_iq, chunks, C)
+        del host_iq
         res["cpu_baseline"] = {"value": round(v, 1), "unit": "MS/s", "cores": min(c, physical_cores() or c), "threads": c, "nproc": nproc,
                                "physical_cores": physical_cores(), "kind": "port", "sample": sample,
-                               "threads_calibration_MSps": calib,
-                               "gpu_matches_oracle_on_sample": (bool(same) if n_bits else None),
-                               "compared": "per stream: symbols produced, characters emitted, sentences -- GPU engine vs oracle over warm-up + timed steps",
-                               "bits_in_sample": n_bits, "chars_in_sample": n_chars, "sentences_in_sample": int(sum(len(x) for x in logs))}
+                               "threads_calibration_MSps": calib}
+        res["cpu_baseline"].update(oracle_sample_check(w, eng, ring, chunks, C, list(range(min(S, 16)))))
+    elif cpu_leg == "check":
+        # no CPU timing asked for: the line still says whether what it timed decodes what the oracle decodes (a far-off-tune stream among them)
+        res["cpu_baseline"] = {"value": None, "kind": "port", "note": "self-check only (--no-cpu-baseline / secondary workload): the oracle was not timed"}
+        res["cpu_baseline"].update(oracle_sample_check(w, eng, ring, chunks, C, sorted({0, min(7, S - 1), S // 2, S - 1})))
     eng.close()
     del ring
     torch.cuda.empty_cache()
@@ -352,6 +456,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary line for BASELINE configs[2] (/4)")
     ap.add_argument("--sync", action="store_true", help="deliver each step's text before the next step starts (no pipelining of calls)")
+    ap.add_argument("--threads", action="store_true", help="with --gpus N and no torchrun: ONE process, an engine + a host thread per device (no RCCL anywhere)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -363,18 +468,27 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    threads = 0
+    if args.threads:
+        if world > 1:
+            raise SystemExit("bench.py --threads is the one-process mode: start it without torchrun")
+        threads = max(1, args.gpus)
+        if torch.cuda.device_count() < threads:
+            raise SystemExit(f"bench.py --threads --gpus {threads}: only {torch.cuda.device_count()} device(s) visible")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     r = run_workload(torch, dist, dev, rank, local_rank, world, args.workload, args.steps, args.warmup, args.streams, args.sync,
-                     cpu_leg=not args.no_cpu_baseline)
+                     cpu_leg="check" if args.no_cpu_baseline else "full", threads=threads)
+    if threads:
+        world = threads
     also = None
     if args.workload == "cfg4" and not args.no_also and world == 1:
         # BASELINE configs[2] ("1024 batched IQ streams @ 2.048 MS/s, dec=2, on 1 MI355X"): the harder, VALU-bound single-GPU
         # configuration, measured beside the headline (its own ring, a short timed region).
-        also = run_workload(torch, dist, dev, rank, local_rank, world, "cfg3", 24, 4, 0, args.sync, cpu_leg=False)
+        also = run_workload(torch, dist, dev, rank, local_rank, world, "cfg3", 24, 4, 0, args.sync, cpu_leg="check")
     if rank != 0:
         if dist is not None:
             dist.barrier(device_ids=[local_rank])
@@ -389,15 +503,19 @@ def main():
         "config": {"workload": f"{args.workload}: {w['desc']}", "streams_per_gpu": r["S"], "chunk_samples": r["C"], "ring_chunks": r["ring_chunks"],
                    "sharding": f"{r['S']} independent streams per GPU, no data-path collective"},
         "timed_region_ms": r["timed_region_ms"],
-        "roofline": r["roofline"], "pipeline": r["pipeline"],
+        "roofline": r["roofline"], "pipeline": r["pipeline"], "box": r.get("box"),
     }
+    if threads:
+        line["config"]["launcher"] = f"one process, {threads} engine(s) each with its own host thread and device (bench.py --threads)"
     if "cpu_baseline" in r:
         line["cpu_baseline"] = r["cpu_baseline"]
     if also:
         aw = also["w"]
         line["also"] = {"workload": f"cfg3: {aw['desc']}", "value": also["value"], "unit": "MS/s", "ms_per_step": also["ms_per_step"], "steps": also["steps"],
                         "timed_region_ms": also["timed_region_ms"], "roofline": also["roofline"],
-                        "hbm_frac_end_to_end": also["pipeline"]["hbm_frac_end_to_end"], "launch_path": also["pipeline"]["launch_path"]}
+                        "hbm_frac_end_to_end": also["pipeline"]["hbm_frac_end_to_end"], "launch_path": also["pipeline"]["launch_path"],
+                        "gpu_matches_oracle_on_sample": also["cpu_baseline"]["gpu_matches_oracle_on_sample"],
+                        "self_check": {k: also["cpu_baseline"][k] for k in ("streams_in_sample", "bits_in_sample", "chars_in_sample", "sentences_in_sample")}}
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier(device_ids=[local_rank])

@@ -587,7 +587,7 @@ template <int T, int D2, int T2>
 __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const StreamCall* __restrict__ call, StreamCall* __restrict__ call_copy,
                                                  const TailArgs ta, const uint32_t n_tail, const uint32_t n_streams, const uint32_t tail_bytes,
                                                  const uint32_t n_loaders /* 2: a loader on SIMD 0 and on SIMD 1; 1: SIMD 1 computes with both of its waves */,
-                                                 const uint32_t n_slots /* tile slots in the ring region: 4, or (one loader, tails that fit beside them) 5 */)
+                                                 const uint32_t n_slots /* tile slots in the ring region: 4, or (one loader, tails that fit beside them) 5, or (no tails in the launch) 8 */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char cu_lds[];
     unsigned char* ring = cu_lds;
@@ -623,15 +623,12 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
 #else
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #endif
-    // Tile slots: two per loader in the ring region, and -- as the tails finish -- the tails' LDS slices, two per loader (a slice is at least a
-    // slot long; without tails in the launch there are no slices).
+    // Tile slots: the ring region's (four, five beside the compact tails, eight in a launch without tails), and -- as the tails finish -- slots inside
+    // the tails' LDS slices (stage1_ring.h: ring_extra_slots), up to eight in all per loader pair.
+    RingGeom geom{ring, n_slots / n_loaders, tails, 0u, 0u, 0u, n_loaders};
 #ifndef HD_CU_NO_EXTRA_SLOTS
-    const bool slices = n_tail != 0 && tail_bytes >= (uint32_t)ring_slot_bytes<T>();
-#else
-    const bool slices = false;
+    ring_extra_slots(geom, tail_bytes, (uint32_t)ring_slot_bytes<T>(), n_slots < 8u ? 8u - n_slots : 0u, n_tail != 0);
 #endif
-    const uint32_t nb_ = n_slots / n_loaders, ne_ = slices ? (4u / n_loaders < 8u / n_loaders - nb_ ? 4u / n_loaders : 8u / n_loaders - nb_) : 0u;   // (a loader watches at most 8 / n_loaders slots)
-    const RingGeom geom{ring, nb_, tails, ne_, tail_bytes, n_loaders};
     if (w < n_loaders) {
 #ifdef HD_RING_LOADER_PRIO
         __builtin_amdgcn_s_setprio(HD_RING_LOADER_PRIO);
@@ -650,7 +647,7 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
         }
         // my slice of LDS is free from here on: a tile slot for the loaders (every LDS access of the tail has completed: its results are stored)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&ctl->tail_free[k], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) (void)__hip_atomic_fetch_or(&ctl->tail_mask, 1u << k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifndef HD_CU_NO_LATE_CONSUMERS
         __builtin_amdgcn_s_setprio(0);
         ring_consumer<T>(ra, geom, ctl, false, w);                       // the tail is done: one more wave for the tap loops
@@ -689,7 +686,7 @@ __global__ __launch_bounds__(D == 32 ? 1024 : 512) void k_stage1_cu(const RingAr
         }
         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)pick);
     }
-    const RingGeom geom{ring, (uint32_t)kRingNSLAlone * (3u - n_loaders), nullptr, 0u, 0u, n_loaders};
+    const RingGeom geom{ring, (uint32_t)kRingNSLAlone * (3u - n_loaders), nullptr, 0u, 0u, 0u, n_loaders};
     if (w < n_loaders) ring_loader<T>(ra, geom, ctl, w);
     else ring_consumer<T, D>(ra, geom, ctl, w == 2, w);
 }
@@ -826,6 +823,7 @@ bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2
 {
     if (n_loaders != 1u) n_loaders = 2u;
     if (n_slots != 5u || n_loaders != 1u) n_slots = 2u * (uint32_t)kRingNSL;
+    if (!n_tail && n_loaders == 1u && n_slots == 5u) n_slots = 8u;          // a launch without tails (the first after a flush): the whole CU's LDS is tile slots
     if (ratio != 32 || !claim.ctr || !uniform_n || uniform_n % 2048u) return false;
     RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, uniform_n / 2048u, claim, gave_up};
 #define HD_CU_CASE(T, D2, T2)                                                                                                         \

@@ -87,7 +87,9 @@ struct TailArgs {
     // spectrum of a stream whose 4096-sample buffer completes in this call, done by the tail itself when fft_tw != nullptr (spectrum_wave.h)
     const float2* fft_tw; float2* spec; float* power; SpectrumStatsDev* stats; double rate; int bins_sep;
     // LDS carve in bytes from the base of the workgroup's scratch (tail_layout)
-    uint32_t pend_max, f_off, v_off, ws_off, words_off, tp_off, h2_off, lmask_off, flips_off, fl_cap, strips_off, wc_off, wc_cap, vc_off, vc_cap, lds_bytes;
+    // (search phase, overlaying the stream windows: [header][flip list + run info][run-sum strips] at fixed offsets, then from dyn_off to lds_bytes a region
+    // every stream carves for itself: the flag-mask image of its searchable backlog, a sample cache for the run sums, a window-sum cache for the edge search)
+    uint32_t pend_max, f_off, v_off, ws_off, words_off, tp_off, h2_off, flips_off, fl_cap, strips_off, dyn_off, lds_bytes;
 };
 // Fills the LDS carve for `lanes` (64 or 256) lanes per stream; returns false when (ratio2, ntaps2) has no tail instantiation or the
 // windows for max_taps / max_R do not fit into lds_limit bytes -- the caller then runs launch_backend / launch_decimate + launch_fir_demod

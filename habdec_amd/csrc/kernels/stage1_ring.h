@@ -79,18 +79,52 @@ struct RingCtl {
                             // carries l so that the impossible is detected, not assumed.)
     uint32_t simd_rank[4];  // waves of the workgroup that have arrived on each SIMD (role assignment, k_step_cu)
     uint32_t roles_taken;   // bit w: role w has a wave
-    uint32_t tail_free[4];  // tail slice k holds no tail any more (or never did): the loaders may land tiles in it
+    uint32_t tail_mask;     // bit k: tail slice k holds no tail any more (or never did): the loaders may land tiles in the extra slots that lie in it
+    uint32_t _pad2[3];
 };
 static_assert(sizeof(RingCtl) <= kRingCtlBytes, "ring control block");
 
 // Where a loader's tile slots are.  One loader owns them all (up to eight); each of two loaders owns up to four: `nb` of them in the ring region proper, and -- inside a step launch --
-// `ne` more that are the LDS slices of stream tails: slice k becomes a slot when its tail is done (RingCtl::tail_free[k]; a slice is at least a
-// slot long).  Local slot j of loader L: j < nb: ring + (L * nb + j) * SLOT; else extra + (L * ne + j - nb) * extra_stride.
+// `ne` more that lie in the LDS slices of the stream tails: extra slot g (loader L's local slot j >= nb is g = L * ne + j - nb) sits xoff[g] bytes into the
+// tails' region and becomes a slot when every tail whose slice it touches is done (xneed[g]: bits of RingCtl::tail_mask).  A slice at least a slot
+// long is a slot of its own (the four-slot layouts); shorter slices (the five-slot layout: 16 720-byte tails, 19 312-byte slots) are taken in
+// neighbouring pairs -- three slots out of four slices, the launch's second half on eight slots instead of five.
 struct RingGeom {
     unsigned char* ring; uint32_t nb;
-    unsigned char* extra; uint32_t ne, extra_stride;
+    unsigned char* extra; uint32_t ne;
+    uint32_t xstride;       // extra slot g starts (g * xstride) & ~15 bytes into the tails' region (a formula, not a table: the struct must stay in registers)
+    uint32_t xslice;        // bytes per tail slice (which tails an extra slot waits for follows from where it lies)
     uint32_t nl;            // loader waves: 2, or 1 (which then owns every slot: nb + ne <= 8, and all sixteen descriptor entries)
 };
+
+// The extra slots of a step launch: `tail_bytes` per slice, four slices, `slot` bytes per tile slot, `room` = how many extra slots the loaders can watch
+__device__ __forceinline__ void ring_extra_slots(RingGeom& g, const uint32_t tail_bytes, const uint32_t slot, const uint32_t room, const bool tails_present)
+{
+    g.ne = 0; g.xstride = 0; g.xslice = tail_bytes;
+    if (!tails_present || !room) return;
+    uint32_t n = 0;
+    if (tail_bytes >= slot) {                               // a slice is a slot
+        n = room < 4u ? room : 4u;
+        g.xstride = tail_bytes;
+    } else if (g.nl == 1u) {                                // slots across neighbouring slices, spread over the region (first at its start, last at its end)
+        n = 4u * tail_bytes / slot;
+        if (n > room) n = room;
+        if (n > 4u) n = 4u;
+        g.xstride = n > 1u ? (4u * tail_bytes - slot) / (n - 1u) : 0u;
+    }
+    g.ne = n / g.nl;                                        // per loader
+}
+__device__ __forceinline__ uint32_t ring_extra_off(const RingGeom& g, const uint32_t i) { return (i * g.xstride) & ~15u; }
+template <int SLOT>
+__device__ __forceinline__ uint32_t ring_extra_need(const RingGeom& g, const uint32_t i)       // bits of RingCtl::tail_mask
+{
+    const uint32_t off = ring_extra_off(g, i);
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (off < (uint32_t)(k + 1) * g.xslice && off + (uint32_t)SLOT > (uint32_t)k * g.xslice) m |= 1u << k;
+    return m;
+}
 
 struct RingArgs {
     const float2* in; size_t in_stride;             // this call's IQ slab
@@ -145,8 +179,11 @@ __device__ __forceinline__ void glds4(const void* base, uint32_t off, uint32_t l
 __device__ __forceinline__ void glds16_x17(const void* base, const uint32_t (&off)[17], uint32_t lds_dst)
 {
     unsigned keep, scc_keep;                      // (s_add_u32 writes SCC, which compiler code around the statement may hold live: saved and restored)
-#ifdef HD_GLDS_NT                                // cache policy of the body rows' LDS-DMA: " nt" for once-read bytes (the halo rows, which the previous tile of
-#define HD_GLDS_BODY_POLICY " nt"                // the run has just brought into this XCD's L2, stay on the default policy)
+// Cache policy of the body rows' LDS-DMA: nt -- these bytes are read exactly once (measured on one box, alternating builds: step launch 158.8 ->
+// 156.2 us, stage 1 alone 115.6 -> 111.2; MI355X_MICROARCH.md rows ldsdma-fill / nt-weights).  The halo rows, which the previous tile of the run has
+// just brought into this XCD's L2, stay on the default policy.  -DHD_GLDS_DEFAULT_POLICY: the A/B build.
+#ifndef HD_GLDS_DEFAULT_POLICY
+#define HD_GLDS_BODY_POLICY " nt"
 #else
 #define HD_GLDS_BODY_POLICY ""
 #endif
@@ -184,9 +221,14 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
     constexpr int NBODY = 17;                       // 64 rows x 17 chunks = 17 x 64 chunks
     constexpr int NHALO = (HR * 17 + 63) / 64;      // halo rows out of the stream itself (every tile but a stream's first)
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t base_lds = lds_addr_of(geo.ring) + L * geo.nb * (uint32_t)SLOT;
-    const uint32_t extra_lds = geo.ne ? lds_addr_of(geo.extra) + L * geo.ne * geo.extra_stride : 0u;
     const uint32_t nslots = geo.nb + geo.ne;             // <= 4 (two loaders), <= 8 (one)
+    // lane j < nslots watches my local slot j: where it is, and which tails must be done before it may be used (none for the ring region's slots)
+    uint32_t my_dst = lds_addr_of(geo.ring) + (L * geo.nb + lane) * (uint32_t)SLOT, my_need = 0;
+    if (lane >= geo.nb && lane < nslots) {
+        const uint32_t g = L * geo.ne + lane - geo.nb;
+        my_dst = lds_addr_of(geo.extra) + ring_extra_off(geo, g);
+        my_need = ring_extra_need<SLOT>(geo, g);
+    }
     const uint32_t dmask = geo.nl == 1u ? 15u : 7u;      // descriptor entries per loader - 1
 
     // per-lane source offsets (bytes from the tile's first body row / first halo row)
@@ -266,15 +308,15 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
             if (lane < nslots) {
                 const uint32_t dn = __hip_atomic_load(&ctl->slot_done[4u * L + lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 ok = my_seq == 0xFFFFFFFFu || dn == my_seq + 1u;
-                if (ok && lane >= geo.nb) ok = __hip_atomic_load(&ctl->tail_free[L * geo.ne + lane - geo.nb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
+                if (ok && my_need) ok = (__hip_atomic_load(&ctl->tail_mask, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & my_need) == my_need;
             }
             free_mask = __ballot(ok);
         }
         if (free_mask) {
             const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(free_mask));
-            const uint32_t dst = slot < geo.nb ? base_lds + slot * (uint32_t)SLOT : extra_lds + (slot - geo.nb) * geo.extra_stride;
+            const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)my_dst, (int)slot);
             const unsigned char* body = reinterpret_cast<const unsigned char*>(a.in + (size_t)s * a.in_stride) + (size_t)tile * (64u * 256u);
-            if (lane == 0) ctl->desc[8u * L + (issued & dmask)] = make_uint4(s, tile, slot, issued);
+            if (lane == 0) ctl->desc[8u * L + (issued & dmask)] = make_uint4(s, tile, slot | (dst << 4), issued);      // (LDS addresses are below 2^18)
             if (lane == slot) my_seq = issued;
             uint32_t cnt = NBODY;
             if (tile == 0) {
@@ -365,7 +407,6 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
                                               const uint32_t role /* the wave's role number in the workgroup (diagnostic builds: its row in the stamp table) */)
 {
     constexpr int HR = ring_halo_rows<T>();
-    constexpr int SLOT = ring_slot_bytes<T>();
     constexpr int JS = HR * 32 - (T - 1);           // slot of tap 0, counted from column 0 of the lane's first row
     constexpr int NS = JS + T;                      // taps sit on slots [JS, NS)
     constexpr int C0 = JS / 16, C1 = (NS - 1) / 16; // first and last 16-slot chunk that carries taps
@@ -438,13 +479,12 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
         RSTAMP(0);
         const uint4 d = ctl->desc[8u * L + (seq & (geo.nl == 1u ? 15u : 7u))];
         const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.x), tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y),
-                       slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z);
+                       slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z) & 15u, slot_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z) >> 4;
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)d.w) != seq) {   // (the entry was reused under this wave's feet: cannot happen, see RingCtl::desc)
             if (lane == 0) (void)__hip_atomic_fetch_add(a.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
-        const unsigned char* p = (slot < geo.nb ? geo.ring + (L * geo.nb + slot) * (uint32_t)SLOT : geo.extra + (L * geo.ne + slot - geo.nb) * geo.extra_stride) +
-                                 lane * (uint32_t)kRingRowBytes;
+        const unsigned char* p = geo.ring + (slot_lds - lds_addr_of(geo.ring)) + lane * (uint32_t)kRingRowBytes;
 
         if constexpr (D == 32) {
         // the T-term sum in tap order: 16-slot chunks (half rows), the next chunk's samples and taps requested before the current one is summed

@@ -201,5 +201,36 @@ __device__ __forceinline__ uint32_t find_flag_lds(const unsigned long long* lmas
     return 0xFFFFFFFFu;
 }
 
+// The same search over a COMPACT image of the mask: lmask[i] is ring word (wr0 >> 6) + i, wr0 = the (64-aligned) ring position of the first
+// word a search can touch -- the image then takes as many words as the searched backlog has, not as many as the ring (tail_body.h).
+__device__ __forceinline__ uint32_t find_flag_rel(const unsigned long long* lmask, uint32_t base, uint32_t wr0,
+                                                  uint32_t from, uint32_t to, bool want)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wrs = (base + from) & ~63u;
+    for (uint32_t it = 0;; ++it) {
+        const uint32_t wstart = wrs + it * 4096u;
+        if ((int32_t)(wstart - base) >= (int32_t)to) break;
+        const uint32_t wr = wstart + lane * 64u;
+        const int32_t lw = (int32_t)(wr - base);
+        unsigned long long w = 0;
+        if (lw < (int32_t)to) {
+            w = lmask[(wr - wr0) >> 6];
+            if (!want) w = ~w;
+            const int32_t lo = (int32_t)from - lw;
+            if (lo > 0) w = lo >= 64 ? 0ull : (w & (~0ull << lo));
+            const int32_t hi = (int32_t)to - lw;
+            if (hi < 64) w &= (1ull << hi) - 1ull;
+        }
+        const unsigned long long hit = __ballot(w != 0ull);
+        if (hit) {
+            const int src = __ffsll((long long)hit) - 1;
+            const unsigned long long ww = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), src) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, src);     // src is wave-uniform
+            return (uint32_t)((int32_t)(wstart - base) + src * 64 + (__ffsll((long long)ww) - 1));
+        }
+    }
+    return 0xFFFFFFFFu;
+}
 
 }  // namespace hd

@@ -40,26 +40,25 @@ bool tail_layout(TailArgs& a, int lanes, int ratio2, int ntaps2, uint32_t max_ta
     a.tp_off = off; off += ((max_taps + 8 + 3) & ~3u) * 4;
     a.h2_off = off; off += (((uint32_t)ntaps2 + 7) & ~3u) * 4;
     const uint32_t stream_phase = off;
-    // search phase (overlays the windows above): flag-mask image, flip list, run info, run-sum strips, window-sum cache
+    // search phase (overlays the windows above): flip list, run info and run-sum strips at fixed offsets, then the region each stream carves for
+    // itself (tail_body.h): flag-mask image of the backlog it searches | cached samples | cached window sums
     off = kTailHdrBytes;
-    a.lmask_off = off; off += (ring_cap / 64) * 8;
     uint32_t fl_cap = ring_cap / (min_R ? min_R : 4u) + 2u;              // a flip point moves the search on by R
     fl_cap = (fl_cap + 63u) & ~63u;
     if (fl_cap > kMaxFlipsPerCall) fl_cap = kMaxFlipsPerCall;           // (the same bound on every path: sym_common.h)
     a.fl_cap = fl_cap;
     a.flips_off = off; off += fl_cap * 8;
     a.strips_off = off; off += (NT / 64) * kTailStrip * 4;
-    a.wc_off = off;
-    uint32_t need = stream_phase > off + 6144 ? stream_phase : off + 6144;   // at least 1024 cached window sums + 512 cached samples
+    a.dyn_off = off;
+    // the mask image of the longest backlog there can be (the whole ring) must fit; in the common case (a few symbols of backlog) the mask takes
+    // a few hundred bytes and the region should hold at least 1024 cached window sums + 512 cached samples
+    const uint32_t dyn_min = (ring_cap / 64) * 8 > 6144u + 512u ? (ring_cap / 64) * 8 : 6144u + 512u;
+    uint32_t need = stream_phase > off + dyn_min ? stream_phase : off + dyn_min;
     if (need < kTailHdrBytes + kSpecWaveLds) need = kTailHdrBytes + kSpecWaveLds;   // the spectrum's transpose plane (spectrum_wave.h) reuses the scratch at the end
     if (need > lds_limit) return false;
-    uint32_t want = off + 4 * (2560 + 1536);                             // window sums of ~four symbols of backlog at 50 baud, samples of one call and a half
+    uint32_t want = off + 512u + 4 * (2560 + 1536);                      // mask + window sums of ~four symbols of backlog at 50 baud + samples of one call and a half
     if (want < need) want = need;
-    a.lds_bytes = want < lds_limit ? want : lds_limit;
-    const uint32_t room = ((a.lds_bytes - a.wc_off) / 4) & ~3u;          // split 5 : 3 between the window-sum cache and the sample cache
-    a.wc_cap = (room * 5 / 8) & ~3u;
-    a.vc_off = a.wc_off + a.wc_cap * 4;
-    a.vc_cap = room - a.wc_cap;
+    a.lds_bytes = (want < lds_limit ? want : lds_limit) & ~15u;
     return true;
 }
 

@@ -626,11 +626,21 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     const bool hunt = m && do_sums && search;
     const uint32_t limit = hunt ? h - q.spb : 0u;                      // backlog indices searched: [R, limit)
     const uint32_t carried_to = st.run_pos - st.base;
-    const uint32_t wc_n = (hunt && limit <= a.wc_cap) ? limit : 0u;    // window sums of the searchable backlog, when they fit
-    // the run sums add up the backlog samples [carried_to, frontier) (frontier <= limit), in pieces
-    const uint32_t vc_n = (hunt && limit > carried_to && limit - carried_to <= a.vc_cap) ? limit - carried_to : 0u;
     const uint32_t wr0 = (st.base + R) & ~63u;
     const uint32_t nw = hunt ? ((st.base + limit) - wr0 + 63u) >> 6 : 0u;
+    // This stream's carve of the search-phase region [dyn_off, lds_bytes): the flag-mask image of the backlog it searches (nw words: a few dozen for
+    // a few symbols of backlog, the whole ring's worth for a stream that has been idle for seconds), then the sample cache the run sums add up from
+    // -- [carried_to, limit), i.e. about one call's worth -- and the window sums of the searchable backlog [0, limit) with what is left.  Either cache
+    // may hold only a prefix: what lies behind it comes from the global rings as before (a round trip per edge zone / per strip of a run -- which is
+    // what made the busiest streams' tails the longest waves of a step launch while the caches were all-or-nothing and a 4 KiB mask image sat in front).
+    const uint32_t lmw = (nw + 1u) & ~1u;
+    const uint32_t dyn_floats = hunt ? (((a.lds_bytes - a.dyn_off) - lmw * 8u) >> 2) & ~3u : 0u;
+    const uint32_t vc_want = (hunt && limit > carried_to) ? limit - carried_to : 0u;
+    const uint32_t vc_cap = min((vc_want + 3u) & ~3u, (dyn_floats * 5u / 8u) & ~3u);
+    const uint32_t wc_cap = dyn_floats - vc_cap;
+    const uint32_t wc_n = hunt ? min(limit, wc_cap) : 0u;              // window sums [0, wc_n) of the backlog
+    // the run sums add up the backlog samples [carried_to, frontier) (frontier <= limit), in pieces
+    const uint32_t vc_n = min(vc_want, vc_cap);                        // samples [carried_to, carried_to + vc_n)
     constexpr int MB = 512 / NT, CB = 1024 / NT, SB = 1024 / NT;
     unsigned long long tm0[MB];
     float tc0[CB], ts0[SB];
@@ -686,23 +696,23 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         }
         return;
     }
-    unsigned long long* lmask = reinterpret_cast<unsigned long long*>(lds + a.lmask_off);
+    unsigned long long* lmask = reinterpret_cast<unsigned long long*>(lds + a.dyn_off);   // lmask[i]: ring word (wr0 >> 6) + i
     uint32_t* flips = reinterpret_cast<uint32_t*>(lds + a.flips_off);
     uint32_t* runinfo = flips + a.fl_cap;
     float* strips = reinterpret_cast<float*>(lds + a.strips_off);
-    float* wc = reinterpret_cast<float*>(lds + a.wc_off);
-    float* vc = reinterpret_cast<float*>(lds + a.vc_off);              // vc[k] = backlog sample carried_to + k
+    float* vc = reinterpret_cast<float*>(lds + a.dyn_off + lmw * 8u);  // vc[k] = backlog sample carried_to + k
+    float* wc = vc + vc_cap;                                            // wc[k] = window sum of backlog position k
     const uint32_t fl_cap = a.fl_cap;
     tb_sync<NT>();                                                      // the slide above read the stream windows these images overwrite
     {
 #pragma unroll
-        for (int u = 0; u < MB; ++u) { const uint32_t i = tid + u * NT; if (i < nw) lmask[((wr0 + 64u * i) & rmask) >> 6] = tm0[u]; }
+        for (int u = 0; u < MB; ++u) { const uint32_t i = tid + u * NT; if (i < nw) lmask[i] = tm0[u]; }
 #pragma unroll
         for (int u = 0; u < CB; ++u) { const uint32_t k = tid + u * NT; if (k < wc_n) wc[k] = tc0[u]; }
 #pragma unroll
         for (int u = 0; u < SB; ++u) { const uint32_t k = tid + u * NT; if (k < vc_n) vc[k] = ts0[u]; }
         // longer backlogs than the first batches cover (idle or freshly re-parameterised streams): plain loops
-        for (uint32_t i = tid + MB * NT; i < nw; i += NT) { const uint32_t wi = ((wr0 + 64u * i) & rmask) >> 6; lmask[wi] = gmask[wi]; }
+        for (uint32_t i = tid + MB * NT; i < nw; i += NT) lmask[i] = gmask[((wr0 + 64u * i) & rmask) >> 6];
         for (uint32_t k = tid + CB * NT; k < wc_n; k += NT) wc[k] = gw[(st.base + k) & rmask];
         for (uint32_t k = tid + SB * NT; k < vc_n; k += NT) vc[k] = vring[(st.base + carried_to + k) & rmask];
     }
@@ -713,9 +723,9 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         uint32_t pos = R, nfl = 0, overflow = 0;
         uint32_t frontier = 0xFFFFFFFFu;                                // backlog index no future flip point can precede
         while (pos < limit) {
-            const uint32_t lo = find_flag_lds(lmask, st.base, rmask, pos, limit, true);
+            const uint32_t lo = find_flag_rel(lmask, st.base, wr0, pos, limit, true);
             if (lo == 0xFFFFFFFFu) break;
-            const uint32_t hi = find_flag_lds(lmask, st.base, rmask, lo + 1, limit, false);
+            const uint32_t hi = find_flag_rel(lmask, st.base, wr0, lo + 1, limit, false);
             if (hi == 0xFFFFFFFFu) { frontier = lo; break; }            // an edge zone is open: the next flip lies at or after lo
             unsigned long long key = 0ull;                              // first maximum of the weight over [lo, hi): (weight bits, ~index)
             constexpr int ZB = 4;
@@ -883,12 +893,14 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     // ---- the stream's spectrum, when its 4096-sample buffer completed in this call (Decoder.h:475-489): transform, half swap, power and
     // AFC statistics by this same wave (spectrum_wave.h) -- no launches of their own, no fft_raw round trip.  The buffer's last samples
     // were stored by this workgroup a moment ago.
+#ifndef HD_TB_NO_SPECTRUM     // (register-budget experiments: the tail without the in-wave transform)
     if (a.fft_tw && c.fft_run) {
         __threadfence_block();
         tb_sync<NT>();                                                  // every wave is done with the LDS images
         if (wave == 0)
             spectrum_wave_body(a.fft_in, a.fft_tw, a.spec, a.power, a.stats, s, a.rate, a.bins_sep, reinterpret_cast<float*>(lds + kTailHdrBytes));
     }
+#endif
     TSTAMP_WRITE();
 }
 

@@ -38,9 +38,11 @@ def main():
     ap.add_argument("--workload", default="cfg4"); ap.add_argument("--steps", type=int, default=100); ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--rounds", type=int, default=3); ap.add_argument("--sync", action="store_true"); ap.add_argument("--streams", type=int, default=0)
     ap.add_argument("--timing", type=int, default=3)
+    ap.add_argument("--no-offsets", action="store_true", help="cfg4 without its far-off-tune streams (every stream within +-200 Hz... of nothing: all on tune)")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     w = dict(bench.WORKLOADS[a.workload]); S = a.streams or w["S"]; Cn = w["C"]
+    if a.no_offsets: w["offsets"] = False
     dev = torch.device("cuda", 0)
     ring, rc, _ = bench.generate_ring(torch, dev, w, S, 0, 1234)
     base = ring.data_ptr()
@@ -56,10 +58,10 @@ def main():
             capi._lib = L                                   # (Engine() and check() go through capi.lib())
             eng = engine.Engine(n_streams=S, max_chunk=Cn, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"],
                                 lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"], pipeline=0 if a.sync else 2)
-            for k in env: os.environ.pop(k, None)
             eng.set_timing(a.timing)
             for i in range(a.warmup): eng.process_device(base + (i % rc) * S * Cn * 8, Cn, Cn)
             eng.flush(); torch.cuda.synchronize()
+            for k in env: os.environ.pop(k, None)           # (some knobs are read at the first call, not at engine creation)
             fr = []; seen = eng.timing()["timed_calls"]
             t0 = time.perf_counter()
             for i in range(a.warmup, a.warmup + a.steps):
