@@ -179,7 +179,11 @@ def oracle_sample_check(w, eng, ring, chunks, C, streams, lookup_mode=1):
     gpu_bits = [eng.bits_total(s) for s in streams]
     n_chars, n_bits = int(sum(len(x.chars) for x in logs)), int(sum(x.bits for x in logs))
     same = gpu_sent == [list(x) for x in logs] and gpu_chars == [x.chars for x in logs] and gpu_bits == [x.bits for x in logs]
-    return {"gpu_matches_oracle_on_sample": (bool(same) if n_bits else None),
+    diff = [(int(s), f) for i, s in enumerate(streams) for f, g, o in (("sentences", gpu_sent[i], list(logs[i])), ("chars", gpu_chars[i], logs[i].chars), ("bits", gpu_bits[i], logs[i].bits)) if g != o]
+    if diff:
+        i = list(streams).index(diff[0][0])
+        sys.stderr.write(f"[bench] self-check mismatch {diff[:8]}: stream {diff[0][0]} gpu bits {gpu_bits[i]} chars {gpu_chars[i]!r} / oracle bits {logs[i].bits} chars {logs[i].chars!r}\n")
+    return {"gpu_matches_oracle_on_sample": (bool(same) if n_bits else None), "mismatches": diff[:8],
             "compared": "per stream: symbols produced, characters emitted, sentences -- GPU engine vs oracle over warm-up + timed steps",
             "streams_in_sample": [int(x) for x in streams] if len(streams) <= 8 else len(streams),
             "bits_in_sample": n_bits, "chars_in_sample": n_chars, "sentences_in_sample": int(sum(len(x) for x in logs))}
@@ -250,6 +254,10 @@ class Shard:
                                      rtty_stops=w["stops"], lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"],
                                      device=device_index, pipeline=0 if sync else int(os.environ.get("HD_BENCH_PIPELINE", "2")))
         self.ring, self.ring_chunks, self.texts = generate_ring(torch, self.dev, w, S, rank, seed=1234 + rank)
+        # The ring is generated on torch's stream, the engine launches on its own queues: without this wait the warm-up steps run while the last
+        # streams' slabs are still being written (rounds 1-3 did -- harmless for the timing, but the self-check then compares the oracle's run over the
+        # final data with a GPU run that saw unfinished data in its first calls; it went unnoticed because only the first streams were sampled).
+        torch.cuda.synchronize(self.dev)
         self.eng.set_timing(3)     # HIP-event brackets on every 3rd call (each record is a barrier packet worth microseconds of queue time; 3, not 4: every 4th
                                    # launch carries the streams' spectra, and the sample must see light and heavy launches in their true proportion)
         self.base = self.ring.data_ptr()

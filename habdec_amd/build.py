@@ -16,6 +16,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "libhabdec_amd.so"
+FAULT_OUT = HERE / "libhabdec_amd_fault.so"
 SOURCES = ["engine.cpp", "host_api.cpp", "kernels/decimate.hip", "kernels/fir_demod.hip", "kernels/backend.hip", "kernels/spectrum.hip", "kernels/spectrum_wave.hip", "kernels/symbols.hip", "kernels/tail.hip"]
 ARCH = "gfx950"
 
@@ -27,10 +28,10 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def _stale() -> bool:
-    if not OUT.exists():
+def _stale(out: Path = OUT) -> bool:
+    if not out.exists():
         return True
-    t = OUT.stat().st_mtime
+    t = out.stat().st_mtime
     deps = list(CSRC.rglob("*.hip")) + list(CSRC.rglob("*.cpp")) + list(CSRC.rglob("*.h")) + list(CSRC.rglob("*.hpp")) + \
         list(CSRC.rglob("*.inc")) + [HERE.parent / "include" / "habdec_amd.h", Path(__file__)]
     return any(d.stat().st_mtime > t for d in deps)
@@ -41,7 +42,13 @@ def build(force: bool = False, verbose: bool = False, variant: str | None = None
     gpurun_in/variants/libhd_<variant>.so (tools/micro/ab_step.py loads several of them into one process); flags from HD_EXTRA_FLAGS."""
     variant = variant or os.environ.get("HD_BUILD_VARIANT") or None
     target = OUT
-    if variant:
+    if variant == "fault":
+        # the fault-injection library of tests/test_gpu_fault.py: one LDS-DMA loader of the process drops a tile's publish (-DHD_RING_FAULT), so
+        # that the bounded waits, the give-up word and the engine's failed state are exercised end to end.  In-tree beside the product library.
+        target = FAULT_OUT
+        if not force and target.exists() and not _stale(target):
+            return target
+    elif variant:
         target = HERE.parent / "gpurun_in" / "variants" / f"libhd_{variant}.so"
         target.parent.mkdir(parents=True, exist_ok=True)
     elif not force and not _stale():
@@ -49,7 +56,7 @@ def build(force: bool = False, verbose: bool = False, variant: str | None = None
     objs = []
     build_dir = HERE / "build" / variant if variant else HERE / "build"
     build_dir.mkdir(parents=True, exist_ok=True)
-    extra = os.environ.get("HD_EXTRA_FLAGS", "").split()
+    extra = os.environ.get("HD_EXTRA_FLAGS", "").split() + (["-DHD_RING_FAULT"] if variant == "fault" else [])
     common = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
               # (the atomic optimiser rewrites lane 0's ticket draw in the step kernel into a form that needs the old value at once: the wave
               # would wait for the round trip it issues a tile early precisely not to wait for)

@@ -135,9 +135,12 @@ struct hd_engine {
     bool cu_slots4 = false;         // HD_CU_SLOTS=4: never five tile slots in a step launch (A/B measurements)
     uint32_t ring_run = 0;     // HD_RING_RUN: tiles per drawn run of k_step_cu's loader (default 8)
     uint32_t ring_loaders = 1; // HD_RING_LOADERS: LDS-DMA waves per CU in a step launch (1 or 2; one leaves SIMD 1 two computing waves: 0.157 against 0.160 ms per launch)
-    uint32_t s1_loaders = 1;   // HD_S1_LOADERS: ... when stage 1 is a launch of its own (/32: no difference; /8: 0.350 against 0.360 ms per step)
+    uint32_t s1_loaders = 2;   // HD_S1_LOADERS: ... when stage 1 is a launch of its own.  Two since round 4: with the nt policy on the body rows one loader's 3 tiles in
+                               // flight (its 6-bit vmcnt holds 57 DMA instructions) are what bounds the launch -- 102.7 us with one loader, 94.7 with two (one box, alternating)
     uint32_t s1_waves = 8;     // HD_S1_WAVES: waves per workgroup of k_stage1_cu (8 .. 16)
-    PinBuf<unsigned int> ring_gave_up;     // mapped host word the waves of k_step_cu bump when a bounded wait runs out (never in a correct run)
+    PinBuf<unsigned int> ring_gave_up;     // mapped host word a wave of k_step_cu / k_stage1_cu sets when a bounded wait runs out (never in a correct run)
+    bool device_failed = false;            // ... after which the engine stays failed: the launch that gave up left stage-1 output incomplete, and up to
+                                           // three calls are undelivered by the time a collect() sees the word -- which of them it was cannot be told
     uint64_t step_launches = 0;
     DevBuf<unsigned int> step_ctr;         // two sets of per-XCD run counters ([2][16][32] u32), alternating per step launch
     uint32_t qa_cus = 0;       // HD_CU_SPLIT experiment: CUs the stage-1 queue may use (0 = all)
@@ -681,12 +684,10 @@ int collect(hd_engine* e, hd_engine::CallSlot& sl)
         ++e->last_timing.timed_calls;
     }
     int rc = HD_OK;
-    if (e->ring_gave_up.p && e->ring_gave_up.p[0]) {
-        char msg[128];
-        snprintf(msg, sizeof msg, "k_step_cu: a bounded wait ran out (consumers %u, loaders %u): results of this call are incomplete", e->ring_gave_up.p[0] & 0xFFFFu, e->ring_gave_up.p[0] >> 16);
-        e->ring_gave_up.p[0] = 0;
-        rc = fail(HD_ERR_DEVICE, msg);
-    }
+    if (e->ring_gave_up.p && e->ring_gave_up.p[0]) e->device_failed = true;
+    if (e->device_failed)
+        rc = fail(HD_ERR_DEVICE, "k_step_cu / k_stage1_cu: a bounded wait ran out inside a launch (word " + std::to_string(e->ring_gave_up.p ? e->ring_gave_up.p[0] : 0u) +
+                                 "): the results of this and of every later call of this engine are unreliable -- destroy the engine");
     for (uint32_t s = 0; s < e->S; ++s) {
         StreamHost& st = e->st[s];
         const hd::StreamCall& c = sl.h_call.p[s];
@@ -705,7 +706,7 @@ int collect(hd_engine* e, hd_engine::CallSlot& sl)
         st.last_nbits = hdr->nbits; st.last_nflips = hdr->nflips;
         st.bits_total += hdr->nbits;
         st.demod_ck[0] = hdr->demod_ck[0]; st.demod_ck[1] = hdr->demod_ck[1]; st.demod_ck_n = hdr->demod_n; st.demod_ck_call = e->delivered;
-        if (hdr->overflow) rc = fail(HD_ERR_CAPACITY, "symbol result slot overflow on stream " + std::to_string(s));
+        if (hdr->overflow && rc != HD_ERR_DEVICE) rc = fail(HD_ERR_CAPACITY, "symbol result slot overflow on stream " + std::to_string(s));
         const uint32_t* words = slot + sizeof(hd::BitsHeader) / 4;
         st.last_words.assign(words, words + (hdr->nbits + 31) / 32);
         if (!c.fir_m) continue;
@@ -754,6 +755,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     if ((reinterpret_cast<uintptr_t>(d_iq) & 15) || (stride & 1)) return fail(HD_ERR_INVALID, "IQ base must be 16-byte aligned and stream_stride even");
     std::lock_guard<std::recursive_mutex> lock(e->mtx);
     if (e->in_callback) return fail(HD_ERR_INVALID, "hd_process_* cannot be called from a sentence / character callback");   // (a nested delivery would count the slot being delivered twice)
+    if (e->device_failed) return fail(HD_ERR_DEVICE, "this engine is in its failed state (a bounded wait ran out inside an earlier launch): no new calls are accepted -- destroy the engine");
     const auto h0 = std::chrono::steady_clock::now();
     HD_HIP(hipSetDevice(e->cfg.device));
     const uint32_t S = e->S;
@@ -961,8 +963,10 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         // leaves the device copy the tails (next launch) and the spectrum commit read.
         // Five tile slots instead of four where the tails' windows fit what that leaves (one loader; the compact 64-lane carve of tail.hip at 161
         // taps and R = 160 fits with a few dozen bytes to spare): this call's tails are laid out for it now, the launch that runs them decides.
-        const uint32_t cu_tail5 = (e->ring_loaders == 1u && !e->cu_slots4) ? hd::step_cu_tail_lds((int)R1, (int)T1, 5u) : 0u;
-        if (cu_tail5 && !e->no_cu_step) {
+        // (... and only where k_step_cu can serve the plan and the sizes at all: the single-wave fallback would run its tails with smaller caches for nothing)
+        const bool cu_shape = !e->no_cu_step && !e->no_claim && !any_zero1 && max_in % 2048u == 0 && hd::step_cu_supported((int)R1, (int)T1, (int)R2, (int)T2);
+        const uint32_t cu_tail5 = (cu_shape && e->ring_loaders == 1u && !e->cu_slots4) ? hd::step_cu_tail_lds((int)R1, (int)T1, 5u) : 0u;
+        if (cu_tail5) {
             hd::TailArgs ta5{};
             if (hd::tail_layout(ta5, 64, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, cu_tail5)) ta_step = ta5;
         }
@@ -976,8 +980,9 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         const uint32_t ntiles1 = (max_n1 + 63) / 64;
         uint32_t ring_run = e->ring_run >= 2 ? e->ring_run : 8u;
         while (ring_run > 2 && (ntiles1 % ring_run || ((uint64_t)S * ntiles1 / ring_run) % (e->n_cus / 32u ? e->n_cus / 32u : 1u))) ring_run >>= 1;
+        if (ring_run < 2u) ring_run = 2u;                      // (k_step treats shorter runs as "not drawn" while the counter sets have already alternated)
         static const int cu_exp0 = getenv("HD_CU_EXP") ? atoi(getenv("HD_CU_EXP")) : 0;
-        const bool want_cu = !e->no_cu_step && cu_tail && !any_zero1 && max_in % 2048u == 0 && ((cu_exp0 & 1) || (ta_step.lds_bytes <= cu_tail &&
+        const bool want_cu = cu_shape && cu_tail && ((cu_exp0 & 1) || (ta_step.lds_bytes <= cu_tail &&
                              (!prev.valid || prev.ta.lds_bytes <= cu_tail)));
         const hd::StepClaim claim = make_claim(0, want_cu ? ring_run : 0u);
         if (claim.ctr && !e->step_wgs) wgs = 8u * e->n_cus;

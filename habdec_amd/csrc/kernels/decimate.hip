@@ -583,8 +583,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 64 ? 1 
 // stream tails -- four streams per CU at 1024 streams, each in its own slice of LDS -- leave the device copy of their streams' parameter
 // blocks for the next launch, and then join the computing waves.  Compared with k_step (single-wave workgroups, dispatcher-scheduled) the loads of stage 1 never stop
 // while the tails hold half of the CU's wave slots, and what runs where does not depend on the dispatcher.
+#ifndef HD_CU_WAVES
+#define HD_CU_WAVES 8          // waves of the step workgroup: 8 (two per SIMD at <= 256 VGPRs); 12 = the three-per-SIMD experiment (<= 168 VGPRs)
+#endif
 template <int T, int D2, int T2>
-__global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const StreamCall* __restrict__ call, StreamCall* __restrict__ call_copy,
+__global__ __launch_bounds__(64 * HD_CU_WAVES) void k_step_cu(const RingArgs ra, const StreamCall* __restrict__ call, StreamCall* __restrict__ call_copy,
                                                  const TailArgs ta, const uint32_t n_tail, const uint32_t n_streams, const uint32_t tail_bytes,
                                                  const uint32_t n_loaders /* 2: a loader on SIMD 0 and on SIMD 1; 1: SIMD 1 computes with both of its waves */,
                                                  const uint32_t n_slots /* tile slots in the ring region: 4, or (one loader, tails that fit beside them) 5, or (no tails in the launch) 8 */)
@@ -604,12 +607,19 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
     uint32_t rank = 0;
     if ((threadIdx.x & 63u) == 0) rank = __hip_atomic_fetch_add(&ctl->simd_rank[simd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)rank);
+#if HD_CU_WAVES == 12
+    // three waves per SIMD: a tail on every SIMD (role 8 + simd), the loader on SIMD 0 beside two computing waves, two computing waves on the others
+    constexpr uint32_t kPerSimd = 3u, kTailBase = 8u, kFeeder = 4u;
+    uint32_t w = rank == 0u ? 8u + simd : rank == 1u ? simd : 4u + simd;                                   // 0 loader, 1-7 computing, 8-11 tails
+#else
+    constexpr uint32_t kPerSimd = 2u, kTailBase = 4u, kFeeder = 2u;
     uint32_t w = simd < 2u ? (rank ? 2u + simd : simd) : 4u + 2u * (simd - 2u) + rank;                     // 0-1 loaders, 2-3 computing, 4-7 tails
-    // (Two per SIMD is what the register budget gives today; should a build ever fit a third wave on a SIMD, that wave takes one of the roles
+#endif
+    // (kPerSimd waves per SIMD is what the register budget gives; should the hardware ever place one more on a SIMD, that wave takes one of the roles
     // nobody claimed -- every role must be filled exactly once, whatever the placement.)
-    if (rank < 2u && (threadIdx.x & 63u) == 0) (void)__hip_atomic_fetch_or(&ctl->roles_taken, 1u << w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (rank < kPerSimd && (threadIdx.x & 63u) == 0) (void)__hip_atomic_fetch_or(&ctl->roles_taken, 1u << w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
-    if (rank >= 2u) {
+    if (rank >= kPerSimd) {
         uint32_t pick = 0;
         if ((threadIdx.x & 63u) == 0) {
             for (;;) {                                                       // claim the lowest role still free
@@ -621,6 +631,7 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)pick);
     }
 #else
+    constexpr uint32_t kTailBase = HD_CU_WAVES - 4u, kFeeder = 2u;
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #endif
     // Tile slots: the ring region's (four, five beside the compact tails, eight in a launch without tails), and -- as the tails finish -- slots inside
@@ -634,11 +645,11 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
         __builtin_amdgcn_s_setprio(HD_RING_LOADER_PRIO);
 #endif
         ring_loader<T>(ra, geom, ctl, w);
-    } else if (w < 4) {
-        ring_consumer<T>(ra, geom, ctl, w == 2, w);                      // (the wave beside loader 0 draws the runs)
+    } else if (w < kTailBase) {
+        ring_consumer<T>(ra, geom, ctl, w == kFeeder, w);                // (the wave beside loader 0 draws the runs)
     } else {
         __builtin_amdgcn_s_setprio(HD_STEP_PRIO);
-        const uint32_t k = w - 4u, lane = threadIdx.x & 63u;
+        const uint32_t k = w - kTailBase, lane = threadIdx.x & 63u;
         const uint32_t s = blockIdx.x * 4u + k;                          // (the grid has at least n_streams / 4 workgroups)
         if (s < n_streams) {
         if (s < n_tail) tail_body<64, 4, D2, T2>(ta, s, tails + k * tail_bytes);
@@ -837,12 +848,17 @@ bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_cu<T, D2, T2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) return false; \
             attr_set[dev_] = true;                                                                                                    \
         }                                                                                                                             \
-        hipLaunchKernelGGL((k_step_cu<T, D2, T2>), dim3(n_cus > (n_streams + 3u) / 4u ? n_cus : (n_streams + 3u) / 4u), dim3(512), lds, st, ra, call, call_copy, ta, n_tail, n_streams, tail_bytes, n_loaders, n_slots); \
+        hipLaunchKernelGGL((k_step_cu<T, D2, T2>), dim3(n_cus > (n_streams + 3u) / 4u ? n_cus : (n_streams + 3u) / 4u), dim3(64 * HD_CU_WAVES), lds, st, ra, call, call_copy, ta, n_tail, n_streams, tail_bytes, n_loaders, n_slots); \
         return true;                                                                                                                  \
     }
     HD_CU_CASE(212, 2, 69) HD_CU_CASE(174, 4, 139)
 #undef HD_CU_CASE
     return false;
+}
+
+bool step_cu_supported(int ratio, int ntaps, int ratio2, int ntaps2)
+{
+    return ratio == 32 && ((ntaps == 212 && ratio2 == 2 && ntaps2 == 69) || (ntaps == 174 && ratio2 == 4 && ntaps2 == 139));   // (HD_CU_CASE in launch_step_cu)
 }
 
 bool stage1_cu_supported(int ratio, int ntaps)

@@ -6,11 +6,13 @@
 // samples never go to HBM unless a parity test asks for them: per decimated sample the kernel reads 8 B and writes
 // 4 B, the "8/D + 4/D" terms of the pipeline's byte model.
 //
-// Mapping: grid = (tiles, streams), 256 lanes per tile, FOUR adjacent outputs per lane (4l .. 4l+3 within the tile) on a rolling
-// register window: one 16-byte LDS read (two samples) feeds eight packed multiply-adds, and the four independent sums let a wave
-// issue back to back (one sum per lane waits out the adder on every tap; two, as in rounds 1-2, left the kernel at half the
-// packed-f32 rate with 44 registers in use).  Taps come in blocks of sixteen through the scalar cache, requested a block ahead.
-// Tiles advance by 1020 outputs and overlap by four: lane 0 only recomputes the predecessor y[i-1] that lane 1's first output needs.  The per-stream input buffer keeps the FIR history right in front of the
+// Mapping: grid = (tiles, streams), 256 lanes per tile, SIX adjacent outputs per lane (6l .. 6l+5 within the tile) on a rolling
+// register window: one 16-byte LDS read (two samples) feeds twelve packed multiply-adds, and the six independent sums let a wave
+// issue back to back (one sum per lane waits out the adder on every tap).  Six, not four: consecutive lanes then start 48 bytes
+// apart, and three 16-byte chunks is an odd stride -- the sixteen lanes of each ds_read_b128 lane group fall into sixteen different
+// bank quads.  With four outputs per lane (32 bytes apart, round 3) two lanes of every group shared a quad: half of the kernel's LDS
+// cycles were bank conflicts (profiles/r03_other_shapes_pmc_sq.txt).  Taps come in blocks of sixteen through the scalar cache, requested a block ahead.
+// Tiles advance by 1530 outputs and overlap by six: lane 0 only recomputes the predecessor y[i-1] that lane 1's first output needs.  The per-stream input buffer keeps the FIR history right in front of the
 // pending samples, so a tile's 512+T-1 inputs are one contiguous, coalesced read into LDS.  Taps are per stream and
 // wave-uniform (scalar loads).
 #include <hip/hip_runtime.h>
@@ -34,18 +36,23 @@ extern "C" void hd_debug_fir_stamps(unsigned long long* host, size_t n) { (void)
 #endif
 
 constexpr int kFirLanes = 256;
-constexpr int kFirOut = 4;                       // adjacent outputs per lane
+#ifndef HD_FIR_OUT
+#define HD_FIR_OUT 6
+#endif
+constexpr int kFirOut = HD_FIR_OUT;              // adjacent outputs per lane (even; 6: lanes 48 bytes apart, conflict-free 16-byte LDS reads)
 constexpr int kFirTile = kFirOut * kFirLanes;    // outputs computed per tile
 constexpr int kFirAdvance = kFirTile - kFirOut;  // outputs written per tile (lane 0 only supplies lane 1's predecessor)
-constexpr int kFirSlack = 24;                    // samples a lane may read past its last tap (whole 16-tap blocks of a four-output window)
+constexpr int kFirWin = (16 + kFirOut) / 2;      // 16-byte pairs a block of sixteen taps touches (samples 0 .. 14 + kFirOut of the lane's window)
+constexpr int kFirSlack = 16 + 2 * kFirWin;      // samples a lane may read past its last tap (the re-read last block of a kFirOut-output window)
+static_assert(kFirOut % 2 == 0 && kFirOut >= 2 && kFirOut <= 8, "outputs per lane: pairs of samples, lane windows 16-byte aligned");
 
 typedef float fd_f32x2 __attribute__((ext_vector_type(2)));
 typedef float fd_f32x4 __attribute__((ext_vector_type(4)));
 
-// Sixteen taps for a lane's four adjacent outputs.  w[0..9] are the twenty samples x[4l + t0 .. 4l + t0 + 19] (pairs); output q takes sample
-// j + q with tap j.  Four independent sums: per tap four products, then four adds -- every sum still receives its products in ascending tap
+// Sixteen taps for a lane's kFirOut adjacent outputs.  w[] holds the samples x[kFirOut l + t0 ..] of the block (pairs); output q takes sample
+// j + q with tap j.  kFirOut independent sums: per tap kFirOut products, then kFirOut adds -- every sum still receives its products in ascending tap
 // order with separately rounded multiply and add, and one wave keeps issuing back to back (a single chain waits out the add on every tap).
-__device__ __forceinline__ void fir_block16(fd_f32x2 (&acc)[kFirOut], const fd_f32x4 (&w)[10], const float (&k)[16])
+__device__ __forceinline__ void fir_block16(fd_f32x2 (&acc)[kFirOut], const fd_f32x4 (&w)[kFirWin], const float (&k)[16])
 {
     auto smp = [&](int i) -> fd_f32x2 { return (i & 1) ? w[i >> 1].zw : w[i >> 1].xy; };
 #pragma unroll
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
     if (i0 + kFirOut >= (long)m) return;
     const long b0 = (long)fir_hist_cap - (long)(T - 1) + i0;       // buffer index of tile-local sample 0
     const uint32_t live = (uint32_t)min((long)kFirTile, (long)m - i0);   // outputs of this tile that exist
-    const uint32_t need = ((live + 3u) & ~3u) + T + kFirSlack;     // + what whole blocks read past the last tap (zero-filled)
+    const uint32_t need = ((live + (uint32_t)kFirOut - 1u) / (uint32_t)kFirOut) * (uint32_t)kFirOut + T + kFirSlack;   // + what whole blocks read past the last tap (zero-filled)
     const long end = (long)fir_hist_cap + (long)m;                 // one past the last valid input
     constexpr int LB = 4;                                          // loads in flight per lane before the first LDS store
     for (uint32_t j0 = threadIdx.x; j0 < need; j0 += LB * kFirLanes) {
@@ -143,17 +150,16 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
 #pragma unroll
     for (int q = 0; q < kFirOut; ++q) acc[q] = fd_f32x2{0.f, 0.f};
     if (active) {
-        // lane l's outputs 4l .. 4l+3 take samples 4l + t + q: a rolling window of twenty samples per sixteen taps, eight new 16-byte reads per
-        // block (half the LDS reads per multiply-add of the two-output version), the next block's samples and taps requested before this
-        // block's 128 packed operations.
-        const fd_f32x4* p = reinterpret_cast<const fd_f32x4*>(lds) + 2u * threadIdx.x;    // pair index: sample 4l + 2k
+        // lane l's outputs 6l .. 6l+5 take samples 6l + t + q: a rolling window of twenty-two samples per sixteen taps, eleven 16-byte reads per
+        // block of 192 packed operations, the next block's samples and taps requested before this block's arithmetic.
+        const fd_f32x4* p = reinterpret_cast<const fd_f32x4*>(lds) + (uint32_t)(kFirOut / 2) * threadIdx.x;    // pair index: sample kFirOut l + 2k
         const uint32_t nblk = T / 16u;
-        fd_f32x4 w[10], wn[10];
+        fd_f32x4 w[kFirWin], wn[kFirWin];
         float k[16], kn[16];
-        auto load_block = [&](fd_f32x4 (&ww)[10], float (&kk)[16], const uint32_t b) {
+        auto load_block = [&](fd_f32x4 (&ww)[kFirWin], float (&kk)[16], const uint32_t b) {
             const fd_f32x4* pn = p + 8u * b;
 #pragma unroll
-            for (int i = 0; i < 10; ++i) ww[i] = pn[i];
+            for (int i = 0; i < kFirWin; ++i) ww[i] = pn[i];
             const ctaps_t tn = tp + 16u * b;
 #pragma unroll
             for (int j = 0; j < 16; ++j) kk[j] = tn[j];
@@ -182,8 +188,9 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
     FSTAMP(2);
     __syncthreads();                       // everyone is done reading inputs: reuse LDS for the outputs
     if (active) {
-        reinterpret_cast<float4*>(lds)[2u * threadIdx.x] = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
-        reinterpret_cast<float4*>(lds)[2u * threadIdx.x + 1u] = make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y);
+#pragma unroll
+        for (int q = 0; q < kFirOut; q += 2)
+            reinterpret_cast<float4*>(lds)[(uint32_t)(kFirOut / 2) * threadIdx.x + (uint32_t)(q / 2)] = make_float4(acc[q].x, acc[q].y, acc[q + 1].x, acc[q + 1].y);
     }
     __syncthreads();
 
@@ -200,9 +207,12 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
     d[0] = discriminate(acc[0].x, acc[0].y, pr, pi);
 #pragma unroll
     for (int q = 1; q < kFirOut; ++q) d[q] = (uint32_t)q < nv ? discriminate(acc[q].x, acc[q].y, acc[q - 1].x, acc[q - 1].y) : 0.f;
-    float* dm = demod + (size_t)s * demod_stride + i;                // i is a multiple of four, demod_stride is even
-    if (nv >= 2) *reinterpret_cast<float2*>(dm) = make_float2(d[0], d[1]); else dm[0] = d[0];
-    if (nv == 4) *reinterpret_cast<float2*>(dm + 2) = make_float2(d[2], d[3]); else if (nv == 3) dm[2] = d[2];
+    float* dm = demod + (size_t)s * demod_stride + i;                // i is even, demod_stride is even
+#pragma unroll
+    for (int q = 0; q < kFirOut; q += 2) {
+        if ((uint32_t)q + 1u < nv) *reinterpret_cast<float2*>(dm + q) = make_float2(d[q], d[q + 1]);
+        else if ((uint32_t)q < nv) dm[q] = d[q];
+    }
     if (sym_ring) {      // append straight into the symbol extractor's ring (SymbolExtractor::pushSamples); a vent
         const SymState st = sym[s];   // (backlog > 30000) restarts the backlog at the same position base + held
         float* ring = sym_ring + (size_t)s * ring_cap;
@@ -217,7 +227,9 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
     const long last = (long)m - 1;
     if (i <= last && last < i + (long)kFirOut) {
         DemodCarry kc; kc.primed = 1; kc._pad = 0;
-        const fd_f32x2 y = last == i ? acc[0] : last == i + 1 ? acc[1] : last == i + 2 ? acc[2] : acc[3];
+        fd_f32x2 y = acc[0];
+#pragma unroll
+        for (int q = 1; q < kFirOut; ++q) if (last == i + q) y = acc[q];
         kc.re = y.x; kc.im = y.y;
         carry_out[s] = kc;
     }

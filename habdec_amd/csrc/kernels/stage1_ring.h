@@ -64,6 +64,11 @@ extern "C" void hd_debug_ring_stamps(unsigned long long* host, size_t n) { (void
 #define RSTAMP_WRITE(wave_, n_) do { } while (0)
 #endif
 
+#ifdef HD_RING_FAULT
+__device__ unsigned int g_ring_fault_fired;
+extern "C" void hd_debug_ring_fault_arm() { const unsigned int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ring_fault_fired), &z, sizeof z); }   // (one fault per arming)
+#endif
+
 struct RingCtl {
     uint32_t landed[2];     // per loader: tiles published so far
     uint32_t end[2];        // per loader: its total, 0xFFFFFFFF until it has issued its last tile
@@ -134,7 +139,7 @@ struct RingArgs {
     uint32_t n;                                     // samples per stream this call (uniform, multiple of 2048)
     uint32_t ntiles;                                // n / 2048
     StepClaim claim;
-    unsigned int* gave_up;                          // mapped host word: += 1 by every wave whose bounded wait ran out (never in a correct run; the engine fails the call)
+    unsigned int* gave_up;                          // mapped host word: set by a wave whose bounded wait ran out (never in a correct run; the engine then stays failed)
 };
 
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p)
@@ -278,6 +283,13 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
 #endif
             inflight_instr -= oldest; fifo >>= 8;
             ++landed;
+#ifdef HD_RING_FAULT   // fault-injection build (libhabdec_amd_fault.so, tests/test_gpu_fault.py): ONE loader of the process never publishes its second tile
+            if (landed == 2u) {
+                unsigned int won = 1u;
+                if (lane == 0) won = atomicCAS(&g_ring_fault_fired, 0u, 1u);
+                if ((unsigned int)__builtin_amdgcn_readfirstlane((int)won) == 0u) { --landed; inflight_instr = 0; fifo = 0; issued = landed; have = false; ended = true; continue; }
+            }
+#endif
             if (lane == 0) __hip_atomic_store(&ctl->landed[L], landed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         RSTAMP(2);
@@ -343,7 +355,7 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
         }
         if (!have && ended && issued == landed) break;                 // nothing left to issue, nothing in flight
         if (issued == landed && ++idle_spins > kRingSpinLimit) {       // (bounded, see the consumers' wait)
-            if (lane == 0) (void)__hip_atomic_fetch_add(a.gave_up, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (lane == 0) __hip_atomic_store(a.gave_up, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (a plain store: atomics on mapped host memory need PCIe atomics)
             if (lane == 0) __hip_atomic_store(&ctl->end[L], issued, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             break;
         }
@@ -469,7 +481,7 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
                 if (seq < e2) { skip = true; break; }
             }
             if (spin > kRingSpinLimit) {            // (never in a correct run: a bounded wait cannot hang the device, and the engine reports it)
-                if (lane == 0) (void)__hip_atomic_fetch_add(a.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (lane == 0) __hip_atomic_store(a.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 return;
             }
             feed();
@@ -481,7 +493,7 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
         const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.x), tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y),
                        slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z) & 15u, slot_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z) >> 4;
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)d.w) != seq) {   // (the entry was reused under this wave's feet: cannot happen, see RingCtl::desc)
-            if (lane == 0) (void)__hip_atomic_fetch_add(a.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (lane == 0) __hip_atomic_store(a.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
         const unsigned char* p = geo.ring + (slot_lds - lds_addr_of(geo.ring)) + lane * (uint32_t)kRingRowBytes;

@@ -29,9 +29,10 @@ __device__ __forceinline__ SymState state_after_push(SymState st, const SymbolPa
 // four accumulators whose window contains it.  Each accumulator still receives exactly its own R samples in index
 // order, so the sums are bit-identical to std::accumulate, with 1/16 of the LDS instructions of the scalar form.
 #ifndef HD_SYM_POS
-#define HD_SYM_POS 8     // (8: half the LDS reads per position and four add chains per lane; /4 at 512 kHz: 0.868 against 0.898 ms per step)
-#endif
-constexpr int kAvgPos = HD_SYM_POS;                         // positions per lane of k_symbols (4 or 8)
+#define HD_SYM_POS 8     // (8: half the LDS reads per position of 4 and four add chains per lane; /4 at 512 kHz: 0.868 against 0.898 ms per step.  12 -- lanes 48
+#endif                   // bytes apart, 16-byte LDS reads without bank conflicts, see window_sums_wide -- measured SLOWER: /4 0.860 against 0.853 ms, /16 0.360 against
+                         // 0.353: the workgroup's LDS grows by 8 KB, one fewer fits a CU, and the conflicts were latency the other waves covered)
+constexpr int kAvgPos = HD_SYM_POS;                         // positions per lane of k_symbols (4, 8 or 12)
 constexpr int kAvgSpan = kAvgLanes * kAvgPos;               // positions per workgroup and sweep
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -85,68 +86,83 @@ __device__ __forceinline__ void window_sums(const float* __restrict__ w, uint32_
     acc[0] = acc0; acc[1] = acc1; acc[2] = acc2; acc[3] = acc3;
 }
 
-// The same for a lane that owns EIGHT consecutive positions: acc[j] = w[j] + ... + w[j+R-1], j = 0..7.  Four packed accumulators are
-// four independent add chains -- what ONE wave needs to issue back to back (two chains wait out the add latency on every element).
-// Element e feeds accumulator j iff j <= e <= j + R - 1.  `w` is 16-byte aligned and readable up to w[R + 15].
-constexpr int kWidePos = 8;
-__device__ __forceinline__ void window_sums8(const float* __restrict__ w, uint32_t R, float acc[kWidePos])
+// The same for a lane that owns KP (8 or 12) consecutive positions: acc[j] = w[j] + ... + w[j+R-1], j = 0..KP-1.  KP/2 packed accumulators are
+// KP/2 independent add chains -- what ONE wave needs to issue back to back (two chains wait out the add latency on every element).
+// Element e feeds accumulator j iff j <= e <= j + R - 1.  `w` is 16-byte aligned and readable up to w[R + KP + 7].
+// Eight positions per lane put consecutive lanes 32 bytes apart: two lanes of every ds_read_b128 lane group then share a bank quad (a 2-way
+// conflict on every read); twelve put them 48 bytes apart -- three 16-byte chunks, an odd stride -- and the sixteen lanes of a group cover
+// all sixteen quads.  The one-wave stream tail keeps eight (512 new positions per round = 64 lanes x 8: a full sweep); k_symbols was measured with
+// twelve and stays at eight too (HD_SYM_POS).
+template <int KP>
+__device__ __forceinline__ void window_sums_wide(const float* __restrict__ w, uint32_t R, float (&acc)[KP])
 {
-    float s[kWidePos];
+    static_assert(KP % 4 == 0 && KP >= 8, "whole 16-byte chunks per lane");
+    float s[KP];
 #pragma unroll
-    for (int j = 0; j < kWidePos; ++j) s[j] = 0.0f;
+    for (int j = 0; j < KP; ++j) s[j] = 0.0f;
     const float4* w4 = reinterpret_cast<const float4*>(w);
-    if (R >= (uint32_t)kWidePos) {
-        {   // head: element u < 8 feeds the accumulators j <= u
-            const float4 x0 = w4[0], x1 = w4[1];
-            const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    if (R >= (uint32_t)KP) {
+        {   // head: element u < KP feeds the accumulators j <= u
+            float xs[KP];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int c = 0; c < KP / 4; ++c) { const float4 x = w4[c]; xs[4 * c] = x.x; xs[4 * c + 1] = x.y; xs[4 * c + 2] = x.z; xs[4 * c + 3] = x.w; }
+#pragma unroll
+            for (int u = 0; u < KP; ++u)
 #pragma unroll
                 for (int j = 0; j <= u; ++j) s[j] = s[j] + xs[u];
         }
-        f32x2 a01 = {s[0], s[1]}, a23 = {s[2], s[3]}, a45 = {s[4], s[5]}, a67 = {s[6], s[7]};
-        uint32_t e = 8;
-        auto feed8 = [&](const float4 x) {                  // interior: every element feeds all eight
-            a01 = a01 + (f32x2){x.x, x.x}; a23 = a23 + (f32x2){x.x, x.x}; a45 = a45 + (f32x2){x.x, x.x}; a67 = a67 + (f32x2){x.x, x.x};
-            a01 = a01 + (f32x2){x.y, x.y}; a23 = a23 + (f32x2){x.y, x.y}; a45 = a45 + (f32x2){x.y, x.y}; a67 = a67 + (f32x2){x.y, x.y};
-            a01 = a01 + (f32x2){x.z, x.z}; a23 = a23 + (f32x2){x.z, x.z}; a45 = a45 + (f32x2){x.z, x.z}; a67 = a67 + (f32x2){x.z, x.z};
-            a01 = a01 + (f32x2){x.w, x.w}; a23 = a23 + (f32x2){x.w, x.w}; a45 = a45 + (f32x2){x.w, x.w}; a67 = a67 + (f32x2){x.w, x.w};
+        f32x2 a[KP / 2];
+#pragma unroll
+        for (int p = 0; p < KP / 2; ++p) a[p] = (f32x2){s[2 * p], s[2 * p + 1]};
+        uint32_t e = KP;
+        auto feed = [&](const float4 x) {                   // interior: every element feeds every accumulator
+#pragma unroll
+            for (int p = 0; p < KP / 2; ++p) a[p] = a[p] + (f32x2){x.x, x.x};
+#pragma unroll
+            for (int p = 0; p < KP / 2; ++p) a[p] = a[p] + (f32x2){x.y, x.y};
+#pragma unroll
+            for (int p = 0; p < KP / 2; ++p) a[p] = a[p] + (f32x2){x.z, x.z};
+#pragma unroll
+            for (int p = 0; p < KP / 2; ++p) a[p] = a[p] + (f32x2){x.w, x.w};
         };
-        float4 xa = w4[2], xb;                              // two images taking turns, one chunk ahead (no copies between trips)
+        float4 xa = w4[KP / 4], xb;                         // two images taking turns, one chunk ahead (no copies between trips)
         for (; e + 8 <= R; e += 8) {                        // xa holds elements e .. e+3
             xb = w4[(e >> 2) + 1];
             __builtin_amdgcn_sched_barrier(0);
-            feed8(xa);
+            feed(xa);
             xa = w4[(e >> 2) + 2];
             __builtin_amdgcn_sched_barrier(0);
-            feed8(xb);
+            feed(xb);
         }
-        if (e + 4 <= R) { feed8(xa); e += 4; }
-        s[0] = a01.x; s[1] = a01.y; s[2] = a23.x; s[3] = a23.y; s[4] = a45.x; s[5] = a45.y; s[6] = a67.x; s[7] = a67.y;
-        for (; e < R; ++e) {                                // R % 4 elements that still feed all eight
+        if (e + 4 <= R) { feed(xa); e += 4; }
+#pragma unroll
+        for (int p = 0; p < KP / 2; ++p) { s[2 * p] = a[p].x; s[2 * p + 1] = a[p].y; }
+        for (; e < R; ++e) {                                // R % 4 elements that still feed every accumulator
             const float xe = w[e];
 #pragma unroll
-            for (int j = 0; j < kWidePos; ++j) s[j] = s[j] + xe;
+            for (int j = 0; j < KP; ++j) s[j] = s[j] + xe;
         }
-        // tail: element R + d (d = 0..6) feeds the accumulators j > d
-        float xt[7];
+        // tail: element R + d (d = 0 .. KP-2) feeds the accumulators j > d
+        float xt[KP - 1];
 #pragma unroll
-        for (int d = 0; d < 7; ++d) xt[d] = w[R + d];
+        for (int d = 0; d < KP - 1; ++d) xt[d] = w[R + d];
 #pragma unroll
-        for (int d = 0; d < 7; ++d)
+        for (int d = 0; d < KP - 1; ++d)
 #pragma unroll
-            for (int j = d + 1; j < kWidePos; ++j) s[j] = s[j] + xt[d];
+            for (int j = d + 1; j < KP; ++j) s[j] = s[j] + xt[d];
     } else {                                                // tiny windows (fewer than 32 samples per bit): plain loops
-        for (uint32_t e = 0; e < R + kWidePos - 1; ++e) {
+        for (uint32_t e = 0; e < R + KP - 1; ++e) {
             const float xe = w[e];
 #pragma unroll
-            for (int j = 0; j < kWidePos; ++j)
+            for (int j = 0; j < KP; ++j)
                 if (e < (uint32_t)j + R && (uint32_t)j <= e) s[j] = s[j] + xe;
         }
     }
 #pragma unroll
-    for (int j = 0; j < kWidePos; ++j) acc[j] = s[j];
+    for (int j = 0; j < KP; ++j) acc[j] = s[j];
 }
+constexpr int kWidePos = 8;
+__device__ __forceinline__ void window_sums8(const float* __restrict__ w, uint32_t R, float (&acc)[kWidePos]) { window_sums_wide<kWidePos>(w, R, acc); }
 
 // Wave-wide maximum of an unsigned 64-bit key with DPP moves (a ds_bpermute-based shuffle reduction costs an LDS round trip
 // per step, ~1.5k cycles for an arg-max; this is a few dozen).  Result is uniform.

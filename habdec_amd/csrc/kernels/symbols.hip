@@ -107,8 +107,8 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     // of p+R (same elements, same order, same rounding), so one sum per position is computed and cached (ring `wsum`);
     // flag(p) = sgn(W(p-R)/R) != sgn(W(p)/R).
     float* wl = win + ((kAvgSpan + R + 16 + 3) & ~3u);      // W of [c0 - R, c0 + span)
-    const uint32_t wn = kAvgSpan + R + 8;
-    constexpr int WB = kAvgPos == 8 ? 10 : 6, LB = 2, MB = 2;                   // loads per lane issued back to back (covers R <= 504, 32768 searchable positions)
+    const uint32_t wn = kAvgSpan + R + kAvgPos;
+    constexpr int WB = kAvgPos == 12 ? 14 : kAvgPos == 8 ? 10 : 6, LB = 2, MB = 2;                   // loads per lane issued back to back (covers R <= 504, 32768 searchable positions)
     unsigned long long first_word = 0ull;                   // mask word holding position c0, as earlier calls left it
     {
         const uint32_t c0 = st.cached;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
         const bool any = (int32_t)(pend - p0) > 0;
         float wp[kAvgPos];
         if (any) {
-            if constexpr (kAvgPos == 8) window_sums8(win + tid * kAvgPos, R, wp); else window_sums(win + tid * kAvgPos, R, wp);
+            if constexpr (kAvgPos >= 8) window_sums_wide<kAvgPos>(win + tid * kAvgPos, R, wp); else window_sums(win + tid * kAvgPos, R, wp);
 #pragma unroll
             for (int j = 0; j < kAvgPos; ++j) {
                 wl[R + tid * kAvgPos + j] = wp[j];

@@ -91,15 +91,17 @@ def test_realtime_throttle_paces_the_rounds_like_the_reference(tmp_path):
         assert alive == want[2] and list(n) == list(want[1])
         assert np.array_equal(slab.view(np.uint32), want[0].view(np.uint32))
     t_slow = time.perf_counter() - t0
-    assert t_fast < 0.2
-    assert 0.8 <= t_slow < 2.0, t_slow                              # 8 x 100 ms (sleep_for never returns early)
+    # (lower bounds are the contract -- sleep_for never returns early; the upper bounds only say "the throttle is the sleep, not a busy loop gone wrong",
+    # and are generous: a loaded CI host stretches every sleep)
+    assert t_slow >= 0.8, t_slow                                    # 8 x 100 ms
+    assert t_slow >= t_fast + 0.7 and t_slow < 30.0, (t_fast, t_slow)
     # the truncation to whole milliseconds (size_t(...)): 100 samples at 40960 samples/s are 2.44 ms -> 2 ms, not 0 and not 3
     tiny = habdec_amd.IqFiles(paths, chunk=128, granule=64, realtime_rate=40960.0)
     t0 = time.perf_counter()
     for _ in range(20):
         tiny.next()
     dt = time.perf_counter() - t0
-    assert 0.06 <= dt < 0.5, dt                                     # 20 x 3 ms (128 samples: 3.125 ms -> 3 ms)
+    assert 0.06 <= dt < 30.0, dt                                    # 20 x 3 ms (128 samples: 3.125 ms -> 3 ms); no tight upper bound (loaded hosts)
 
 
 def test_open_errors(tmp_path):
