@@ -138,6 +138,8 @@ struct hd_engine {
     uint32_t s1_loaders = 2;   // HD_S1_LOADERS: ... when stage 1 is a launch of its own.  Two since round 4: with the nt policy on the body rows one loader's 3 tiles in
                                // flight (its 6-bit vmcnt holds 57 DMA instructions) are what bounds the launch -- 102.7 us with one loader, 94.7 with two (one box, alternating)
     uint32_t s1_waves = 8;     // HD_S1_WAVES: waves per workgroup of k_stage1_cu (8 .. 16)
+    uint32_t s1_slots = 4;     // HD_S1_SLOTS: tile slots of k_stage1_cu in batch mode on the separate-kernels path: four leave half of a CU's LDS to the back-half
+                               // workgroups of the previous call on the other queue (/16: 0.334-0.343 ms per step against 0.342-0.351 with eight, one box, alternating)
     PinBuf<unsigned int> ring_gave_up;     // mapped host word a wave of k_step_cu / k_stage1_cu sets when a bounded wait runs out (never in a correct run)
     bool device_failed = false;            // ... after which the engine stays failed: the launch that gave up left stage-1 output incomplete, and up to
                                            // three calls are undelivered by the time a collect() sees the word -- which of them it was cannot be told
@@ -329,6 +331,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     if (const char* v = getenv("HD_CU_SLOTS")) e->cu_slots4 = atoi(v) == 4;
     if (const char* v = getenv("HD_S1_LOADERS")) e->s1_loaders = atoi(v) == 1 ? 1u : 2u;
     if (const char* v = getenv("HD_S1_WAVES")) e->s1_waves = (uint32_t)atoi(v);
+    if (const char* v = getenv("HD_S1_SLOTS")) e->s1_slots = (uint32_t)atoi(v);
     if (const char* v = getenv("HD_STEP_WGS")) e->step_wgs = (uint32_t)atoi(v);
     if (const char* v = getenv("HD_TAIL_LANES")) e->tail_lanes = atoi(v);
     if (const char* v = getenv("HD_TAIL_MAX_N2")) e->tail_max_n2 = (uint32_t)strtoul(v, nullptr, 0);
@@ -745,7 +748,9 @@ int hd_flush(hd_engine* e)
     std::lock_guard<std::recursive_mutex> lock(e->mtx);
     if (e->in_callback) return fail(HD_ERR_INVALID, "hd_flush cannot be called from a sentence / character callback (the delivery it would join is the one running)");
     HD_HIP(hipSetDevice(e->cfg.device));
-    return flush_locked(e);
+    const int rc = flush_locked(e);
+    if (e->device_failed) return fail(HD_ERR_DEVICE, "this engine is in its failed state (a bounded wait ran out inside an earlier launch) -- destroy the engine");
+    return rc;
 }
 
 int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint32_t* n_per_stream, uint32_t n_uniform)
@@ -1056,7 +1061,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             if (cl.ctr) {
                 if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
                 s1_cu = hd::launch_stage1_cu(qa, (int)R1, (int)T1, e->n_cus, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
-                                             max_in, cl, e->ring_gave_up.dev, e->s1_loaders, e->s1_waves);
+                                             max_in, cl, e->ring_gave_up.dev, e->s1_loaders, e->s1_waves, (e->cfg.pipeline && !fuse) ? e->s1_slots : 8u);
                 if (!s1_cu) --e->step_launches;                // (the counter sets alternate per launch that really draws: this one did not)
             }
         }

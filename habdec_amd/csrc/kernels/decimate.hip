@@ -596,7 +596,7 @@ __global__ __launch_bounds__(64 * HD_CU_WAVES) void k_step_cu(const RingArgs ra,
     unsigned char* ring = cu_lds;
     RingCtl* ctl = reinterpret_cast<RingCtl*>(cu_lds + n_slots * ring_slot_bytes<T>());
     unsigned char* tails = cu_lds + n_slots * ring_slot_bytes<T>() + kRingCtlBytes;
-    if (threadIdx.x < kRingCtlBytes / 4) reinterpret_cast<uint32_t*>(ctl)[threadIdx.x] = (threadIdx.x == 2 || threadIdx.x == 3) ? 0xFFFFFFFFu : 0u;   // end[] = "not known yet"
+    ring_ctl_init(ctl, n_loaders);
     __syncthreads();
     // Roles by SIMD, not by wave number.  A 512-thread workgroup at 256 VGPRs puts exactly two waves on each of the CU's four SIMDs; which two
     // is the hardware's choice.  The tap loops and the tails are both VALU work, the loaders are not: SIMDs 0 and 1 each get a loader and a
@@ -636,15 +636,27 @@ __global__ __launch_bounds__(64 * HD_CU_WAVES) void k_step_cu(const RingArgs ra,
 #endif
     // Tile slots: the ring region's (four, five beside the compact tails, eight in a launch without tails), and -- as the tails finish -- slots inside
     // the tails' LDS slices (stage1_ring.h: ring_extra_slots), up to eight in all per loader pair.
-    RingGeom geom{ring, n_slots / n_loaders, tails, 0u, 0u, 0u, n_loaders};
+    RingGeom geom{ring, n_slots, tails, 0u, 0u, 0u};
 #ifndef HD_CU_NO_EXTRA_SLOTS
     ring_extra_slots(geom, tail_bytes, (uint32_t)ring_slot_bytes<T>(), n_slots < 8u ? 8u - n_slots : 0u, n_tail != 0);
+#endif
+    // Who loads into what.  One loader from the start owns the ring region; the extra slots -- which exist from the moment tails finish -- belong to a
+    // SECOND loader: the first tail wave that is done (three more tiles in flight for the launch's second half; HD_CU_NO_LATE_LOADER: the first loader
+    // takes them too, as in round 3).  Two loaders from the start (HD_RING_LOADERS=2) split the ring region and the extra slots evenly.
+#ifndef HD_CU_NO_LATE_LOADER
+    const bool late_loader = n_loaders == 1u && geom.ne != 0u;
+#else
+    const bool late_loader = false;
 #endif
     if (w < n_loaders) {
 #ifdef HD_RING_LOADER_PRIO
         __builtin_amdgcn_s_setprio(HD_RING_LOADER_PRIO);
 #endif
-        ring_loader<T>(ra, geom, ctl, w);
+        if (n_loaders == 1u) ring_loader<T>(ra, geom, ctl, 0u, late_loader ? geom.nb : geom.nb + geom.ne, w);
+        else {   // loader w: its half of the ring region; the extra slots go to loader 1 as a block when the halves would not be whole slots of one kind
+            const uint32_t hb = geom.nb / 2u;
+            if (w == 0u) ring_loader<T>(ra, geom, ctl, 0u, hb, w); else ring_loader<T>(ra, geom, ctl, hb, geom.nb - hb + geom.ne, w);
+        }
     } else if (w < kTailBase) {
         ring_consumer<T>(ra, geom, ctl, w == kFeeder, w);                // (the wave beside loader 0 draws the runs)
     } else {
@@ -659,9 +671,22 @@ __global__ __launch_bounds__(64 * HD_CU_WAVES) void k_step_cu(const RingArgs ra,
         // my slice of LDS is free from here on: a tile slot for the loaders (every LDS access of the tail has completed: its results are stored)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) (void)__hip_atomic_fetch_or(&ctl->tail_mask, 1u << k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifndef HD_CU_NO_LATE_CONSUMERS
         __builtin_amdgcn_s_setprio(0);
-        ring_consumer<T>(ra, geom, ctl, false, w);                       // the tail is done: one more wave for the tap loops
+        if (late_loader) {
+            // The first tail wave that is done becomes the second loader -- if a loader is still at work: `live` is only ever raised from a non-zero
+            // value (a consumer that saw zero may already have left; raising it from zero would be a promise nobody is left to hear).
+            uint32_t first = 1u, was = 0u;
+            if (lane == 0) first = __hip_atomic_fetch_add(&ctl->late_loader, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)first) == 0u) {
+                if (lane == 0) {
+                    was = __hip_atomic_load(&ctl->live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    while (was != 0u && !__hip_atomic_compare_exchange_strong(&ctl->live, &was, was + 1u, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { }
+                }
+                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)was) != 0u) ring_loader<T>(ra, geom, ctl, geom.nb, geom.ne, w);
+            }
+        }
+#ifndef HD_CU_NO_LATE_CONSUMERS
+        ring_consumer<T>(ra, geom, ctl, false, w);                       // the tail is done (and, for one of them, the loading): one more wave for the tap loops
 #endif
     }
 }
@@ -671,12 +696,12 @@ __global__ __launch_bounds__(64 * HD_CU_WAVES) void k_step_cu(const RingArgs ra,
 // room for eight -- and computing waves in all the others.  512 MiB of IQ in 107-112 us where the single-wave grid (k_decimate<32,212,64>) takes
 // 118-123.  D = 8: the same kernel for the /8 first stage of /16 plans (ring_consumer: four outputs per lane row).
 template <int T, int D>
-__global__ __launch_bounds__(D == 32 ? 1024 : 512) void k_stage1_cu(const RingArgs ra, const uint32_t n_loaders)
+__global__ __launch_bounds__(D == 32 ? 1024 : 512) void k_stage1_cu(const RingArgs ra, const uint32_t n_loaders, const uint32_t n_slots /* 2 .. 8 */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char cu_lds[];
     unsigned char* ring = cu_lds;
-    RingCtl* ctl = reinterpret_cast<RingCtl*>(cu_lds + 2 * kRingNSLAlone * ring_slot_bytes<T>());
-    if (threadIdx.x < kRingCtlBytes / 4) reinterpret_cast<uint32_t*>(ctl)[threadIdx.x] = (threadIdx.x == 2 || threadIdx.x == 3) ? 0xFFFFFFFFu : 0u;
+    RingCtl* ctl = reinterpret_cast<RingCtl*>(cu_lds + n_slots * ring_slot_bytes<T>());
+    ring_ctl_init(ctl, n_loaders);
     __syncthreads();
     // one loader per SIMD pair, the first computing wave beside a loader feeds the runs (roles as in k_step_cu; any placement fills every role)
     const uint32_t simd = (__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4)) & 3u;
@@ -697,8 +722,9 @@ __global__ __launch_bounds__(D == 32 ? 1024 : 512) void k_stage1_cu(const RingAr
         }
         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)pick);
     }
-    const RingGeom geom{ring, (uint32_t)kRingNSLAlone * (3u - n_loaders), nullptr, 0u, 0u, 0u, n_loaders};
-    if (w < n_loaders) ring_loader<T>(ra, geom, ctl, w);
+    const RingGeom geom{ring, n_slots, nullptr, 0u, 0u, 0u};
+    const uint32_t h0 = n_slots / 2u;                                    // two loaders: [0, h0) and [h0, n_slots)
+    if (w < n_loaders) ring_loader<T>(ra, geom, ctl, (n_loaders == 1u || w == 0u) ? 0u : h0, n_loaders == 1u ? n_slots : (w == 0u ? h0 : n_slots - h0), w);
     else ring_consumer<T, D>(ra, geom, ctl, w == 2, w);
 }
 
@@ -819,6 +845,13 @@ bool launch_step(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, u
     return false;
 }
 
+// what a publication word of the ring protocol can name (stage1_ring.h, RingCtl::pub): 24 bits of sequence number, 20 of stream, 12 of tile
+static bool ring_limits_ok(uint32_t uniform_n, const StepClaim& claim)
+{
+    const uint64_t ntiles = uniform_n / 2048u, total = (uint64_t)claim.runs_per_xcd * claim.n_xcd * claim.run_len;
+    return ntiles && ntiles <= 4096u && total < (1ull << 24) && total / ntiles <= (1ull << 20);
+}
+
 uint32_t step_cu_tail_lds(int ratio, int ntaps, uint32_t n_slots)
 {
     auto lim = [&](int slot) { const uint32_t rb = n_slots * (uint32_t)slot + (uint32_t)kRingCtlBytes, left = rb < 163840u ? (163840u - rb) / 4u : 16u; return (left < kStepLdsBytes ? left : kStepLdsBytes) & ~15u; };
@@ -836,6 +869,7 @@ bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2
     if (n_slots != 5u || n_loaders != 1u) n_slots = 2u * (uint32_t)kRingNSL;
     if (!n_tail && n_loaders == 1u && n_slots == 5u) n_slots = 8u;          // a launch without tails (the first after a flush): the whole CU's LDS is tile slots
     if (ratio != 32 || !claim.ctr || !uniform_n || uniform_n % 2048u) return false;
+    if (!ring_limits_ok(uniform_n, claim)) return false;
     RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, uniform_n / 2048u, claim, gave_up};
 #define HD_CU_CASE(T, D2, T2)                                                                                                         \
     if (ntaps == T && ratio2 == D2 && ntaps2 == T2) {                                                                                 \
@@ -867,16 +901,19 @@ bool stage1_cu_supported(int ratio, int ntaps)
 }
 
 bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, const float2* in, size_t in_stride, const float2* hist_in, float2* hist_out,
-                      const float* taps, float2* out, size_t out_stride, uint32_t uniform_n, const StepClaim& claim, unsigned int* gave_up, uint32_t n_loaders, uint32_t n_waves)
+                      const float* taps, float2* out, size_t out_stride, uint32_t uniform_n, const StepClaim& claim, unsigned int* gave_up, uint32_t n_loaders, uint32_t n_waves,
+                      uint32_t n_slots)
 {
     if (n_loaders != 1u) n_loaders = 2u;
+    if (n_slots < 2u * n_loaders || n_slots > 8u) n_slots = 8u;
     if (n_waves < 8u || n_waves > 16u) n_waves = 8u;
     if (!claim.ctr || !uniform_n || uniform_n % 2048u) return false;
+    if (!ring_limits_ok(uniform_n, claim)) return false;
     RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, uniform_n / 2048u, claim, gave_up};
 #define HD_S1_CASE(D, T)                                                                                                              \
     if (ratio == D && ntaps == T) {                                                                                                   \
-        constexpr uint32_t lds = (uint32_t)ring_bytes<T, kRingNSLAlone>();                                                            \
-        static_assert(lds <= 163840u, "eight tile slots must fit a CU's LDS");                                                        \
+        static_assert((uint32_t)ring_bytes<T, kRingNSLAlone>() <= 163840u, "eight tile slots must fit a CU's LDS");                   \
+        const uint32_t lds = n_slots * (uint32_t)ring_slot_bytes<T>() + (uint32_t)kRingCtlBytes;                                                        \
         static bool attr_set[64] = {};                                                                                                \
         int dev_ = 0;                                                                                                                 \
         if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return false;                                                \
@@ -884,7 +921,7 @@ bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, cons
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_stage1_cu<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) return false; \
             attr_set[dev_] = true;                                                                                                    \
         }                                                                                                                             \
-        hipLaunchKernelGGL((k_stage1_cu<T, D>), dim3(n_cus), dim3(64u * (D == 32 ? n_waves : 8u)), lds, st, ra, n_loaders);           \
+        hipLaunchKernelGGL((k_stage1_cu<T, D>), dim3(n_cus), dim3(64u * (D == 32 ? n_waves : 8u)), lds, st, ra, n_loaders, n_slots);           \
         return true;                                                                                                                  \
     }
     HD_S1_CASE(32, 212) HD_S1_CASE(32, 174) HD_S1_CASE(8, 54)

@@ -22,13 +22,18 @@
 // first output's stride) are two more -- or, for a stream's first tile, HR dword-wide LDS-DMA rows out of the stage history, whose
 // samples sit at odd 8-byte offsets.
 //
-// Protocol (LDS words, RingCtl).  Loader L numbers its tiles l = 0, 1, ... and puts tile l into any of its slots that is free (never
-// used, or slot_done says the consumer of the tile last put there is finished), writes desc = (stream, tile, slot, l), issues the DMA,
-// and bumps landed[L] when IB_STS.VM_CNT shows the tile has arrived.  Consumers draw g = taken++ (with two loaders: tile g >> 1 of
-// loader g & 1), sleep until it is published, compute, and store l + 1 into slot_done.  Runs of tiles come from the per-XCD counters of the step launches (StepClaim, launch.h):
-// the first consumer wave draws them -- a returning atomic, which a wave without DMA in flight can simply wait for -- and feeds the
-// loader(s) through run_q.  end[L] tells consumers how many tiles a loader had in all.  No s_barrier after the start: the stream tails in
-// the workgroup's other waves never take part; every wait is bounded and reported (RingArgs::gave_up).
+// Protocol (LDS words, RingCtl).  A loader owns a range of tile slots.  It puts its next tile into any of them that is free (never used, or
+// slot_done counts as many finished tiles as the loader has put there; a slot inside a tail's LDS slice only once that tail is done), issues the
+// DMA, and -- when IB_STS.VM_CNT shows the tile has arrived -- PUBLISHES it: it draws the next global sequence number g from pub_tail and stores
+// the 64-bit word (g, slot, stream, tile) into pub[g & 15].  Consumers draw g = taken++, sleep until pub[g & 15] carries the tag g -- the word is
+// the whole descriptor: no second LDS round trip between waking up and the first sample read -- compute, and add one to slot_done.  One
+// publication order for all loaders: how many loader waves there are, and when they join, is nobody else's business -- stage 1 alone runs two from
+// the start, a step launch starts with one and the first stream tail that finishes becomes the second (round 4: one loader's 6-bit vmcnt holds
+// three tiles' DMA instructions, and three tiles in flight per CU are what bounded a launch once the tails were out of the way).  `live` counts
+// the loaders that may still publish: a consumer whose sequence number is not published and sees live == 0 is done.  Runs of tiles come from the
+// per-XCD counters of the step launches (StepClaim, launch.h): the feeding consumer draws them -- a returning atomic, which a wave without DMA in
+// flight can simply wait for -- and hands them to the loaders through run_q, "no more" sentinels included, for as long as it lives.  No s_barrier
+// after the start: the stream tails in the workgroup's other waves never take part; every wait is bounded and reported (RingArgs::gave_up).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -45,7 +50,7 @@ constexpr int kRingRowBytes = 272;                  // 32 samples + one 16-byte 
 #endif
 constexpr int kRingNSL = HD_RING_NSL;                 // tile slots per loader wave in a step launch (beside four stream tails: what fits)
 constexpr int kRingNSLAlone = 4;                      // ... when stage 1 has the CU to itself (k_stage1_cu)
-constexpr int kRingCtlBytes = 384;                 // (372 bytes of RingCtl; every 16 bytes count when a fifth tile slot has to fit beside four tails)
+constexpr int kRingCtlBytes = 384;                 // (256 bytes of RingCtl; every 16 bytes count when a fifth tile slot has to fit beside four tails)
 constexpr uint32_t kRingSpinLimit = 1u << 22;   // polls before a waiting wave gives up (seconds; a correct run waits microseconds)
 template <int T> constexpr int ring_halo_rows() { return (T - 1 + 31) / 32; }
 template <int T> constexpr int ring_slot_bytes() { return (64 + ring_halo_rows<T>()) * kRingRowBytes; }
@@ -70,36 +75,47 @@ extern "C" void hd_debug_ring_fault_arm() { const unsigned int z = 0; (void)hipM
 #endif
 
 struct RingCtl {
-    uint32_t landed[2];     // per loader: tiles published so far
-    uint32_t end[2];        // per loader: its total, 0xFFFFFFFF until it has issued its last tile
+    uint32_t pub_tail;      // tiles published so far = the next publication's sequence number
+    uint32_t live;          // loader waves that may still publish
     uint32_t taken;         // next sequence number a consumer draws
     uint32_t run_tail;      // runs the feeding consumer has put into run_q so far
     uint32_t run_head;      // runs the loaders have claimed (fetch-add)
-    uint32_t _pad;
+    uint32_t late_loader;   // step launch: finished tail waves that have asked to become the second loader (the first one does)
+    uint32_t _pad[2];
     uint32_t run_q[4];      // drawn run numbers (0xFFFFFFFF: no more)
-    uint32_t slot_done[8];  // per slot 4 L + j: 1 + l of the tile last finished in it
-    uint4 desc[16];         // per loader and tile number l & 7: stream, tile, local slot j, l.  (Eight entries for at most four tiles in a loader's
-                            // slots: tile l + 8 cannot be issued before tile l + 4 .. l + 7 have all been issued, i.e. four more slots were
-                            // free while l still held one -- and the consumer of l copies its entry the moment it sees l published.  The entry
-                            // carries l so that the impossible is detected, not assumed.)
+    uint32_t slot_done[8];  // per slot: tiles finished in it so far (free when that equals what its loader has put there)
+    unsigned long long pub[16];   // publication g: high word (g << 8) | slot, low word (stream << 12) | tile -- stored, as one 8-byte write, when tile g has
+                            // landed (tag 0xFFFFFF: nothing yet).  Sixteen entries for at most eight slots: publication g + 16 needs a free slot while the
+                            // tile of g -- whose consumer has not even read pub yet -- and everything published after it hold theirs, i.e. more than
+                            // eight.  Limits (checked by the launcher): fewer than 2^24 tiles per launch, 2^20 streams, 4096 tiles per stream and call.
     uint32_t simd_rank[4];  // waves of the workgroup that have arrived on each SIMD (role assignment, k_step_cu)
     uint32_t roles_taken;   // bit w: role w has a wave
     uint32_t tail_mask;     // bit k: tail slice k holds no tail any more (or never did): the loaders may land tiles in the extra slots that lie in it
-    uint32_t _pad2[3];
+    uint32_t _pad2[2];
 };
 static_assert(sizeof(RingCtl) <= kRingCtlBytes, "ring control block");
+// first thing in the kernel, before the workgroup's first barrier: everything zero, `live` = the loaders that exist from the start, no publications
+__device__ __forceinline__ void ring_ctl_init(RingCtl* ctl, const uint32_t n_live)
+{
+    const uint32_t i = threadIdx.x;
+    if (i < (uint32_t)kRingCtlBytes / 4u) {
+        uint32_t v = 0u;
+        if (i == (uint32_t)offsetof(RingCtl, live) / 4u) v = n_live;
+        if (i >= (uint32_t)offsetof(RingCtl, pub) / 4u && i < (uint32_t)offsetof(RingCtl, pub) / 4u + 32u) v = 0xFFFFFFFFu;
+        reinterpret_cast<uint32_t*>(ctl)[i] = v;
+    }
+}
 
-// Where a loader's tile slots are.  One loader owns them all (up to eight); each of two loaders owns up to four: `nb` of them in the ring region proper, and -- inside a step launch --
-// `ne` more that lie in the LDS slices of the stream tails: extra slot g (loader L's local slot j >= nb is g = L * ne + j - nb) sits xoff[g] bytes into the
-// tails' region and becomes a slot when every tail whose slice it touches is done (xneed[g]: bits of RingCtl::tail_mask).  A slice at least a slot
-// long is a slot of its own (the four-slot layouts); shorter slices (the five-slot layout: 16 720-byte tails, 19 312-byte slots) are taken in
-// neighbouring pairs -- three slots out of four slices, the launch's second half on eight slots instead of five.
+// Where the tile slots are.  Global slot j < nb: ring + j * SLOT, the ring region proper; slot nb + i (i < ne), inside a step launch: the i-th
+// extra slot, xoff(i) bytes into the LDS slices of the stream tails, usable once every tail whose slice it touches is done (RingCtl::tail_mask).
+// A slice at least a slot long is a slot of its own (the four-slot layouts); shorter slices (the five-slot layout: 16 720-byte tails, 19 312-byte
+// slots) are taken in neighbouring pairs -- three slots out of four slices, the launch's second half on eight slots instead of five.  A loader owns
+// a contiguous range of global slots (ring_loader's slot0, nslots).
 struct RingGeom {
     unsigned char* ring; uint32_t nb;
     unsigned char* extra; uint32_t ne;
-    uint32_t xstride;       // extra slot g starts (g * xstride) & ~15 bytes into the tails' region (a formula, not a table: the struct must stay in registers)
+    uint32_t xstride;       // extra slot i starts (i * xstride) & ~15 bytes into the tails' region (a formula, not a table: the struct must stay in registers)
     uint32_t xslice;        // bytes per tail slice (which tails an extra slot waits for follows from where it lies)
-    uint32_t nl;            // loader waves: 2, or 1 (which then owns every slot: nb + ne <= 8, and all sixteen descriptor entries)
 };
 
 // The extra slots of a step launch: `tail_bytes` per slice, four slices, `slot` bytes per tile slot, `room` = how many extra slots the loaders can watch
@@ -111,13 +127,13 @@ __device__ __forceinline__ void ring_extra_slots(RingGeom& g, const uint32_t tai
     if (tail_bytes >= slot) {                               // a slice is a slot
         n = room < 4u ? room : 4u;
         g.xstride = tail_bytes;
-    } else if (g.nl == 1u) {                                // slots across neighbouring slices, spread over the region (first at its start, last at its end)
+    } else {                                                // slots across neighbouring slices, spread over the region (first at its start, last at its end)
         n = 4u * tail_bytes / slot;
         if (n > room) n = room;
         if (n > 4u) n = 4u;
         g.xstride = n > 1u ? (4u * tail_bytes - slot) / (n - 1u) : 0u;
     }
-    g.ne = n / g.nl;                                        // per loader
+    g.ne = n;
 }
 __device__ __forceinline__ uint32_t ring_extra_off(const RingGeom& g, const uint32_t i) { return (i * g.xstride) & ~15u; }
 template <int SLOT>
@@ -218,23 +234,24 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p)
 }
 
 // ---------------------------------------------------------------------------------------------------------------- a loader wave
+// The calling wave has been counted in RingCtl::live (ring_ctl_init for the loaders that exist from the start; a late one counts itself in,
+// k_step_cu).  It owns the global slots [slot0, slot0 + nslots), nslots <= 8.
 template <int T>
-__device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& geo, RingCtl* __restrict__ ctl, const uint32_t L)
+__device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& geo, RingCtl* __restrict__ ctl, const uint32_t slot0, const uint32_t nslots,
+                                            const uint32_t stamp_row /* diagnostic builds */)
 {
     constexpr int HR = ring_halo_rows<T>();
     constexpr int SLOT = ring_slot_bytes<T>();
     constexpr int NBODY = 17;                       // 64 rows x 17 chunks = 17 x 64 chunks
     constexpr int NHALO = (HR * 17 + 63) / 64;      // halo rows out of the stream itself (every tile but a stream's first)
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t nslots = geo.nb + geo.ne;             // <= 4 (two loaders), <= 8 (one)
-    // lane j < nslots watches my local slot j: where it is, and which tails must be done before it may be used (none for the ring region's slots)
-    uint32_t my_dst = lds_addr_of(geo.ring) + (L * geo.nb + lane) * (uint32_t)SLOT, my_need = 0;
-    if (lane >= geo.nb && lane < nslots) {
-        const uint32_t g = L * geo.ne + lane - geo.nb;
-        my_dst = lds_addr_of(geo.extra) + ring_extra_off(geo, g);
-        my_need = ring_extra_need<SLOT>(geo, g);
+    // lane j < nslots watches my slot j (global slot slot0 + j): where it is, and which tails must be done before it may be used (none for the ring region's slots)
+    const uint32_t gs = slot0 + lane;
+    uint32_t my_dst = lds_addr_of(geo.ring) + gs * (uint32_t)SLOT, my_need = 0;
+    if (gs >= geo.nb && lane < nslots) {
+        my_dst = lds_addr_of(geo.extra) + ring_extra_off(geo, gs - geo.nb);
+        my_need = ring_extra_need<SLOT>(geo, gs - geo.nb);
     }
-    const uint32_t dmask = geo.nl == 1u ? 15u : 7u;      // descriptor entries per loader - 1
 
     // per-lane source offsets (bytes from the tile's first body row / first halo row)
     uint32_t boff[NBODY], hoff[NHALO], hist_off[HR];
@@ -252,8 +269,8 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
     }
 
     // ---- runs of tiles: drawn from this XCD's counter by the feeding consumer (ring_consumer), handed over through ctl->run_q.  (A loader
-    // issues nothing but LDS-DMA: a returning atomic among them would have to be counted by hand too, and its destination register is
-    // the compiler's to move before the value has arrived.)
+    // issues nothing but LDS-DMA: a returning GLOBAL atomic among them would have to be counted by hand too, and its destination register is
+    // the compiler's to move before the value has arrived.  The LDS atomics below return through the other counter.)
     const uint32_t xcd0 = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // XCC_ID
     const uint32_t xcd = xcd0 < a.claim.n_xcd ? xcd0 : a.claim.n_xcd - 1;
     const uint32_t runs = a.claim.runs_per_xcd, run_len = a.claim.run_len;
@@ -261,9 +278,9 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
     uint32_t s = 0, tile = 0, left = 0, my_run = 0;
     uint32_t issued = 0, landed = 0;                // my tiles
     uint32_t inflight_instr = 0;                    // vector-memory instructions of my tiles in flight (at most three tiles: the counter holds 63)
-    unsigned long long fifo = 0;                    // ... per tile, oldest in the low byte
-    const uint32_t max_fly = geo.nb >= 3u ? 3u : 2u;
-    uint32_t my_seq = 0xFFFFFFFFu;                  // lane j < nslots watches my local slot j: the tile in it (none)
+    unsigned long long fifo = 0, sfifo = 0;         // ... per tile, oldest in the low byte; and the slots they are going to
+    const uint32_t max_fly = nslots >= 3u ? 3u : 2u;
+    uint32_t my_cnt = 0, my_desc = 0;               // lane j < nslots: tiles I have put into my slot j; (stream << 12) | tile of the one there now
     uint32_t idle_spins = 0;
     RSTAMP_DECL;
 
@@ -281,16 +298,20 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
 #else
             asm volatile("" ::: "memory");
 #endif
-            inflight_instr -= oldest; fifo >>= 8;
+            const uint32_t lslot = (uint32_t)(sfifo & 0xFFu), ldesc = (uint32_t)__builtin_amdgcn_readlane((int)my_desc, (int)(lslot - slot0));
+            inflight_instr -= oldest; fifo >>= 8; sfifo >>= 8;
             ++landed;
-#ifdef HD_RING_FAULT   // fault-injection build (libhabdec_amd_fault.so, tests/test_gpu_fault.py): ONE loader of the process never publishes its second tile
+#ifdef HD_RING_FAULT   // fault-injection build (libhabdec_amd_fault.so, tests/test_gpu_fault.py): ONE loader of the process never publishes its second tile and stops
             if (landed == 2u) {
                 unsigned int won = 1u;
                 if (lane == 0) won = atomicCAS(&g_ring_fault_fired, 0u, 1u);
-                if ((unsigned int)__builtin_amdgcn_readfirstlane((int)won) == 0u) { --landed; inflight_instr = 0; fifo = 0; issued = landed; have = false; ended = true; continue; }
+                if ((unsigned int)__builtin_amdgcn_readfirstlane((int)won) == 0u) { RSTAMP_WRITE(stamp_row, issued); return; }   // (still counted in `live`: the consumers' waits run out)
             }
 #endif
-            if (lane == 0) __hip_atomic_store(&ctl->landed[L], landed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            uint32_t g = 0;
+            if (lane == 0) g = __hip_atomic_fetch_add(&ctl->pub_tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+            if (lane == 0) __hip_atomic_store(&ctl->pub[g & 15u], ((unsigned long long)((g << 8) | lslot) << 32) | ldesc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         RSTAMP(2);
         if (!have && !ended) {                                         // the current run is used up: take the next one the feeder has drawn
@@ -309,27 +330,25 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
                     s = g0 / a.ntiles; tile = g0 - s * a.ntiles; left = run_len; have = true;
                 } else {
                     ended = true;
-                    if (lane == 0) __hip_atomic_store(&ctl->end[L], issued, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
         unsigned long long free_mask = 0;
         if (have && issued - landed < max_fly && inflight_instr + (uint32_t)(NBODY + (HR > NHALO ? HR : NHALO)) <= 63u) {
-            // which of my slots are free?  (never used, or its consumer has finished; a tail's slice only once the tail is done)
+            // which of my slots are free?  (never used, or its consumer has finished; a slot in the tails' slices only once those tails are done)
             bool ok = false;
             if (lane < nslots) {
-                const uint32_t dn = __hip_atomic_load(&ctl->slot_done[4u * L + lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                ok = my_seq == 0xFFFFFFFFu || dn == my_seq + 1u;
+                const uint32_t dn = __hip_atomic_load(&ctl->slot_done[gs], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ok = dn == my_cnt;
                 if (ok && my_need) ok = (__hip_atomic_load(&ctl->tail_mask, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & my_need) == my_need;
             }
             free_mask = __ballot(ok);
         }
         if (free_mask) {
-            const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(free_mask));
+            const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(free_mask));      // my slot number; global slot slot0 + slot
             const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)my_dst, (int)slot);
             const unsigned char* body = reinterpret_cast<const unsigned char*>(a.in + (size_t)s * a.in_stride) + (size_t)tile * (64u * 256u);
-            if (lane == 0) ctl->desc[8u * L + (issued & dmask)] = make_uint4(s, tile, slot | (dst << 4), issued);      // (LDS addresses are below 2^18)
-            if (lane == slot) my_seq = issued;
+            if (lane == slot) { ++my_cnt; my_desc = (s << 12) | tile; }
             uint32_t cnt = NBODY;
             if (tile == 0) {
                 const unsigned char* hb = reinterpret_cast<const unsigned char*>(a.hist_in + (size_t)s * (T - 1));
@@ -345,6 +364,7 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
             }
             glds16_x17(body, boff, dst + (uint32_t)(HR * kRingRowBytes));
             fifo |= (unsigned long long)cnt << (8u * (issued - landed));
+            sfifo |= (unsigned long long)(slot0 + slot) << (8u * (issued - landed));
             inflight_instr += cnt;
             ++issued;
             ++tile; --left;
@@ -356,13 +376,14 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
         if (!have && ended && issued == landed) break;                 // nothing left to issue, nothing in flight
         if (issued == landed && ++idle_spins > kRingSpinLimit) {       // (bounded, see the consumers' wait)
             if (lane == 0) __hip_atomic_store(a.gave_up, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (a plain store: atomics on mapped host memory need PCIe atomics)
-            if (lane == 0) __hip_atomic_store(&ctl->end[L], issued, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             break;
         }
-        __builtin_amdgcn_s_sleep(1);                                   // my slot is busy, the next run has not been drawn yet, or loads are on their way
+        __builtin_amdgcn_s_sleep(1);                                   // my slots are busy, the next run has not been drawn yet, or loads are on their way
         RSTAMP(3);
     }
-    RSTAMP_WRITE(L, issued);
+    // every tile of mine is published: count myself out (the consumers' end condition)
+    if (lane == 0) (void)__hip_atomic_fetch_sub(&ctl->live, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    RSTAMP_WRITE(stamp_row, issued);
 }
 
 // -------------------------------------------------------------------------------------------------------------- a consumer wave
@@ -435,8 +456,10 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
     const uint32_t my_wave = role; (void)my_wave;
     // The feeding consumer also draws the runs for the loader(s) from this XCD's counter (StepClaim, launch.h) -- a returning atomic the
     // compiler counts and waits for, which a wave without DMA in flight can afford -- and keeps two of them ready in ctl->run_q.
-    bool feeding = feeder;
-    uint32_t fed = 0, sentinels = 0;
+    const bool feeding = feeder;
+    uint32_t fed = 0;
+    bool exhausted = false;                         // the XCD's counter has run out: from here on the loaders are fed "no more" sentinels, on demand, for
+                                                    // as long as this wave lives -- and it lives until every loader has counted itself out
     const uint32_t xcd0 = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // XCC_ID
     const uint32_t xcd = xcd0 < a.claim.n_xcd ? xcd0 : a.claim.n_xcd - 1;
     unsigned int* my_ctr = a.claim.ctr + (size_t)xcd * 32;
@@ -444,22 +467,21 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
     auto feed = [&]() {
         while (feeding) {
             const uint32_t head = __hip_atomic_load(&ctl->run_head, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((int32_t)(fed - head) >= 2) break;  // two unclaimed runs are ready (entries are reused four later: a claimed one has been read long before)
+            if ((int32_t)(fed - head) >= 2) break;  // two unclaimed entries are ready (entries are reused four later: a claimed one has been read long before)
             uint32_t v = 0xFFFFFFFFu;
-            if (!sentinels) {
+            if (!exhausted) {
                 unsigned int t = 0;
                 if (lane == 0) t = __hip_atomic_fetch_add(my_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
                 // the first ticket past the end -- exactly one per XCD and launch -- resets the XCD's counter of the other set for the next step launch
                 if (t == a.claim.runs_per_xcd && lane == 0) (void)__hip_atomic_exchange(next_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (t < a.claim.runs_per_xcd) v = t;
+                if (t < a.claim.runs_per_xcd) v = t; else exhausted = true;
             }
             if (lane == 0) {
                 ctl->run_q[fed & 3u] = v;
                 __hip_atomic_store(&ctl->run_tail, fed + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             ++fed;
-            if (v == 0xFFFFFFFFu && ++sentinels == geo.nl) feeding = false;                // one "no more" for each loader
         }
     };
 
@@ -469,16 +491,16 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
         uint32_t g = 0;
         if (lane == 0) g = __hip_atomic_fetch_add(&ctl->taken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
-        const uint32_t L = geo.nl == 1u ? 0u : (g & 1u), seq = geo.nl == 1u ? g : (g >> 1);
-        bool skip = false;
+        unsigned long long pw = 0;
         for (uint32_t spin = 0;; ++spin) {
-            const uint32_t l = __hip_atomic_load(&ctl->landed[L], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((int32_t)(l - seq) > 0) break;
-            const uint32_t e = __hip_atomic_load(&ctl->end[L], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (seq >= e) {                         // this loader never issues tile seq; the other one may still have some
-                const uint32_t e2 = geo.nl == 1u ? e : __hip_atomic_load(&ctl->end[L ^ 1u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (seq >= e2 && !feeding) { RSTAMP(0); RSTAMP_WRITE(my_wave, n_done); return; }
-                if (seq < e2) { skip = true; break; }
+            pw = __hip_atomic_load(&ctl->pub[g & 15u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((uint32_t)(pw >> 40) == g) break;
+            if (__hip_atomic_load(&ctl->live, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
+                // no loader will publish any more -- unless publication g went out between the two reads (a loader publishes, THEN counts itself out)
+                pw = __hip_atomic_load(&ctl->pub[g & 15u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((uint32_t)(pw >> 40) == g) break;
+                RSTAMP(0); RSTAMP_WRITE(my_wave, n_done);
+                return;
             }
             if (spin > kRingSpinLimit) {            // (never in a correct run: a bounded wait cannot hang the device, and the engine reports it)
                 if (lane == 0) __hip_atomic_store(a.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -487,16 +509,10 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
             feed();
             __builtin_amdgcn_s_sleep(1);
         }
-        if (skip) continue;
         RSTAMP(0);
-        const uint4 d = ctl->desc[8u * L + (seq & (geo.nl == 1u ? 15u : 7u))];
-        const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.x), tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y),
-                       slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z) & 15u, slot_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z) >> 4;
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)d.w) != seq) {   // (the entry was reused under this wave's feet: cannot happen, see RingCtl::desc)
-            if (lane == 0) __hip_atomic_store(a.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            return;
-        }
-        const unsigned char* p = geo.ring + (slot_lds - lds_addr_of(geo.ring)) + lane * (uint32_t)kRingRowBytes;
+        const uint32_t phi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pw >> 32)), plo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pw);
+        const uint32_t slot = phi & 0xFFu, s = plo >> 12, tile = plo & 0xFFFu;
+        const unsigned char* p = (slot < geo.nb ? geo.ring + slot * (uint32_t)ring_slot_bytes<T>() : geo.extra + ring_extra_off(geo, slot - geo.nb)) + lane * (uint32_t)kRingRowBytes;
 
         if constexpr (D == 32) {
         // the T-term sum in tap order: 16-slot chunks (half rows), the next chunk's samples and taps requested before the current one is summed
@@ -554,7 +570,7 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
 #endif
         RSTAMP(1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&ctl->slot_done[4u * L + slot], seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) (void)__hip_atomic_fetch_add(&ctl->slot_done[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         a.out[(size_t)s * a.out_stride + (size_t)tile * 64u + lane] = make_float2(acc.x, acc.y);
         if (tile + 1 == a.ntiles) {                 // the stream's last tile: carry the last T-1 inputs (Decimator.h:140-143)
             const float2* in_s = a.in + (size_t)s * a.in_stride;
@@ -601,7 +617,7 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
         }
         RSTAMP(1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&ctl->slot_done[4u * L + slot], seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) (void)__hip_atomic_fetch_add(&ctl->slot_done[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         float2* dst = a.out + (size_t)s * a.out_stride + ((size_t)tile * 64u + lane) * OPL;      // (16-byte aligned: the stride is even)
 #pragma unroll
         for (int q = 0; q < OPL; q += 2) *reinterpret_cast<float4*>(dst + q) = make_float4(acc[q].x, acc[q].y, acc[q + 1].x, acc[q + 1].y);

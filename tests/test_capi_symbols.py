@@ -54,3 +54,21 @@ def test_product_never_touches_the_oracle():
             assert "oracle" not in text.replace("the oracle's std::regex", "").replace("the CPU oracle", "").lower() or path.name in {"sentence.hpp", "__init__.py"}, path
     text = (ROOT / "habdec_amd" / "capi.py").read_text() + (ROOT / "habdec_amd" / "engine.py").read_text()
     assert "pyoracle" not in text and "liboracle" not in text
+
+
+def test_fault_injection_library_loads_and_binds():
+    """tests/test_gpu_fault.py's library (the product sources with -DHD_RING_FAULT, built by __graft_entry__.build()) must load here and export the
+    whole C ABI plus its arming hook -- so that the GPU test cannot be skipped or fail for a link error."""
+    import ctypes
+    from habdec_amd import capi
+    path = capi.LIB_PATH.with_name("libhabdec_amd_fault.so")
+    if not path.exists():
+        from habdec_amd.build import build
+        build(variant="fault")
+    L = ctypes.CDLL(str(path))
+    for table in (capi.ENGINE_API, capi.HOST_API):
+        for name in table:
+            getattr(L, name)
+    getattr(L, "hd_debug_ring_fault_arm")
+    prod = ctypes.CDLL(str(capi.LIB_PATH))
+    assert not hasattr(prod, "hd_debug_ring_fault_arm")      # the hook is compiled out of the product
