@@ -190,8 +190,9 @@ def oracle_sample_check(w, eng, ring, chunks, C, streams, lookup_mode=1):
 
 
 def box_identity(torch, dev):
-    """What this box's GPU delivers right now, so that a kernel time can be attributed (boxes of the pool differ by +-6 %): clocks as rocm-smi
-    reports them, and a 20 ms calibration pass -- a 1 GiB device-to-device copy, the access pattern of the guide's 6.29 TB/s float4 copy figure."""
+    """What this box's GPU delivers right now, so that a kernel time can be attributed (boxes of the pool differ by +-6 %): a 20 ms calibration
+    pass -- a 1 GiB device-to-device copy, the access pattern of the guide's 6.29 TB/s float4 copy figure -- and the clock levels the driver
+    reports right after it."""
     out = {"gpu": torch.cuda.get_device_name(dev)}
     try:
         n = 1 << 28
@@ -208,14 +209,17 @@ def box_identity(torch, dev):
         del a, b
     except Exception as ex:                      # (never let the calibration take the line down)
         out["copy_GBps"] = None; out["copy_note"] = f"calibration failed: {ex}"
+    # clocks as the driver publishes them in sysfs (the active level of pp_dpm_sclk / pp_dpm_mclk).  No child process here: this process has
+    # initialised the GPU, and a fork + exec from it (rocm-smi is a script) is refused on this pool.
     try:
-        import subprocess
-        js = json.loads(subprocess.run(["rocm-smi", "-d", str(dev.index or 0), "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout)
-        card = next(iter(js.values()))
-        for k, v in card.items():
-            kl = k.lower()
-            if "sclk" in kl and "level" in kl: out["sclk"] = v
-            if "mclk" in kl and "level" in kl: out["mclk"] = v
+        import glob
+        pr = torch.cuda.get_device_properties(dev)
+        want = "%04x:%02x:%02x." % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1) & 0xFF, getattr(pr, "pci_device_id", 0))
+        card = next((c for c in glob.glob("/sys/class/drm/card[0-9]*/device") if want in os.path.realpath(c)), None)   # (a node shows all its GPUs in sysfs)
+        for key, name in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk")):
+            if card and os.path.exists(f"{card}/{name}"):
+                act = [ln.split(":", 1)[1].replace("*", "").strip() for ln in open(f"{card}/{name}") if "*" in ln]
+                out[key + "_after_run"] = act[0] if act else None
     except Exception:
         pass
     return out

@@ -63,7 +63,8 @@ struct BitsHeader {
     uint32_t nbits;         // symbols produced this call
     uint32_t held_after;    // backlog kept by the symbol extractor after this call
     uint32_t nflips;        // flip points found this call
-    uint32_t overflow;      // 1 = more bits/flips than the slot can hold (never with the derived capacities)
+    uint32_t overflow;      // bit 0: more bits than the result slot can hold (never with the derived capacities; the call fails with HD_ERR_CAPACITY);
+                            // bit 1: the flip list was full -- the search stopped at its last flip and goes on in the next call (not an error)
     uint32_t uncached;      // backlog samples whose windows are not final yet (sizes the next call's window kernel)
     // Stream tail only (tail_body.h): a checksum of the call's discriminator output, so that a test can compare every call of a free-running
     // batch with a CPU reference without asking for the samples (which would flush the pipeline and change the launch shape):

@@ -95,6 +95,7 @@ struct StreamHost {
     hd::SpectrumStats stats{};
     // last call (for the getters)
     uint32_t last_n2 = 0, last_pend_before = 0, last_m = 0, last_nbits = 0, last_nflips = 0;
+    uint64_t flip_list_full = 0;   // calls in which the device's flip list filled up (kMaxFlipsPerCall) and the search went on a call later
     uint64_t bits_total = 0;
     int last_buf = 0;
     std::vector<uint32_t> last_words;
@@ -709,7 +710,8 @@ int collect(hd_engine* e, hd_engine::CallSlot& sl)
         st.last_nbits = hdr->nbits; st.last_nflips = hdr->nflips;
         st.bits_total += hdr->nbits;
         st.demod_ck[0] = hdr->demod_ck[0]; st.demod_ck[1] = hdr->demod_ck[1]; st.demod_ck_n = hdr->demod_n; st.demod_ck_call = e->delivered;
-        if (hdr->overflow && rc != HD_ERR_DEVICE) rc = fail(HD_ERR_CAPACITY, "symbol result slot overflow on stream " + std::to_string(s));
+        if ((hdr->overflow & 1u) && rc != HD_ERR_DEVICE) rc = fail(HD_ERR_CAPACITY, "symbol result slot overflow on stream " + std::to_string(s));
+        if (hdr->overflow & 2u) ++st.flip_list_full;     // (the search stopped at the flip-list bound and resumes next call: bits arrive a call later)
         const uint32_t* words = slot + sizeof(hd::BitsHeader) / 4;
         st.last_words.assign(words, words + (hdr->nbits + 31) / 32);
         if (!c.fir_m) continue;
@@ -1394,6 +1396,12 @@ uint64_t hd_stream_bits_total(hd_engine* e, uint32_t s)
     if (check_stream(e, s)) return 0;
     std::lock_guard<std::recursive_mutex> l(e->mtx);
     return e->st[s].bits_total;
+}
+uint64_t hd_stream_flip_list_full(hd_engine* e, uint32_t s)
+{
+    if (check_stream(e, s)) return 0;
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
+    return e->st[s].flip_list_full;
 }
 int hd_stream_demod_checksum(hd_engine* e, uint32_t s, uint64_t* call_index, uint32_t* n, uint32_t ck[2])
 {

@@ -201,21 +201,25 @@ __device__ __forceinline__ void glds16_x17(const void* base, const uint32_t (&of
 {
     unsigned keep, scc_keep;                      // (s_add_u32 writes SCC, which compiler code around the statement may hold live: saved and restored)
 // Cache policy of the body rows' LDS-DMA: nt -- these bytes are read exactly once (measured on one box, alternating builds: step launch 158.8 ->
-// 156.2 us, stage 1 alone 115.6 -> 111.2; MI355X_MICROARCH.md rows ldsdma-fill / nt-weights).  The halo rows, which the previous tile of the run has
-// just brought into this XCD's L2, stay on the default policy.  -DHD_GLDS_DEFAULT_POLICY: the A/B build.
+// 156.2 us, stage 1 alone 115.6 -> 111.2; MI355X_MICROARCH.md rows ldsdma-fill / nt-weights) -- EXCEPT the last two of the seventeen instructions:
+// they carry the tile's rows 56.5 .. 63, whose last seven are the NEXT tile's halo; left on the default policy they stay in this XCD's L2 for that
+// re-read (with nt on all seventeen the PMC traffic of a step launch rose from 630.6 to 647.6 MB: the halo reads went to HBM).  The halo rows
+// themselves are default-policy loads.  -DHD_GLDS_DEFAULT_POLICY: the A/B build without nt.
 #ifndef HD_GLDS_DEFAULT_POLICY
 #define HD_GLDS_BODY_POLICY " nt"
 #else
 #define HD_GLDS_BODY_POLICY ""
 #endif
 #define HD_G1(n) "global_load_lds_dwordx4 %" #n ", %19" HD_GLDS_BODY_POLICY "\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+#define HD_G1D(n) "global_load_lds_dwordx4 %" #n ", %19\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
     asm volatile("s_cselect_b32 %1, 1, 0\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %20\n\ts_nop 0\n\t"
-                 HD_G1(2) HD_G1(3) HD_G1(4) HD_G1(5) HD_G1(6) HD_G1(7) HD_G1(8) HD_G1(9) HD_G1(10) HD_G1(11) HD_G1(12) HD_G1(13) HD_G1(14) HD_G1(15) HD_G1(16) HD_G1(17)
-                 "global_load_lds_dwordx4 %18, %19" HD_GLDS_BODY_POLICY "\n\ts_mov_b32 m0, %0\n\ts_cmp_lg_u32 %1, 0"
+                 HD_G1(2) HD_G1(3) HD_G1(4) HD_G1(5) HD_G1(6) HD_G1(7) HD_G1(8) HD_G1(9) HD_G1(10) HD_G1(11) HD_G1(12) HD_G1(13) HD_G1(14) HD_G1(15) HD_G1(16) HD_G1D(17)
+                 "global_load_lds_dwordx4 %18, %19\n\ts_mov_b32 m0, %0\n\ts_cmp_lg_u32 %1, 0"
                  : "=&s"(keep), "=&s"(scc_keep)
                  : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]), "v"(off[8]), "v"(off[9]),
                    "v"(off[10]), "v"(off[11]), "v"(off[12]), "v"(off[13]), "v"(off[14]), "v"(off[15]), "v"(off[16]), "s"(base), "s"(lds_dst)
                  : "memory");
+#undef HD_G1D
 #undef HD_G1
 }
 // HR history rows, one dword-wide DMA instruction per row (pitch 272 bytes)

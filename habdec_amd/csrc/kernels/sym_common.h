@@ -9,9 +9,10 @@
 namespace hd {
 
 constexpr int kAvgLanes = 256;
-constexpr uint32_t kMaxFlipsPerCall = 512;    // upper bound of the LDS flip list ON EVERY LAUNCH PATH (the launcher sizes it from backlog / R; overflow is flagged):
-                                              // 512 is what fits beside a stage-1 slot inside a step launch, and a stream must get the same answer -- including the
-                                              // same HD_ERR_CAPACITY -- whichever path serves it; three symbols' worth of backlog holds a dozen flip points
+constexpr uint32_t kMaxFlipsPerCall = 512;    // upper bound of the LDS flip list ON EVERY LAUNCH PATH (the launcher sizes it from backlog / R): 512 is what fits beside
+                                              // a stage-1 slot inside a step launch, and a stream must get the same answer whichever path serves it.  Three symbols' worth
+                                              // of backlog holds a dozen flip points; a call that finds more than the bound (noise with four-sample windows and thousands of
+                                              // decimated samples per call) stops at the bound and goes on in the next call -- same bits, a call later (symbols.hip, tail_body.h)
 
 __device__ __forceinline__ int sgnf(float v) { return (0.0f < v) - (v < 0.0f); }
 

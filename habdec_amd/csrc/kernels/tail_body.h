@@ -749,8 +749,14 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
                 }
             }
             const uint32_t f = ~(uint32_t)wave_max_u64(key);
-            if (nfl < fl_cap) { if (lane == 0) flips[nfl] = f; ++nfl; } else { overflow = 1; break; }
+            if (lane == 0) flips[nfl] = f;
+            ++nfl;
             pos = f + R;
+            // The flip list is full (kMaxFlipsPerCall; the reference has no such bound): stop HERE and leave the rest of the backlog to the next call.
+            // The search is a pure function of the samples around each flip, and a search that resumes at the last flip's position + R is exactly
+            // what the reference does next -- so the stream of bits is the one the reference produces, only delivered a call later (BitsHeader::
+            // overflow bit 1, not an error; the one visible difference: a backlog that is consumed later reaches the 30 000-sample vent earlier).
+            if (nfl == fl_cap && pos < limit) { frontier = f; overflow = 2; break; }
         }
         if (frontier == 0xFFFFFFFFu) frontier = max(pos, limit);        // nothing flagged in [pos, limit)
         if (lane == 0) { sh[0] = nfl; sh[1] = overflow; sh[2] = frontier; }
@@ -855,7 +861,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         for (uint32_t r = 0; r < nfl; ++r) {
             const uint32_t bit = runinfo[r] & 1u;
             for (uint32_t k = runinfo[r] >> 1; k; --k) {
-                if (nbits >= cap_bits) { overflow = 1; break; }
+                if (nbits >= cap_bits) { overflow |= 1u; break; }
                 curw |= bit << (nbits & 31);
                 if ((nbits & 31) == 31) { outw[nbits >> 5] = curw; curw = 0; }
                 ++nbits;

@@ -145,6 +145,7 @@ class Engine:
     def symbol_backlog(self, s=0) -> int: return self.L.hd_stream_symbol_backlog(self.h, s)
 
     def bits_total(self, s=0) -> int: return int(self.L.hd_stream_bits_total(self.h, s))
+    def flip_list_full(self, s=0) -> int: return int(self.L.hd_stream_flip_list_full(self.h, s))
 
     def demod_checksum(self, s=0):
         """(call index, n, ck0, ck1) of the call delivered last for stream s -- no flush; n is None where the launch path does not compute it."""

@@ -165,6 +165,9 @@ uint32_t hd_stream_symbol_backlog(hd_engine* e, uint32_t stream);               
  * hd_process_* calls from 0.  n = 0xFFFFFFFF when the launch path that served the call does not compute it (only the stream tail does). */
 int hd_stream_demod_checksum(hd_engine* e, uint32_t stream, uint64_t* call_index, uint32_t* n, uint32_t ck[2]);
 uint64_t hd_stream_bits_total(hd_engine* e, uint32_t stream);                              /* symbols produced since the engine was created (delivered calls) */
+uint64_t hd_stream_flip_list_full(hd_engine* e, uint32_t stream);                          /* delivered calls in which the device's flip list (512 flip points per call) filled up: the symbol search
+                                                                                             * stopped there and went on in the next call -- the same bits as SymbolExtractor::operator() (SymbolExtractor.h:129-158,
+                                                                                             * which has no such bound), delivered a call later */
 
 /* ---- measurement ---- */
 typedef struct hd_timing {

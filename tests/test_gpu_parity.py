@@ -516,3 +516,38 @@ def test_golden_chain_through_the_gpu(hd, ctx):
         assert (a["peak_l"], a["peak_r"]) == (w[4]["peak_l"], w[4]["peak_r"]), k
     assert eng.take_sentences(0) == want["sentences"] and eng.take_chars(0) == want["chars"]
     assert eng.rtty(0) == want["rtty"] and eng.last_sentence(0) == want["last"]
+
+
+def test_flip_list_bound_delays_bits_but_loses_none(hd):
+    """More flip points in one call than the device's flip list holds (512): noise through four-sample windows at 16384 decimated samples per call
+    (/4, the reference's 160 kHz gate lifted).  The reference has no such bound; the engine stops at it and resumes in the next call (not
+    an error any more).  The stream of bits must be the reference's -- per call the engine may lag behind, never differ: its cumulative bits are a
+    prefix of the oracle's at every call and equal once a few quiet calls have let it catch up."""
+    import habdec_amd
+    from oracle import pyoracle
+    fs, D, CH, S = 2.048e6, 4, 65536, 2
+    baud = fs / D / 16.0                                   # 16 decimated samples per bit: R = 4
+    r = np.random.default_rng(5)
+    ncalls, noisy = 14, 2
+    iq = np.zeros((S, ncalls * CH), np.complex64)
+    for s in range(S):
+        n = noisy * CH
+        iq[s, :n] = (0.3 * (r.standard_normal(n) + 1j * r.standard_normal(n))).astype(np.complex64)
+        t = np.arange(ncalls * CH - n)
+        iq[s, n:] = (0.5 * np.exp(2j * np.pi * 250.0 / fs * t)).astype(np.complex64)            # idle mark: no flips, the backlog drains
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=CH, sampling_rate=fs, decimation=D, baud=baud, lowpass_bw_hz=200000.0, ungated=True)
+    orcs = [pyoracle.Decoder("oracle", factor=D, baud=baud, lowpass_bw=200000.0, ungated=True) for _ in range(S)]
+    gb, ob = [[] for _ in range(S)], [[] for _ in range(S)]
+    lag = 0
+    for k in range(ncalls):
+        eng.process_host(np.ascontiguousarray(iq[:, k * CH:(k + 1) * CH]))
+        for s in range(S):
+            orcs[s](iq[s, k * CH:(k + 1) * CH], fs)
+            gb[s] += list(eng.bits(s)); ob[s] += list(orcs[s].bits())
+            assert len(gb[s]) <= len(ob[s]) and gb[s] == ob[s][:len(gb[s])], ("the engine's bits left the oracle's", k, s)
+            lag = max(lag, len(ob[s]) - len(gb[s]))
+    assert all(eng.flip_list_full(s) >= 1 for s in range(S)) and lag > 0, ([eng.flip_list_full(s) for s in range(S)], lag)     # the bound was reached at all
+    for s in range(S):
+        assert len(ob[s]) > 1000 and gb[s] == ob[s], (s, len(gb[s]), len(ob[s]))
+        assert eng.symbol_backlog(s) == orcs[s].symex_held()
+    eng.close()
