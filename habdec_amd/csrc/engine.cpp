@@ -412,7 +412,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         e->no_claim = true;
     if (e->stages.size() >= 1) {
         for (auto& h : e->hist1) HD_HIP(h.alloc((size_t)S * (e->stages[0].taps.size() - 1)));
-        HD_HIP(e->stage_taps[0].alloc(e->stages[0].taps.size()));
+        HD_HIP(e->stage_taps[0].alloc(e->stages[0].taps.size() + 1));       // (+1: the ring kernels read the taps as aligned pairs; the word behind an odd count is never used)
         HD_HIP(hipMemcpy(e->stage_taps[0].p, e->stages[0].taps.data(), e->stages[0].taps.size() * 4, hipMemcpyHostToDevice));
     }
     if (e->stages.size() == 2) {
@@ -956,7 +956,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         const uint32_t ntiles = run_len_cu ? max_in / 2048u : (max_n1 + 63) / 64, n_xcd = e->n_cus / 32u, run_len = run_len_cu ? run_len_cu : e->step_run >= 2 ? e->step_run : 4u;   // (a run must hold the tile in front of which the next draw is issued: at least two; four re-read fewer halos than two)
         const uint64_t runs = (uint64_t)S * ntiles / run_len;
         const bool shape_ok = run_len_cu ? (hd::stage1_cu_supported((int)R1, (int)T1) && max_in % 2048u == 0) : ((R1 == 32 || R1 == 64) && max_n1 % 64 == 0);
-        if (!e->no_claim && nst == 2 && shape_ok && min_in == max_in && max_in && !any_zero1 && n_xcd && e->n_cus % 32u == 0 && n_xcd <= 16 &&
+        if (!e->no_claim && (nst == 2 || (run_len_cu && nst == 1)) && shape_ok && min_in == max_in && max_in && !any_zero1 && n_xcd && e->n_cus % 32u == 0 && n_xcd <= 16 &&
             ntiles && ntiles % run_len == 0 && runs % n_xcd == 0 && !e->qa_cus && (uint64_t)S * ntiles < (1ull << 32) && (uint64_t)ntiles * S >= 4ull * lin_wgs) {   // (the two counter sets alternate: a launch that takes one must really run that way)
             claim.ctr = e->step_ctr.p + (size_t)(e->step_launches & 1u) * 16 * 32;
             claim.ctr_next = e->step_ctr.p + (size_t)((e->step_launches & 1u) ^ 1u) * 16 * 32;
@@ -1055,7 +1055,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         // 4 %; measured on one box, alternating.  HD_CLAIM_ALONE=1 turns it on for experiments.)
         // A /32 first stage over equally sized pushes: one workgroup per CU, LDS-DMA loader waves + computing waves (k_stage1_cu, stage1_ring.h)
         bool s1_cu = false;
-        if (!single && min_in == max_in && max_in && !e->no_cu_step && !any_zero1 && max_in % 2048u == 0 && hd::stage1_cu_supported((int)R1, (int)T1)) {
+        if ((single ? R1 == 4 : R1 != 4) && min_in == max_in && max_in && !e->no_cu_step && !any_zero1 && max_in % 2048u == 0 && hd::stage1_cu_supported((int)R1, (int)T1)) {
             const uint32_t ntiles1 = max_in / 2048u;
             uint32_t ring_run = e->ring_run >= 2 ? e->ring_run : 8u;
             while (ring_run > 2 && (ntiles1 % ring_run || ((uint64_t)S * ntiles1 / ring_run) % (e->n_cus / 32u ? e->n_cus / 32u : 1u))) ring_run >>= 1;
@@ -1063,7 +1063,8 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             if (cl.ctr) {
                 if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
                 s1_cu = hd::launch_stage1_cu(qa, (int)R1, (int)T1, e->n_cus, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
-                                             max_in, cl, e->ring_gave_up.dev, e->s1_loaders, e->s1_waves, (e->cfg.pipeline && !fuse) ? e->s1_slots : 8u);
+                                             max_in, cl, e->ring_gave_up.dev, e->s1_loaders, e->s1_waves, (e->cfg.pipeline && !fuse && !single) ? e->s1_slots : 8u,   // (/4 as the only stage is bound by the vector pipes: eight slots, 0.838 against 0.904 ms per step with four)
+                                             single ? (lean ? sl.h_call.dev : dcall) : nullptr, e->fir_hist_cap, single ? feed : nullptr);
                 if (!s1_cu) --e->step_launches;                // (the counter sets alternate per launch that really draws: this one did not)
             }
         }

@@ -696,7 +696,7 @@ __global__ __launch_bounds__(64 * HD_CU_WAVES) void k_step_cu(const RingArgs ra,
 // room for eight -- and computing waves in all the others.  512 MiB of IQ in 107-112 us where the single-wave grid (k_decimate<32,212,64>) takes
 // 118-123.  D = 8: the same kernel for the /8 first stage of /16 plans (ring_consumer: four outputs per lane row).
 template <int T, int D>
-__global__ __launch_bounds__(D == 32 ? 1024 : 512) void k_stage1_cu(const RingArgs ra, const uint32_t n_loaders, const uint32_t n_slots /* 2 .. 8 */)
+__global__ __launch_bounds__(D == 8 ? 512 : 1024) void k_stage1_cu(const RingArgs ra, const uint32_t n_loaders, const uint32_t n_slots /* 2 .. 8 */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char cu_lds[];
     unsigned char* ring = cu_lds;
@@ -870,7 +870,7 @@ bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2
     if (!n_tail && n_loaders == 1u && n_slots == 5u) n_slots = 8u;          // a launch without tails (the first after a flush): the whole CU's LDS is tile slots
     if (ratio != 32 || !claim.ctr || !uniform_n || uniform_n % 2048u) return false;
     if (!ring_limits_ok(uniform_n, claim)) return false;
-    RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, uniform_n / 2048u, claim, gave_up};
+    RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, uniform_n / 2048u, claim, gave_up, nullptr, 0u, nullptr};
 #define HD_CU_CASE(T, D2, T2)                                                                                                         \
     if (ntaps == T && ratio2 == D2 && ntaps2 == T2) {                                                                                 \
         const uint32_t lds = n_slots * (uint32_t)ring_slot_bytes<T>() + (uint32_t)kRingCtlBytes + (n_tail ? 4u * tail_bytes : 0u);        \
@@ -897,19 +897,25 @@ bool step_cu_supported(int ratio, int ntaps, int ratio2, int ntaps2)
 
 bool stage1_cu_supported(int ratio, int ntaps)
 {
-    return (ratio == 32 && (ntaps == 212 || ntaps == 174)) || (ratio == 8 && ntaps == 54);
+    return (ratio == 32 && (ntaps == 212 || ntaps == 174)) || (ratio == 8 && ntaps == 54) || (ratio == 4 && ntaps == 139);   // (/4: as the final stage of a single-stage plan)
 }
 
 bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, const float2* in, size_t in_stride, const float2* hist_in, float2* hist_out,
                       const float* taps, float2* out, size_t out_stride, uint32_t uniform_n, const StepClaim& claim, unsigned int* gave_up, uint32_t n_loaders, uint32_t n_waves,
-                      uint32_t n_slots)
+                      uint32_t n_slots, const StreamCall* final_call, uint32_t fir_hist_cap, float2* fft_in)
 {
     if (n_loaders != 1u) n_loaders = 2u;
+    if (ratio == 4) {            // 278 flop per input sample: the vector pipes bind, not HBM -- one loader is plenty, and every other wave slot computes
+        n_loaders = 1u;
+        static const uint32_t w4 = getenv("HD_S1_WAVES4") ? (uint32_t)atoi(getenv("HD_S1_WAVES4")) : 16u;
+        n_waves = (w4 >= 8u && w4 <= 16u) ? w4 : 16u;
+    }
     if (n_slots < 2u * n_loaders || n_slots > 8u) n_slots = 8u;
     if (n_waves < 8u || n_waves > 16u) n_waves = 8u;
     if (!claim.ctr || !uniform_n || uniform_n % 2048u) return false;
     if (!ring_limits_ok(uniform_n, claim)) return false;
-    RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, uniform_n / 2048u, claim, gave_up};
+    if ((ratio == 4) != (final_call != nullptr)) return false;               // /4 exists as the final stage of a single-stage plan only, the others as first stages only
+    RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, uniform_n / 2048u, claim, gave_up, final_call, fir_hist_cap, fft_in};
 #define HD_S1_CASE(D, T)                                                                                                              \
     if (ratio == D && ntaps == T) {                                                                                                   \
         static_assert((uint32_t)ring_bytes<T, kRingNSLAlone>() <= 163840u, "eight tile slots must fit a CU's LDS");                   \
@@ -921,10 +927,10 @@ bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, cons
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_stage1_cu<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) return false; \
             attr_set[dev_] = true;                                                                                                    \
         }                                                                                                                             \
-        hipLaunchKernelGGL((k_stage1_cu<T, D>), dim3(n_cus), dim3(64u * (D == 32 ? n_waves : 8u)), lds, st, ra, n_loaders, n_slots);           \
+        hipLaunchKernelGGL((k_stage1_cu<T, D>), dim3(n_cus), dim3(64u * (D == 8 ? 8u : n_waves)), lds, st, ra, n_loaders, n_slots);           \
         return true;                                                                                                                  \
     }
-    HD_S1_CASE(32, 212) HD_S1_CASE(32, 174) HD_S1_CASE(8, 54)
+    HD_S1_CASE(32, 212) HD_S1_CASE(32, 174) HD_S1_CASE(8, 54) HD_S1_CASE(4, 139)
 #undef HD_S1_CASE
     return false;
 }

@@ -116,11 +116,13 @@ bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2
 // Stage 1 alone in the same shape (eight tile slots, one loader wave and seven computing waves by default): a /32 or /8 first stage, equally sized pushes that are a multiple of 2048
 // samples, drawn runs, no history restart; false otherwise (the caller then launches k_decimate).  The call's parameter block is not copied.
 bool step_cu_supported(int ratio, int ntaps, int ratio2, int ntaps2);   // plans k_step_cu is instantiated for: /64 (/32 212 + /2 69), /128 (/32 174 + /4 139)
-bool stage1_cu_supported(int ratio, int ntaps);   // first stages k_stage1_cu exists for: /32 (212, 174 taps), /8 (54 taps)
+bool stage1_cu_supported(int ratio, int ntaps);   // stages k_stage1_cu exists for: /32 (212, 174 taps), /8 (54 taps) as first stages; /4 (139 taps) as the only stage of a plan
 bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, const float2* in, size_t in_stride, const float2* hist_in, float2* hist_out,
                       const float* taps, float2* out, size_t out_stride, uint32_t uniform_n, const StepClaim& claim, unsigned int* gave_up,
                       uint32_t n_loaders /* 1 or 2 */, uint32_t n_waves /* 8 .. 16 waves per workgroup: loaders + computing waves */,
-                      uint32_t n_slots = 8 /* tile slots (2 per loader .. 8): fewer leave LDS for the other queue's kernels */);
+                      uint32_t n_slots = 8 /* tile slots (2 per loader .. 8): fewer leave LDS for the other queue's kernels */,
+                      const StreamCall* final_call = nullptr /* /4 only: the stage is the final one of a single-stage plan -- per-stream pend_before / fft_take / fft_fill */,
+                      uint32_t fir_hist_cap = 0, float2* fft_in = nullptr);
 uint32_t step_cu_tail_lds(int ratio, int ntaps, uint32_t n_slots = 4);   // LDS a tail may use inside k_step_cu beside n_slots (4, 5) tile slots of that first stage; 0 = no such kernel
 uint32_t probe_xcc_mask(hipStream_t st, uint32_t n_cus, unsigned int* d_word);   // bit x set = some workgroup of a chip-filling grid ran on XCC id x
 uint32_t step_lds_bytes(int ratio, int ntaps);   // LDS of a step-launch workgroup for that first stage (its tile, at least kStepLdsBytes); 0 = no step kernel

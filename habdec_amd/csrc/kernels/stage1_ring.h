@@ -61,7 +61,7 @@ __device__ unsigned long long g_ring_stamps[512 * 8 * 8];
 extern "C" void hd_debug_ring_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ring_stamps), n * 8); }
 #define RSTAMP_DECL unsigned long long rs_t = __builtin_amdgcn_s_memtime(), rs_acc[6] = {0, 0, 0, 0, 0, 0}; const unsigned long long rs_r0 = __builtin_amdgcn_s_memrealtime()
 #define RSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); rs_acc[i] += t_ - rs_t; rs_t = t_; } while (0)
-#define RSTAMP_WRITE(wave_, n_) do { if ((threadIdx.x & 63u) == 0 && blockIdx.x < 512) { unsigned long long* g_ = g_ring_stamps + ((size_t)blockIdx.x * 8 + (wave_)) * 8; \
+#define RSTAMP_WRITE(wave_, n_) do { if ((threadIdx.x & 63u) == 0 && blockIdx.x < 512 && (wave_) < 8u) { unsigned long long* g_ = g_ring_stamps + ((size_t)blockIdx.x * 8 + (wave_)) * 8; \
         for (int i_ = 0; i_ < 5; ++i_) g_[i_] = rs_acc[i_]; g_[5] = (n_); g_[6] = rs_r0; g_[7] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define RSTAMP_DECL do { } while (0)
@@ -156,6 +156,9 @@ struct RingArgs {
     uint32_t ntiles;                                // n / 2048
     StepClaim claim;
     unsigned int* gave_up;                          // mapped host word: set by a wave whose bounded wait ran out (never in a correct run; the engine then stays failed)
+    // a single-stage plan (/4): the stage is the FINAL one -- its outputs go behind the pending samples of the low-pass buffer, and the head of the
+    // chunk feeds the spectrum collection (decimate_body's final_stage bookkeeping; Decoder.h:443-444, :467-473)
+    const StreamCall* call; uint32_t fir_hist_cap; float2* fft_in;       // call == nullptr: not the final stage
 };
 
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p)
@@ -439,6 +442,43 @@ __device__ __forceinline__ void ring_mac16_asm(r_f32x2& acc, const r_f32x4 (&x)[
 #undef HD_ADD
 }
 
+// One input sample for EIGHT adjacent outputs (the /4 stage: output q takes this sample with tap t0 - 4 q): eight products, then eight adds, as ONE
+// statement -- every sum still receives its products in ascending tap order, separately rounded.  (As separate statements the compiler's block
+// scheduler put all of a tile's 1112 products first and spilled them.)  ODD: the taps are the high words of their scalar pairs.
+template <bool ODD>
+__device__ __forceinline__ void ring_slot8(r_f32x2 (&acc)[8], const r_f32x2 smp, const r_f32x2 k0, const r_f32x2 k1, const r_f32x2 k2, const r_f32x2 k3,
+                                           const r_f32x2 k4, const r_f32x2 k5, const r_f32x2 k6, const r_f32x2 k7)
+{
+    r_f32x2 t0, t1, t2, t3, t4, t5, t6, t7;
+#define HD_S8_MUL(t, k) "v_pk_mul_f32 %" #t ", %16, %" #k " op_sel_hi:[1,0]\n\t"
+#define HD_S8_MULO(t, k) "v_pk_mul_f32 %" #t ", %16, %" #k " op_sel:[0,1]\n\t"
+#define HD_S8_ADDS "v_pk_add_f32 %0, %0, %8\n\tv_pk_add_f32 %1, %1, %9\n\tv_pk_add_f32 %2, %2, %10\n\tv_pk_add_f32 %3, %3, %11\n\t" \
+                   "v_pk_add_f32 %4, %4, %12\n\tv_pk_add_f32 %5, %5, %13\n\tv_pk_add_f32 %6, %6, %14\n\tv_pk_add_f32 %7, %7, %15"
+#define HD_S8_OPS : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),                       \
+                    "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)                                            \
+                  : "v"(smp), "s"(k0), "s"(k1), "s"(k2), "s"(k3), "s"(k4), "s"(k5), "s"(k6), "s"(k7)
+    if constexpr (ODD)
+        asm volatile(HD_S8_MULO(8, 17) HD_S8_MULO(9, 18) HD_S8_MULO(10, 19) HD_S8_MULO(11, 20) HD_S8_MULO(12, 21) HD_S8_MULO(13, 22) HD_S8_MULO(14, 23) HD_S8_MULO(15, 24) HD_S8_ADDS HD_S8_OPS);
+    else
+        asm volatile(HD_S8_MUL(8, 17) HD_S8_MUL(9, 18) HD_S8_MUL(10, 19) HD_S8_MUL(11, 20) HD_S8_MUL(12, 21) HD_S8_MUL(13, 22) HD_S8_MUL(14, 23) HD_S8_MUL(15, 24) HD_S8_ADDS HD_S8_OPS);
+#undef HD_S8_MUL
+#undef HD_S8_MULO
+#undef HD_S8_ADDS
+#undef HD_S8_OPS
+}
+// ... and for ONE output (the slots at either end of a lane's window, which not every output covers)
+template <bool ODD>
+__device__ __forceinline__ void ring_slot1(r_f32x2& acc, const r_f32x2 smp, const r_f32x2 k)
+{
+    r_f32x2 t;
+    if constexpr (ODD) asm volatile("v_pk_mul_f32 %1, %2, %3 op_sel:[0,1]\n\tv_pk_add_f32 %0, %0, %1" : "+v"(acc), "=&v"(t) : "v"(smp), "s"(k));
+    else asm volatile("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[1,0]\n\tv_pk_add_f32 %0, %0, %1" : "+v"(acc), "=&v"(t) : "v"(smp), "s"(k));
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a compile-time constant inside the body
+template <class F, int... I>
+__device__ __forceinline__ void ring_for_each_index(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+
 template <int T, int D = 32>
 __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom& geo, RingCtl* __restrict__ ctl, const bool feeder,
                                               const uint32_t role /* the wave's role number in the workgroup (diagnostic builds: its row in the stamp table) */)
@@ -448,7 +488,7 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
     constexpr int NS = JS + T;                      // taps sit on slots [JS, NS)
     constexpr int C0 = JS / 16, C1 = (NS - 1) / 16; // first and last 16-slot chunk that carries taps
     static_assert(D != 32 || C1 - C0 >= 3, "filter shorter than four chunks");
-    static_assert(D == 32 || D == 16 || D == 8, "a lane's row of 32 samples is 32 / D outputs");
+    static_assert(D == 32 || D == 16 || D == 8 || D == 4, "a lane's row of 32 samples is 32 / D outputs");
     const uint32_t lane = threadIdx.x & 63u;
     typedef const float __attribute__((address_space(4)))* ctaps_t;
     const ctaps_t taps = (ctaps_t)(uintptr_t)a.taps - JS;                                   // taps[slot]
@@ -584,15 +624,18 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
         } else {
         // Smaller ratios: the lane's row of 32 samples is OPL = 32 / D adjacent outputs, output q taking the window that starts D * q
         // slots further on -- OPL independent sums (each its own T products in ascending tap order), one pass over the lane's
-        // (OPL - 1) * D + T slots.  The filter is short here (54 taps at /8): every tap sits in a scalar register for the whole launch,
-        // and the chunk loop is unrolled with compile-time ranges (which taps of which output a 16-slot chunk carries).
+        // (OPL - 1) * D + T slots, the chunk loop unrolled with compile-time ranges (which taps of which output a 16-slot chunk carries).
+        // A short filter (54 taps at /8) sits in scalar registers for the whole launch; a long one (139 taps at /4) is read chunk by chunk
+        // through the scalar cache (a chunk carries at most 16 + D * (OPL - 1) different taps).
         constexpr int OPL = 32 / D;
         constexpr int NSW = (OPL - 1) * D + T;          // slots a lane reads: [JS, JS + NSW)
         constexpr int CW1 = (JS + NSW - 1) / 16;        // last chunk
-        static_assert(T <= 64, "the taps are held in scalar registers");
-        float k[T];
+        constexpr bool kResident = T <= 64;
+        float k[kResident ? T : 1];
+        if constexpr (kResident) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) k[t] = taps[JS + t];
+            for (int t = 0; t < T; ++t) k[t] = taps[JS + t];
+        }
         r_f32x2 acc[OPL];
 #pragma unroll
         for (int q = 0; q < OPL; ++q) acc[q] = (r_f32x2){0.f, 0.f};
@@ -604,27 +647,80 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
         };
         rdw(xw[0], C0);
         if constexpr (CW1 > C0) rdw(xw[1], C0 + 1);
-#pragma unroll
-        for (int c = C0; c <= CW1; ++c) {
+        ring_for_each_index([&](auto ci) {
+            constexpr int c = C0 + decltype(ci)::value;
             const r_f32x4 (&x)[8] = xw[(c - C0) & 1];
+            if constexpr (kResident) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int slot = 16 * c + j;
-                const r_f32x2 smp = (j & 1) ? x[j >> 1].zw : x[j >> 1].xy;
+                for (int j = 0; j < 16; ++j) {
+                    const int slot_j = 16 * c + j;
+                    const r_f32x2 smp = (j & 1) ? x[j >> 1].zw : x[j >> 1].xy;
 #pragma unroll
-                for (int q = 0; q < OPL; ++q) {
-                    const int t = slot - JS - D * q;
-                    if (t >= 0 && t < T) acc[q] = acc[q] + smp * k[t];
+                    for (int q = 0; q < OPL; ++q) {
+                        const int t = slot_j - JS - D * q;
+                        if (t >= 0 && t < T) acc[q] = acc[q] + smp * k[t];
+                    }
                 }
+            } else {
+                // The chunk's taps as aligned scalar PAIRS (tap 2i, 2i + 1), fetched here -- a chunk touches at most (16 + D (OPL - 1)) / 2 + 1 of them -- and
+                // multiplied straight out of the scalar registers: op_sel picks the pair's low or high word for both halves of the packed multiply.
+                // (Written as `smp * tap` the compiler broadcasts every tap into a VECTOR register pair first -- 2 T registers, spilled at T = 139.)
+                constexpr int TLO = 16 * c - JS - D * (OPL - 1) < 0 ? 0 : 16 * c - JS - D * (OPL - 1);
+                constexpr int THI = 16 * c + 15 - JS >= T ? T - 1 : 16 * c + 15 - JS;          // taps [TLO, THI] are used by this chunk
+                constexpr int P0 = TLO / 2, NP = THI >= TLO ? THI / 2 - P0 + 1 : 0;
+                typedef const r_f32x2 __attribute__((address_space(4)))* cpair_t;
+                const cpair_t tp2 = (cpair_t)(uintptr_t)a.taps;                                  // (the tap table is 8-byte aligned and padded to an even count)
+                r_f32x2 kp[NP > 0 ? NP : 1];
+#pragma unroll
+                for (int i = 0; i < NP; ++i) kp[i] = tp2[P0 + i];
+                ring_for_each_index([&](auto ji) {
+                    constexpr int j = decltype(ji)::value, slot_j = 16 * c + j, t0 = slot_j - JS;      // output q takes this sample with tap t0 - D q
+                    const r_f32x2 smp = (j & 1) ? x[j >> 1].zw : x[j >> 1].xy;
+                    constexpr bool odd = (t0 & 1) != 0;                                               // (D q is even: one parity for all of the slot's taps)
+                    if constexpr (OPL == 8 && t0 - D * (OPL - 1) >= 0 && t0 < T) {
+                        ring_slot8<odd>(acc, smp, kp[(t0 - 0 * D) / 2 - P0], kp[(t0 - 1 * D) / 2 - P0], kp[(t0 - 2 * D) / 2 - P0], kp[(t0 - 3 * D) / 2 - P0],
+                                        kp[(t0 - 4 * D) / 2 - P0], kp[(t0 - 5 * D) / 2 - P0], kp[(t0 - 6 * D) / 2 - P0], kp[(t0 - 7 * D) / 2 - P0]);
+                    } else {
+                        ring_for_each_index([&](auto qi) {
+                            constexpr int q = decltype(qi)::value, t = t0 - D * q;
+                            if constexpr (t >= 0 && t < T) ring_slot1<odd>(acc[q], smp, kp[t / 2 - P0]);
+                        }, std::make_integer_sequence<int, OPL>{});
+                    }
+                }, std::make_integer_sequence<int, 16>{});
+                __builtin_amdgcn_sched_barrier(0);      // (the next chunk's tap pairs are fetched behind this chunk's arithmetic, not in front of the whole loop)
             }
-            if (c + 2 <= CW1) rdw(xw[(c - C0) & 1], c + 2);
-        }
+            if constexpr (c + 2 <= CW1) rdw(xw[(c - C0) & 1], c + 2);
+        }, std::make_integer_sequence<int, CW1 - C0 + 1>{});
         RSTAMP(1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) (void)__hip_atomic_fetch_add(&ctl->slot_done[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        float2* dst = a.out + (size_t)s * a.out_stride + ((size_t)tile * 64u + lane) * OPL;      // (16-byte aligned: the stride is even)
+        const uint32_t o0 = (tile * 64u + lane) * (uint32_t)OPL;                                 // the lane's first output of the stream's chunk
+        if (!a.call) {
+            float2* dst = a.out + (size_t)s * a.out_stride + o0;                                     // (16-byte aligned: the stride is even)
 #pragma unroll
-        for (int q = 0; q < OPL; q += 2) *reinterpret_cast<float4*>(dst + q) = make_float4(acc[q].x, acc[q].y, acc[q + 1].x, acc[q + 1].y);
+            for (int q = 0; q < OPL; q += 2) *reinterpret_cast<float4*>(dst + q) = make_float4(acc[q].x, acc[q].y, acc[q + 1].x, acc[q + 1].y);
+        } else {
+            // the final stage of a single-stage plan: behind the pending low-pass input, and the head of the chunk into the spectrum collection
+            const uint32_t pend = a.call[s].pend_before, ftake = a.call[s].fft_take, ffill = a.call[s].fft_fill;
+            float2* dst = a.out + (size_t)s * a.out_stride + a.fir_hist_cap + pend + o0;
+            if (((a.fir_hist_cap + pend) & 1u) == 0u) {
+#pragma unroll
+                for (int q = 0; q < OPL; q += 2) *reinterpret_cast<float4*>(dst + q) = make_float4(acc[q].x, acc[q].y, acc[q + 1].x, acc[q + 1].y);
+            } else {
+#pragma unroll
+                for (int q = 0; q < OPL; ++q) dst[q] = make_float2(acc[q].x, acc[q].y);
+            }
+            if (a.fft_in && o0 < ftake) {
+                float2* fd = a.fft_in + (size_t)s * kFftBins + ffill + o0;
+                if (o0 + (uint32_t)OPL <= ftake && (ffill & 1u) == 0u) {
+#pragma unroll
+                    for (int q = 0; q < OPL; q += 2) *reinterpret_cast<float4*>(fd + q) = make_float4(acc[q].x, acc[q].y, acc[q + 1].x, acc[q + 1].y);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < OPL; ++q) if (o0 + (uint32_t)q < ftake) fd[q] = make_float2(acc[q].x, acc[q].y);
+                }
+            }
+        }
         if (tile + 1 == a.ntiles) {                 // the stream's last tile: carry the last T-1 inputs (Decimator.h:140-143)
             const float2* in_s = a.in + (size_t)s * a.in_stride;
             float2* hout = a.hist_out + (size_t)s * (T - 1);

@@ -522,30 +522,34 @@ def test_flip_list_bound_delays_bits_but_loses_none(hd):
     """More flip points in one call than the device's flip list holds (512): noise through four-sample windows at 16384 decimated samples per call
     (/4, the reference's 160 kHz gate lifted).  The reference has no such bound; the engine stops at it and resumes in the next call (not
     an error any more).  The stream of bits must be the reference's -- per call the engine may lag behind, never differ: its cumulative bits are a
-    prefix of the oracle's at every call and equal once a few quiet calls have let it catch up."""
+    prefix of the oracle's at every call and equal once some short calls (few new flips each, so the backlog shrinks instead of running into the
+    30 000-sample vent) have let it catch up."""
     import habdec_amd
     from oracle import pyoracle
     fs, D, CH, S = 2.048e6, 4, 65536, 2
     baud = fs / D / 16.0                                   # 16 decimated samples per bit: R = 4
     r = np.random.default_rng(5)
-    ncalls, noisy = 14, 2
-    iq = np.zeros((S, ncalls * CH), np.complex64)
+    noisy, quiet, QC = 2, 40, 4096                         # two full pushes of noise, then short pushes of a clean alternating-bit signal
+    n0 = noisy * CH
+    iq = np.zeros((S, n0 + quiet * QC), np.complex64)
     for s in range(S):
-        n = noisy * CH
-        iq[s, :n] = (0.3 * (r.standard_normal(n) + 1j * r.standard_normal(n))).astype(np.complex64)
-        t = np.arange(ncalls * CH - n)
-        iq[s, n:] = (0.5 * np.exp(2j * np.pi * 250.0 / fs * t)).astype(np.complex64)            # idle mark: no flips, the backlog drains
+        iq[s, :n0] = (0.3 * (r.standard_normal(n0) + 1j * r.standard_normal(n0))).astype(np.complex64)
+        iq[s, n0:] = synth.fsk_iq(np.tile(np.array([0, 1], np.uint8), quiet * QC // 128 + 2), fs, baud, sigma=0.01, seed=70 + s, n_samples=quiet * QC)
     eng = habdec_amd.Engine(n_streams=S, max_chunk=CH, sampling_rate=fs, decimation=D, baud=baud, lowpass_bw_hz=200000.0, ungated=True)
     orcs = [pyoracle.Decoder("oracle", factor=D, baud=baud, lowpass_bw=200000.0, ungated=True) for _ in range(S)]
     gb, ob = [[] for _ in range(S)], [[] for _ in range(S)]
-    lag = 0
-    for k in range(ncalls):
-        eng.process_host(np.ascontiguousarray(iq[:, k * CH:(k + 1) * CH]))
+    lag, pos = 0, 0
+    for k in range(noisy + quiet):
+        n = CH if k < noisy else QC
+        buf = np.zeros((S, CH), np.complex64)
+        buf[:, :n] = iq[:, pos:pos + n]
+        eng.process_host(buf, n)
         for s in range(S):
-            orcs[s](iq[s, k * CH:(k + 1) * CH], fs)
+            orcs[s](iq[s, pos:pos + n], fs)
             gb[s] += list(eng.bits(s)); ob[s] += list(orcs[s].bits())
             assert len(gb[s]) <= len(ob[s]) and gb[s] == ob[s][:len(gb[s])], ("the engine's bits left the oracle's", k, s)
             lag = max(lag, len(ob[s]) - len(gb[s]))
+        pos += n
     assert all(eng.flip_list_full(s) >= 1 for s in range(S)) and lag > 0, ([eng.flip_list_full(s) for s in range(S)], lag)     # the bound was reached at all
     for s in range(S):
         assert len(ob[s]) > 1000 and gb[s] == ob[s], (s, len(gb[s]), len(ob[s]))

@@ -198,13 +198,14 @@ def test_linear_split_and_step_kernels_of_the_other_single_wave_stages(monkeypat
     eng.close()
 
 
-@pytest.mark.parametrize("factor,fs,ungated,per_cu", [(16, 2.5e6, False, True), (16, 2.5e6, False, False), (4, 2.048e6, True, False)])
+@pytest.mark.parametrize("factor,fs,ungated,per_cu", [(16, 2.5e6, False, True), (16, 2.5e6, False, False), (4, 2.048e6, True, True), (4, 2.048e6, True, False)])
 def test_first_stages_of_the_small_ratios_at_1024_streams(monkeypatch, factor, fs, ungated, per_cu):
     """/16 (/8 54 taps -- as k_stage1_cu<54,8>, one workgroup per CU, and as the classic grid k_decimate<8,54,256> -- + <2,69,256>) and
-    /4 (<4,139,256>) at the batch size the bench uses: 1024 streams x 65536 samples per call, every stream its own delayed copy of one
+    /4 (139 taps, the only stage of its plan: k_stage1_cu<139,4> with eight outputs per lane writing behind the low-pass buffer's pending samples
+    and feeding the spectrum collection, and the classic grid <4,139,256>) at the batch size the bench uses: 1024 streams x 65536 samples per call, every stream its own delayed copy of one
     signal, sampled streams against the oracle bit for bit."""
     torch = pytest.importorskip("torch")
-    if factor == 16 and not per_cu:
+    if not per_cu:
         monkeypatch.setenv("HD_NO_CU_STEP", "1")
     import habdec_amd
     from oracle import pyoracle
@@ -229,6 +230,9 @@ def test_first_stages_of_the_small_ratios_at_1024_streams(monkeypatch, factor, f
             assert same_bits(eng.demodulated(s), o.array("last_demod")), (k, s)
             assert np.array_equal(eng.bits(s), o.bits()), (k, s)
             assert eng.symbol_backlog(s) == o.symex_held(), (k, s)
+            ga, oa = eng.afc(s), o.afc()                       # (the spectrum collection is fed by the final stage's epilogue: the ring consumer's at /4)
+            assert (ga["peak_l"], ga["peak_r"]) == (oa["peak_l"], oa["peak_r"]), ("peaks", k, s)
+            assert ga["correction"] == pytest.approx(oa["correction"], rel=1e-9, abs=1e-9), ("afc", k, s)
     assert eng.timing()["step_variant"] == (1 if per_cu else 0)
     eng.close()
 
