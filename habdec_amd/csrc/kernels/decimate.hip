@@ -897,7 +897,7 @@ bool step_cu_supported(int ratio, int ntaps, int ratio2, int ntaps2)
 
 bool stage1_cu_supported(int ratio, int ntaps)
 {
-    return (ratio == 32 && (ntaps == 212 || ntaps == 174)) || (ratio == 8 && ntaps == 54) || (ratio == 4 && ntaps == 139);   // (/4: as the final stage of a single-stage plan)
+    return (ratio == 32 && (ntaps == 212 || ntaps == 174)) || (ratio == 8 && ntaps == 54) || (ratio == 4 && ntaps == 139);   // (/4: as a final stage)
 }
 
 bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, const float2* in, size_t in_stride, const float2* hist_in, float2* hist_out,
@@ -905,7 +905,7 @@ bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, cons
                       uint32_t n_slots, const StreamCall* final_call, uint32_t fir_hist_cap, float2* fft_in)
 {
     if (n_loaders != 1u) n_loaders = 2u;
-    if (ratio == 4) {            // 278 flop per input sample: the vector pipes bind, not HBM -- one loader is plenty, and every other wave slot computes
+    if (ratio <= 4) {            // 278 flop per input sample (/4): the vector pipes bind, not HBM -- one loader is plenty, and every other wave slot computes
         n_loaders = 1u;
         static const uint32_t w4 = getenv("HD_S1_WAVES4") ? (uint32_t)atoi(getenv("HD_S1_WAVES4")) : 16u;
         n_waves = (w4 >= 8u && w4 <= 16u) ? w4 : 16u;
@@ -914,7 +914,7 @@ bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, cons
     if (n_waves < 8u || n_waves > 16u) n_waves = 8u;
     if (!claim.ctr || !uniform_n || uniform_n % 2048u) return false;
     if (!ring_limits_ok(uniform_n, claim)) return false;
-    if ((ratio == 4) != (final_call != nullptr)) return false;               // /4 exists as the final stage of a single-stage plan only, the others as first stages only
+    if ((ratio <= 4) != (final_call != nullptr)) return false;               // /4 exists as a FINAL stage only (the only stage of a plan), the others as first stages only
     RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, uniform_n / 2048u, claim, gave_up, final_call, fir_hist_cap, fft_in};
 #define HD_S1_CASE(D, T)                                                                                                              \
     if (ratio == D && ntaps == T) {                                                                                                   \

@@ -488,7 +488,8 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
     constexpr int NS = JS + T;                      // taps sit on slots [JS, NS)
     constexpr int C0 = JS / 16, C1 = (NS - 1) / 16; // first and last 16-slot chunk that carries taps
     static_assert(D != 32 || C1 - C0 >= 3, "filter shorter than four chunks");
-    static_assert(D == 32 || D == 16 || D == 8 || D == 4, "a lane's row of 32 samples is 32 / D outputs");
+    static_assert(D == 32 || D == 16 || D == 8 || D == 4 || D == 2, "a lane's row of 32 samples is 32 / D outputs");
+    static_assert(D == 32 || T <= 64 || (32 / D) % 8 == 0, "long filters of the small ratios: outputs in groups of eight");
     const uint32_t lane = threadIdx.x & 63u;
     typedef const float __attribute__((address_space(4)))* ctaps_t;
     const ctaps_t taps = (ctaps_t)(uintptr_t)a.taps - JS;                                   // taps[slot]
@@ -677,15 +678,21 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
                     constexpr int j = decltype(ji)::value, slot_j = 16 * c + j, t0 = slot_j - JS;      // output q takes this sample with tap t0 - D q
                     const r_f32x2 smp = (j & 1) ? x[j >> 1].zw : x[j >> 1].xy;
                     constexpr bool odd = (t0 & 1) != 0;                                               // (D q is even: one parity for all of the slot's taps)
-                    if constexpr (OPL == 8 && t0 - D * (OPL - 1) >= 0 && t0 < T) {
-                        ring_slot8<odd>(acc, smp, kp[(t0 - 0 * D) / 2 - P0], kp[(t0 - 1 * D) / 2 - P0], kp[(t0 - 2 * D) / 2 - P0], kp[(t0 - 3 * D) / 2 - P0],
-                                        kp[(t0 - 4 * D) / 2 - P0], kp[(t0 - 5 * D) / 2 - P0], kp[(t0 - 6 * D) / 2 - P0], kp[(t0 - 7 * D) / 2 - P0]);
-                    } else {
-                        ring_for_each_index([&](auto qi) {
-                            constexpr int q = decltype(qi)::value, t = t0 - D * q;
-                            if constexpr (t >= 0 && t < T) ring_slot1<odd>(acc[q], smp, kp[t / 2 - P0]);
-                        }, std::make_integer_sequence<int, OPL>{});
-                    }
+                    // the lane's outputs in groups of eight (one at /4, two at /2): a group whose eight windows all cover this sample takes the
+                    // one-statement form, a group at either end of the lane's span goes output by output
+                    ring_for_each_index([&](auto gi) {
+                        constexpr int g = decltype(gi)::value, tg = t0 - D * 8 * g;
+                        if constexpr (tg - D * 7 >= 0 && tg < T) {
+                            ring_slot8<odd>(reinterpret_cast<r_f32x2 (&)[8]>(acc[8 * g]), smp, kp[(tg - 0 * D) / 2 - P0], kp[(tg - 1 * D) / 2 - P0],
+                                            kp[(tg - 2 * D) / 2 - P0], kp[(tg - 3 * D) / 2 - P0], kp[(tg - 4 * D) / 2 - P0], kp[(tg - 5 * D) / 2 - P0],
+                                            kp[(tg - 6 * D) / 2 - P0], kp[(tg - 7 * D) / 2 - P0]);
+                        } else {
+                            ring_for_each_index([&](auto qi) {
+                                constexpr int q = 8 * g + decltype(qi)::value, t = t0 - D * q;
+                                if constexpr (t >= 0 && t < T) ring_slot1<odd>(acc[q], smp, kp[t / 2 - P0]);
+                            }, std::make_integer_sequence<int, 8>{});
+                        }
+                    }, std::make_integer_sequence<int, OPL / 8>{});
                 }, std::make_integer_sequence<int, 16>{});
                 __builtin_amdgcn_sched_barrier(0);      // (the next chunk's tap pairs are fetched behind this chunk's arithmetic, not in front of the whole loop)
             }
