@@ -242,7 +242,7 @@ def physical_cores():
 STAGE1 = {64: "k_decimate<32,212,64>", 16: "k_decimate<8,54,256>", 4: "k_decimate<4,139,256>", 256: "k_decimate<64,348,64>"}
 STEP = {64: "k_step<32,212,2,69>", 256: "k_step<64,348,4,139>"}
 STEP_CU = {64: "k_step_cu<212,2,69>", 128: "k_step_cu<174,4,139>"}     # one workgroup per CU: loader + computing waves for stage 1, the tails in the others
-STAGE1_CU = {64: "k_stage1_cu<212,32>", 128: "k_stage1_cu<174,32>", 16: "k_stage1_cu<54,8>"}   # stage 1 alone in that shape (eight tile slots, computing waves beside the loader)
+STAGE1_CU = {64: "k_stage1_cu<212,32>", 128: "k_stage1_cu<174,32>", 16: "k_stage1_cu<54,8>", 4: "k_stage1_cu<139,4>"}   # stage 1 alone in that shape (eight tile slots, computing waves beside the loader)
 PATHS = {0: "separate kernels", 1: "fused back end", 2: "stream tail kernel", 3: "step kernel (stage 1 + previous call's stream tails)"}
 
 
@@ -308,8 +308,10 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
         world = threads
         shards = [None] * threads
 
+        same = bool(os.environ.get("HD_BENCH_SAME_DEVICE"))        # (tests on a one-GPU box: every shard on device 0 -- the threading is what is exercised)
+
         def make(d):
-            shards[d] = Shard(torch, w, S, d, d, sync)
+            shards[d] = Shard(torch, w, S, 0 if same else d, d, sync)
         th = [threading.Thread(target=make, args=(d,)) for d in range(threads)]
         for t in th: t.start()
         for t in th: t.join()
@@ -485,7 +487,7 @@ def main():
         if world > 1:
             raise SystemExit("bench.py --threads is the one-process mode: start it without torchrun")
         threads = max(1, args.gpus)
-        if torch.cuda.device_count() < threads:
+        if torch.cuda.device_count() < threads and not os.environ.get("HD_BENCH_SAME_DEVICE"):
             raise SystemExit(f"bench.py --threads --gpus {threads}: only {torch.cuda.device_count()} device(s) visible")
     if world > 1:
         import torch.distributed as dist

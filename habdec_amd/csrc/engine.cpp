@@ -792,7 +792,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
 
     // ---- host mirror of the reference's size bookkeeping -> one StreamCall per stream
     uint32_t max_in = 0, min_in = 0xFFFFFFFFu, max_n1 = 0, max_n2 = 0, max_m = 0, max_taps = 0, max_new = 0, max_pend = 0;
-    bool any_fft = false, any_dc = false, any_zero1 = false, any_zero2 = false;
+    bool any_fft = false, any_dc = false, any_zero1 = false;
     uint64_t total_in = 0;
     for (uint32_t s = 0; s < S; ++s) {
         StreamHost& st = e->st[s];
@@ -850,7 +850,6 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         max_in = std::max(max_in, n); min_in = std::min(min_in, n); max_n1 = std::max(max_n1, c.n1); max_n2 = std::max(max_n2, c.n2);
         any_dc |= c.dc_remove != 0;
         any_zero1 |= c.zero_hist1 != 0;
-        any_zero2 |= c.zero_hist2 != 0;
         total_in += n;
     }
     sl.total_in = total_in;
@@ -951,15 +950,12 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     // Equally sized pushes through a single-wave first stage of a two-stage plan: the stage-1 workgroups (eight resident per CU) draw
     // runs of tiles from per-XCD counters (kernels/decimate.hip) -- no cold start per run, no fixed shares that end ragged.
     auto make_claim = [&](uint32_t lin_wgs /* stage 1 as a launch of its own: the workgroup count of its linear split (which needs four tiles per workgroup); 0 = step launch */,
-                          uint32_t run_len_cu = 0 /* != 0: runs for a per-CU ring kernel's loaders */, bool second_stage = false /* ... of the plan's SECOND stage (its input: max_n1 samples per stream) */) {
+                          uint32_t run_len_cu = 0 /* != 0: runs for a per-CU ring kernel's loaders */) {
         hd::StepClaim claim{};
         // (tiles: 64 outputs of a single-wave /32 or /64 first stage; 2048 input samples -- 64 lanes x one row of 32 -- for the per-CU ring kernels)
-        const uint32_t n_ring = second_stage ? max_n1 : max_in;
-        const uint32_t ntiles = run_len_cu ? n_ring / 2048u : (max_n1 + 63) / 64, n_xcd = e->n_cus / 32u, run_len = run_len_cu ? run_len_cu : e->step_run >= 2 ? e->step_run : 4u;   // (a run must hold the tile in front of which the next draw is issued: at least two; four re-read fewer halos than two)
+        const uint32_t ntiles = run_len_cu ? max_in / 2048u : (max_n1 + 63) / 64, n_xcd = e->n_cus / 32u, run_len = run_len_cu ? run_len_cu : e->step_run >= 2 ? e->step_run : 4u;   // (a run must hold the tile in front of which the next draw is issued: at least two; four re-read fewer halos than two)
         const uint64_t runs = (uint64_t)S * ntiles / run_len;
-        const bool shape_ok = run_len_cu ? (second_stage ? (hd::stage1_cu_supported((int)R2, (int)T2) && R2 <= 4 && n_ring % 2048u == 0 && !any_zero2)
-                                                         : (hd::stage1_cu_supported((int)R1, (int)T1) && max_in % 2048u == 0))
-                                         : ((R1 == 32 || R1 == 64) && max_n1 % 64 == 0);
+        const bool shape_ok = run_len_cu ? (hd::stage1_cu_supported((int)R1, (int)T1) && max_in % 2048u == 0) : ((R1 == 32 || R1 == 64) && max_n1 % 64 == 0);
         if (!e->no_claim && (nst == 2 || (run_len_cu && nst == 1)) && shape_ok && min_in == max_in && max_in && !any_zero1 && n_xcd && e->n_cus % 32u == 0 && n_xcd <= 16 &&
             ntiles && ntiles % run_len == 0 && runs % n_xcd == 0 && !e->qa_cus && (uint64_t)S * ntiles < (1ull << 32) && (uint64_t)ntiles * S >= 4ull * lin_wgs) {   // (the two counter sets alternate: a launch that takes one must really run that way)
             claim.ctr = e->step_ctr.p + (size_t)(e->step_launches & 1u) * 16 * 32;

@@ -144,3 +144,17 @@ def test_bench_self_check_on_every_workload(name, steps):
     cb = r["cpu_baseline"]
     assert cb["gpu_matches_oracle_on_sample"] is True, cb
     assert cb["bits_in_sample"] > 0
+
+
+def test_bench_threads_mode_two_shards(monkeypatch):
+    """`bench.py --gpus 2 --threads`: one process, an engine + host thread per device, no torchrun, no RCCL.  The box has one GPU, so both
+    shards sit on device 0 (HD_BENCH_SAME_DEVICE): what is exercised is the threading -- two rings, two engines, two step loops sharing one interpreter,
+    the timed region = the slower shard's -- and shard 0's self-check."""
+    torch = pytest.importorskip("torch")
+    import bench
+    monkeypatch.setenv("HD_BENCH_SAME_DEVICE", "1")
+    r = bench.run_workload(torch, None, torch.device("cuda", 0), 0, 0, 1, "cfg4", 12, 3, 256, False, cpu_leg="check", threads=2)
+    assert r["cpu_baseline"]["gpu_matches_oracle_on_sample"] is True, r["cpu_baseline"]
+    assert r["value"] > 0 and r["steps"] == 12
+    # value counts both shards' samples over the slower shard's region
+    assert r["value"] == pytest.approx(2 * 256 * 65536 * 12 / (r["timed_region_ms"] * 1e-3) / 1e6, rel=1e-2)
