@@ -664,7 +664,7 @@ __global__ __launch_bounds__(64 * HD_CU_WAVES) void k_step_cu(const RingArgs ra,
         const uint32_t k = w - kTailBase, lane = threadIdx.x & 63u;
         const uint32_t s = blockIdx.x * 4u + k;                          // (the grid has at least n_streams / 4 workgroups)
         if (s < n_streams) {
-        if (s < n_tail) tail_body<64, 4, D2, T2>(ta, s, tails + k * tail_bytes);
+        if (s < n_tail) tail_body<64, 4, D2, T2>(ta, s, tails + k * tail_bytes, k & 1u);    // (k & 1: the wave's rank on its SIMD -- the two tails of a SIMD take turns at the higher priority)
         // this call's parameters live in mapped host memory; the tails of this call (next launch) read the device copy
         if (call_copy && lane < 4) reinterpret_cast<uint4*>(call_copy + s)[lane] = reinterpret_cast<const uint4*>(call + s)[lane];
         }

@@ -100,7 +100,8 @@ __device__ __forceinline__ void tb_sync()
 
 // NT lanes, OP stage-2 outputs per lane and piece, stage-2 design (D2, T2).
 template <int NT, int OP, int D2, int T2>
-__device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, unsigned char* __restrict__ lds)
+__device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, unsigned char* __restrict__ lds,
+                                          const uint32_t prio_phase = 2u /* 0 / 1: one of two tails sharing a SIMD inside a step launch -- see HD_TAIL_PRIO_ALT below; 2: leave the priority alone */)
 {
     constexpr int P = NT * OP;                      // stage-2 outputs per piece
     constexpr int XCH = P * D2;                     // stage-1 samples a piece consumes
@@ -356,6 +357,16 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     // change: the whole backlog is due), then the pieces of the call -- so that the window-sum code exists once.
     uint32_t old_left = old_cnt - take0;
     for (uint32_t pc = 0;;) {
+#ifndef HD_TAIL_PRIO_EQUAL
+        // Two tails share a SIMD inside a step launch, and at equal priority the issue arbiter prefers the OLDER wave every time both are ready:
+        // the younger tail finishes ~20 us after its neighbour (in-kernel clocks, round 4), and the launch's second half -- the slots across PAIRS of
+        // finished tails -- waits for the later one.  Taking turns at the higher priority, piece by piece, lets the two progress alike: launch 152.5 ->
+        // 149.4 us, 0.1576-0.1587 -> 0.1543-0.1560 ms per step (one box, alternating builds; the younger one always on top: 150.5 us).
+#ifndef HD_TAIL_PRIO_LOW
+#define HD_TAIL_PRIO_LOW 2
+#endif
+        if (prio_phase < 2u) { if ((pc + prio_phase) & 1u) __builtin_amdgcn_s_setprio(HD_TAIL_PRIO_LOW); else __builtin_amdgcn_s_setprio(3); }
+#endif
         if (do_sums) {
             tb_sync<NT>();
             sym_feed();

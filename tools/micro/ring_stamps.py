@@ -17,12 +17,13 @@ n = 512 * 8 * 8
 st = np.zeros(n, np.uint64); f(st.ctypes.data, n); st = st.reshape(512, 8, 8).astype(np.float64)[:256]
 t0 = st[:, :, 6][st[:, :, 6] > 0].min()
 print("step kernel ms:", eng.timing()["ms_front"], "variant", eng.timing()["step_variant"])
-for ldw in (0, 1):
-  ld = st[:, ldw]
-  print("loader %d: tiles/CU p0/50/100" % ldw, np.percentile(ld[:, 5], [0, 50, 100]).tolist(), " lifetime us p50/100", np.percentile((ld[:, 7] - ld[:, 6]) / 100, [50, 100]).round(1).tolist())
-  tot = ld[:, :4].sum(axis=1)
-  print("  cycles total p50 %.0f; per tile: take-run %.0f issue %.0f publish+poll %.0f idle %.0f" % ((np.median(tot),) + tuple(np.median(ld[:, i] / ld[:, 5]) for i in range(4))))
-for wv in (2, 3, 4, 5, 6, 7):
+# rows: role 0 = the loader; roles 1-3 = computing waves; roles 4-7 = tail waves, of which the first to finish loads (its row then holds a loader's phases: the row
+# is written twice -- by ring_loader, then by ring_consumer -- and the consumer's record, written last, is what is read here)
+ld = st[:, 0]
+print("loader 0: tiles/CU p0/50/100", np.percentile(ld[:, 5], [0, 50, 100]).tolist(), " lifetime us p50/100", np.percentile((ld[:, 7] - ld[:, 6]) / 100, [50, 100]).round(1).tolist())
+tot = ld[:, :4].sum(axis=1)
+print("  cycles total p50 %.0f; per tile: publish %.0f issue %.0f take-run+check %.0f idle %.0f" % ((np.median(tot),) + tuple(np.median(ld[:, i] / np.maximum(ld[:, 5], 1)) for i in range(4))))
+for wv in (1, 2, 3, 4, 5, 6, 7):
     c = st[:, wv]
     if not (c[:, 5] > 0).any(): continue
     c = c[c[:, 5] > 0]
