@@ -724,8 +724,23 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         for (int u = 0; u < SB; ++u) { const uint32_t k = tid + u * NT; if (k < vc_n) vc[k] = ts0[u]; }
         // longer backlogs than the first batches cover (idle or freshly re-parameterised streams): plain loops
         for (uint32_t i = tid + MB * NT; i < nw; i += NT) lmask[i] = gmask[((wr0 + 64u * i) & rmask) >> 6];
-        for (uint32_t k = tid + CB * NT; k < wc_n; k += NT) wc[k] = gw[(st.base + k) & rmask];
-        for (uint32_t k = tid + SB * NT; k < vc_n; k += NT) vc[k] = vring[(st.base + carried_to + k) & rmask];
+        constexpr int RB = 8;                                           // (eight loads per lane in flight per trip: a loop of single loads is a round trip per element)
+#pragma unroll 1
+        for (uint32_t k0 = tid + CB * NT; k0 < wc_n; k0 += RB * NT) {
+            float t[RB];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) { const uint32_t k = k0 + u * NT; t[u] = k < wc_n ? gw[(st.base + k) & rmask] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) { const uint32_t k = k0 + u * NT; if (k < wc_n) wc[k] = t[u]; }
+        }
+#pragma unroll 1
+        for (uint32_t k0 = tid + SB * NT; k0 < vc_n; k0 += RB * NT) {
+            float t[RB];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) { const uint32_t k = k0 + u * NT; t[u] = k < vc_n ? vring[(st.base + carried_to + k) & rmask] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) { const uint32_t k = k0 + u * NT; if (k < vc_n) vc[k] = t[u]; }
+        }
     }
     tb_sync<NT>();
     TSTAMP(8);
