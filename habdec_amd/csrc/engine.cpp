@@ -985,7 +985,10 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         fill_tail(ta_step);
         hd_engine::PendingTail prev = e->pend;
         hd_engine::CallSlot* ps = prev.valid ? &e->slot[prev.slot] : nullptr;
-        if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
+        // Events of a k_step_cu launch ride on its dispatch packet (launch_step_cu): an event recorded behind it is a barrier packet of its own and
+        // costs the queue ~5 us before the next launch starts.  (Not where the spectra are a launch of their own: ev_done follows that one.)
+        static const bool ext_events = !getenv("HD_STEP_PACKET_EVENTS");
+        bool ev_on_dispatch = false;
         uint32_t wgs = e->step_wgs ? e->step_wgs : 32u * e->n_cus;   // short runs of tiles: the dispatcher evens out the tail of the launch
         // One workgroup per CU (loader + consumer waves for stage 1, the tails in the other four waves) where the plan and the sizes allow it
         const uint32_t cu_tail = hd::step_cu_tail_lds((int)R1, (int)T1);
@@ -1006,21 +1009,26 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             const uint32_t n_slots = (cu_tail5 && ((tb + 15u) & ~15u) <= cu_tail5) ? 5u : 4u;
             hd::StepClaim cl = claim;
             if (cu_exp & 2) cl.runs_per_xcd = 0;
+            ev_on_dispatch = ext_events && (!ps || prev.ta.fft_tw || !prev.any_fft);
+            if (sl.timed && !ev_on_dispatch) HD_HIP(hipEventRecord(sl.t1, qa));
             launched = hd::launch_step_cu(qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, e->n_cus, iq, stride,
                                           e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, prev.ta,
-                                          (prev.valid && !(cu_exp & 1)) ? S : 0u, max_in, cl, (tb + 15u) & ~15u, e->ring_gave_up.dev, e->ring_loaders, n_slots);
+                                          (prev.valid && !(cu_exp & 1)) ? S : 0u, max_in, cl, (tb + 15u) & ~15u, e->ring_gave_up.dev, e->ring_loaders, n_slots,
+                                          ev_on_dispatch && sl.timed ? sl.t1 : nullptr, !ev_on_dispatch ? nullptr : sl.timed ? sl.t2 : ps ? ps->ev_done : nullptr);
+            if (!launched && ev_on_dispatch) { ev_on_dispatch = false; if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa)); }
             if (launched) e->last_step_slots = n_slots;
             e->last_timing.step_variant = launched ? 1u : 0u;
         }
+        else if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
         if (!launched)
         if (!hd::launch_step(qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, max_n1, iq, stride, e->hist1[hin].p,
                              e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, wgs, prev.ta, prev.valid ? S : 0u,
                              any_zero1 ? 0u : max_in, claim))
             return fail(HD_ERR_INVALID, "no step kernel for this decimation plan");
-        if (sl.timed) HD_HIP(hipEventRecord(sl.t2, qa));
+        if (sl.timed && !ev_on_dispatch) HD_HIP(hipEventRecord(sl.t2, qa));
         if (ps) {
             if (!prev.ta.fft_tw) { if (const int r = run_spectrum(e, qa, *ps, prev.any_fft)) return r; }
-            HD_HIP(hipEventRecord(ps->ev_done, qa));
+            if (!ev_on_dispatch || sl.timed) HD_HIP(hipEventRecord(ps->ev_done, qa));    // (a timed launch's own signal is its t2)
         }
         e->pend.valid = true; e->pend.ta = ta_step; e->pend.slot = (int)(e->calls % hd_engine::kSlots); e->pend.any_fft = any_fft;
         e->pend.r2 = (int)R2; e->pend.t2 = (int)T2; e->pend_max_taps = max_taps;

@@ -20,6 +20,7 @@
 // History: the workgroup that owns a stream's last tile also writes the stream's next history (last T-1 inputs)
 // into the OTHER history buffer (ping-pong, so the first tile of the same launch still reads the old one).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <type_traits>
 #include <cstdlib>
 
@@ -863,7 +864,8 @@ uint32_t step_cu_tail_lds(int ratio, int ntaps, uint32_t n_slots)
 
 bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, uint32_t n_streams, uint32_t n_cus, const float2* in, size_t in_stride,
                     const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
-                    StreamCall* call_copy, const TailArgs& ta, uint32_t n_tail, uint32_t uniform_n, const StepClaim& claim, uint32_t tail_bytes, unsigned int* gave_up, uint32_t n_loaders, uint32_t n_slots)
+                    StreamCall* call_copy, const TailArgs& ta, uint32_t n_tail, uint32_t uniform_n, const StepClaim& claim, uint32_t tail_bytes, unsigned int* gave_up, uint32_t n_loaders, uint32_t n_slots,
+                    hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (n_loaders != 1u) n_loaders = 2u;
     if (n_slots != 5u || n_loaders != 1u) n_slots = 2u * (uint32_t)kRingNSL;
@@ -882,7 +884,10 @@ bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_cu<T, D2, T2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) return false; \
             attr_set[dev_] = true;                                                                                                    \
         }                                                                                                                             \
-        hipLaunchKernelGGL((k_step_cu<T, D2, T2>), dim3(n_cus > (n_streams + 3u) / 4u ? n_cus : (n_streams + 3u) / 4u), dim3(64 * HD_CU_WAVES), lds, st, ra, call, call_copy, ta, n_tail, n_streams, tail_bytes, n_loaders, n_slots); \
+        const dim3 grid_(n_cus > (n_streams + 3u) / 4u ? n_cus : (n_streams + 3u) / 4u);                                             \
+        /* events handed to the launch ride on the dispatch packet's own completion signal: no barrier packet behind the kernel */     \
+        if (ev_start || ev_stop) hipExtLaunchKernelGGL((k_step_cu<T, D2, T2>), grid_, dim3(64 * HD_CU_WAVES), lds, st, ev_start, ev_stop, 0u, ra, call, call_copy, ta, n_tail, n_streams, tail_bytes, n_loaders, n_slots); \
+        else hipLaunchKernelGGL((k_step_cu<T, D2, T2>), grid_, dim3(64 * HD_CU_WAVES), lds, st, ra, call, call_copy, ta, n_tail, n_streams, tail_bytes, n_loaders, n_slots); \
         return true;                                                                                                                  \
     }
     HD_CU_CASE(212, 2, 69) HD_CU_CASE(174, 4, 139)

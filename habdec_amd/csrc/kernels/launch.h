@@ -112,7 +112,8 @@ bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2
                     const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
                     StreamCall* call_copy, const TailArgs& ta, uint32_t n_tail, uint32_t uniform_n, const StepClaim& claim, uint32_t tail_bytes,
                     unsigned int* gave_up /* mapped host word, see RingArgs */, uint32_t n_loaders /* 1 or 2 LDS-DMA waves per CU */,
-                    uint32_t n_slots = 4 /* tile slots in the ring region */);
+                    uint32_t n_slots = 4 /* tile slots in the ring region */,
+                    hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr /* signalled by the dispatch itself (hipExtLaunchKernel), not by a packet behind it */);
 // Stage 1 alone in the same shape (eight tile slots, one loader wave and seven computing waves by default): a /32 or /8 first stage, equally sized pushes that are a multiple of 2048
 // samples, drawn runs, no history restart; false otherwise (the caller then launches k_decimate).  The call's parameter block is not copied.
 bool step_cu_supported(int ratio, int ntaps, int ratio2, int ntaps2);   // plans k_step_cu is instantiated for: /64 (/32 212 + /2 69), /128 (/32 174 + /4 139)

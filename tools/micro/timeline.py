@@ -1,13 +1,14 @@
 """Kernel timeline of a bench run from a rocprofv3 --kernel-trace csv: the hd:: kernels of the last few steps with start / end relative to the first one shown,
-their queue, and the gap to the previous kernel on the same queue.  Usage: timeline.py <kernel_trace.csv> [n_last=40]"""
+their queue, and the gap to the previous kernel on the same queue.  Usage: timeline.py <kernel_trace.csv> [n_last=40] [name filter]"""
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+flt = sys.argv[3] if len(sys.argv) > 3 else ""
 ks = []
 for r in rows:
     m = re.search(r"hd::(k_\w+)(<[^>]*>)?", r["Kernel_Name"])
     name = (m.group(1) + (m.group(2) or "")) if m else ("rocfft" if "fft" in r["Kernel_Name"] else None)
-    if name:
+    if name and flt in name:
         ks.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Queue_Id", "?")))
 ks.sort()
 ks = ks[-n:]
