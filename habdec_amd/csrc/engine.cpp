@@ -319,7 +319,9 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         } else
             HD_HIP(hipStreamCreateWithFlags(&e->qa, hipStreamNonBlocking));
     }
-    e->one_stream = getenv("HD_ONE_STREAM") != nullptr;
+    // Synchronous delivery (pipeline = 0) has nothing to overlap between calls: one queue, no cross-queue event between the front and the back half
+    // (0.283 -> 0.268 ms per step at 1024 streams, 12 us of it the hop from one queue to the other).  HD_TWO_QUEUES=1 keeps the two for comparisons.
+    e->one_stream = getenv("HD_ONE_STREAM") != nullptr || (cfg->pipeline == 0 && !e->qb && !getenv("HD_TWO_QUEUES"));
     e->no_fuse = getenv("HD_NO_FUSE") != nullptr;
     e->no_tail = getenv("HD_NO_TAIL") != nullptr;
     e->no_step = getenv("HD_NO_STEP") != nullptr;
@@ -901,9 +903,13 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     sl.timed = e->timing_every && (e->calls % e->timing_every) == 0;
     sl.timed_step = sl.timed && step;                       // a step call is ONE launch: two event records (each a barrier packet), not four
     if (sl.timed && !step) HD_HIP(hipEventRecord(sl.t0, qa));
+    // One queue and the stream tails behind stage 1 (synchronous delivery): both kernels read the call's parameters from the mapped host block -- one
+    // round trip over PCIe at the start of a workgroup instead of a copy kernel in front of stage 1.  (Not where a spectrum launch reads the device copy.)
+    static const bool fetch_env = getenv("HD_FETCH_PARAMS") != nullptr;
+    const bool host_params = tail && !step && e->one_stream && !fetch_env && (!e->cfg.enable_spectrum || (e->tail_fft && !any_dc));
     if (lean) {
         if (e->sym_dirty && e->calls > e->delivered) { if (int rc = flush_locked(e)) return rc; }   // symbol parameters are uploaded below: nothing may still read them
-    } else {
+    } else if (!host_params) {
         // the parameter block is pulled on its own queue, so it does not wait for the previous call's stage 1 to drain
         hd::launch_fetch_params(e->qc, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
         if (!e->one_stream) { HD_HIP(hipEventRecord(sl.ev_params, e->qc)); HD_HIP(hipStreamWaitEvent(qa, sl.ev_params, 0)); }
@@ -933,7 +939,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     const float2* iq = static_cast<const float2*>(d_iq);
     float2* fcur = e->fbuf[e->cur].p;
     float2* fnext = e->fbuf[e->cur ^ 1].p;
-    const hd::StreamCall* dcall = sl.d_call.p;
+    const hd::StreamCall* dcall = host_params ? sl.h_call.dev : sl.d_call.p;
     float2* d1 = (e->calls % 3 == 0) ? e->dec1.p : (e->calls % 3 == 1) ? e->dec1b.p : e->dec1c.p;   // never a buffer a call in flight still reads
     const int hin = e->hist_cur, hout = e->hist_cur ^ 1;
     // spectrum collection rides in the final stage's epilogue unless the DC blocker must see the samples first
