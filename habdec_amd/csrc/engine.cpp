@@ -667,9 +667,9 @@ int run_pending_tail(hd_engine* e)
         // (same buffers, other LDS offsets)
         if (!hd::tail_layout(lay, lanes, e->pend.r2, e->pend.t2, e->pend_max_taps, e->max_R, e->min_R, e->tail_cap, e->pend.ta.pend_max, 64 * 1024)) return fail(HD_ERR_INVALID, "stream tail layout");
     }
-    if (!hd::launch_tail(e->qa, lanes, e->pend.r2, e->pend.t2, e->S, lay)) return fail(HD_ERR_INVALID, "stream tail refused a shape it was selected for");
-    if (!ta.fft_tw) { if (const int r = run_spectrum(e, e->qa, ps, e->pend.any_fft)) return r; }
-    HD_HIP(hipEventRecord(ps.ev_done, e->qa));
+    const bool own_spectrum = (!ta.fft_tw && e->cfg.enable_spectrum && e->pend.any_fft) || getenv("HD_STEP_PACKET_EVENTS");       // a transform launch follows the tails: the event goes behind that one
+    if (!hd::launch_tail(e->qa, lanes, e->pend.r2, e->pend.t2, e->S, lay, own_spectrum ? nullptr : ps.ev_done)) return fail(HD_ERR_INVALID, "stream tail refused a shape it was selected for");
+    if (own_spectrum) { if (!ta.fft_tw) { if (const int r = run_spectrum(e, e->qa, ps, e->pend.any_fft)) return r; } HD_HIP(hipEventRecord(ps.ev_done, e->qa)); }
     HD_HIP(hipGetLastError());
     return HD_OK;
 }
@@ -1126,10 +1126,15 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     // "two-stream pipeline").
     if (!e->one_stream) HD_HIP(hipStreamWaitEvent(qb, sl.ev_front, 0));
     mark();
+    bool done_on_dispatch = false;
+    static const bool dispatch_events = !getenv("HD_STEP_PACKET_EVENTS");
+    const bool ev_ride = dispatch_events && !sl.timed && e->one_stream;   // (two queues: the event is not on the step's critical path, and /16 measured no better with it on the dispatch)
     if (tail) {
         if (lean) hd::launch_fetch_params(qb, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
         fill_tail(ta);
-        if (!hd::launch_tail(qb, tail_lanes, (int)R2, (int)T2, S, ta)) return fail(HD_ERR_INVALID, "stream tail refused a shape it was selected for");
+        // (the call's completion event rides on the tails' dispatch where nothing is launched behind them)
+        done_on_dispatch = ev_ride && (ta.fft_tw || !(e->cfg.enable_spectrum && max_n2));
+        if (!hd::launch_tail(qb, tail_lanes, (int)R2, (int)T2, S, ta, done_on_dispatch ? sl.ev_done : nullptr)) return fail(HD_ERR_INVALID, "stream tail refused a shape it was selected for");
         if (!ta.fft_tw) { if (const int r = spectrum(qb)) return r; }
     } else if (fuse) {
         if (lean) hd::launch_fetch_params(qb, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
@@ -1149,10 +1154,11 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     mark();
     if (!tail)
     hd::launch_symbols(qb, S, max_m, max_new, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p,
-                       dcall, sl.h_slots.dev, e->slot_words, e->flips_cap ? e->flips_dbg.p : nullptr, e->flips_cap, e->min_R);
+                       dcall, sl.h_slots.dev, e->slot_words, e->flips_cap ? e->flips_dbg.p : nullptr, e->flips_cap, e->min_R, ev_ride ? sl.ev_done : nullptr);
+    if (!tail && ev_ride) done_on_dispatch = true;
     mark();
     if (sl.timed) HD_HIP(hipEventRecord(sl.t3, qb));
-    HD_HIP(hipEventRecord(sl.ev_done, qb));
+    if (!done_on_dispatch) HD_HIP(hipEventRecord(sl.ev_done, qb));
     mark();
     HD_HIP(hipGetLastError());
     sl.busy = true;

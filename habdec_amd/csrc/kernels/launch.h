@@ -68,7 +68,8 @@ bool launch_backend(hipStream_t st, int ratio2, int ntaps2, uint32_t n_streams, 
 void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_new, uint32_t max_R, const float* tail,
                     uint32_t ring_cap, SymState* sym, unsigned long long* flipmask, float* weight, const SymbolParams* sp,
                     const StreamCall* call, uint32_t* slots, uint32_t slot_words, uint32_t* flips_dbg, uint32_t flips_cap,
-                    uint32_t min_R /* smallest averaging half-window over the streams: bounds the flips one call can find */);
+                    uint32_t min_R /* smallest averaging half-window over the streams: bounds the flips one call can find */,
+                    hipEvent_t ev_stop = nullptr /* signalled by the dispatch itself, as in launch_step_cu */);
 
 // ---- the fused stream tail (tail_body.h / tail.hip): stage 2 + low-pass + discriminator + symbol extractor, one wave per stream
 struct TailArgs {
@@ -96,7 +97,7 @@ struct TailArgs {
 // and launch_symbols instead.
 bool tail_layout(TailArgs& a, int lanes, int ratio2, int ntaps2, uint32_t max_taps, uint32_t max_R, uint32_t min_R, uint32_t ring_cap,
                  uint32_t pend_max /* most pending samples any stream has in front of or behind this call's low-pass run */, uint32_t lds_limit);
-bool launch_tail(hipStream_t st, int lanes, int ratio2, int ntaps2, uint32_t n_streams, const TailArgs& a);
+bool launch_tail(hipStream_t st, int lanes, int ratio2, int ntaps2, uint32_t n_streams, const TailArgs& a, hipEvent_t ev_stop = nullptr);
 // Batch mode, two-stage plans whose first stage is a single-wave design: ONE launch per step -- the stream tails of the previous call
 // (workgroups [0, n_tail), arguments `ta`) in front of this call's stage 1 as a linear split over stage1_wgs workgroups; every stream
 // has n_out stage-1 outputs.  Returns false when there is no instantiation for the plan.

@@ -19,6 +19,7 @@
 //     positions per step through ballots and find-first-set); per-run sums are accumulated in element order with
 //     the wave loading 256 samples at a time and v_readlane feeding a wave-uniform accumulator; lane 0 packs bits.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdlib>
 
 #include "launch.h"
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
 
 void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_new, uint32_t max_R, const float* tail,
                     uint32_t ring_cap, SymState* sym, unsigned long long* flipmask, float* weight, const SymbolParams* sp,
-                    const StreamCall* call, uint32_t* slots, uint32_t slot_words, uint32_t* flips_dbg, uint32_t flips_cap, uint32_t min_R)
+                    const StreamCall* call, uint32_t* slots, uint32_t slot_words, uint32_t* flips_dbg, uint32_t flips_cap, uint32_t min_R, hipEvent_t ev_stop)
 {
     (void)max_m; (void)max_new;
     // a flip point moves the search on by R, so a call finds at most backlog / R + 1 of them (the backlog never exceeds the ring)
@@ -419,8 +420,10 @@ void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t
     if (fl_cap > kMaxFlipsPerCall) fl_cap = kMaxFlipsPerCall;
     const size_t lds = (size_t)(ring_cap / 64) * 8 + (size_t)fl_cap * 8 +
                  (size_t)(((kAvgSpan + max_R + 16 + 3) & ~3u) + ((kAvgSpan + max_R + 3) & ~3u)) * 4;
-    hipLaunchKernelGGL(k_symbols, dim3(n_streams), dim3(kSymLanes), lds, st, tail, ring_cap, sym, flipmask, weight, sp, call, slots,
-                       slot_words, flips_dbg, flips_cap, fl_cap);
+    if (ev_stop) hipExtLaunchKernelGGL(k_symbols, dim3(n_streams), dim3(kSymLanes), (uint32_t)lds, st, nullptr, ev_stop, 0u, tail, ring_cap, sym, flipmask, weight, sp, call, slots,
+                                       slot_words, flips_dbg, flips_cap, fl_cap);
+    else hipLaunchKernelGGL(k_symbols, dim3(n_streams), dim3(kSymLanes), lds, st, tail, ring_cap, sym, flipmask, weight, sp, call, slots,
+                            slot_words, flips_dbg, flips_cap, fl_cap);
 }
 
 }  // namespace hd

@@ -1,6 +1,7 @@
 // The stream tail as a kernel of its own: one workgroup per stream, 64 lanes (batches) or 256 lanes (a handful of streams, where the
 // latency of the one wave would show).  The same body rides in the stage-1 launch in batch mode (k_step, decimate.hip).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "tail_body.h"
 
@@ -62,11 +63,12 @@ bool tail_layout(TailArgs& a, int lanes, int ratio2, int ntaps2, uint32_t max_ta
     return true;
 }
 
-bool launch_tail(hipStream_t st, int lanes, int ratio2, int ntaps2, uint32_t n_streams, const TailArgs& a)
+bool launch_tail(hipStream_t st, int lanes, int ratio2, int ntaps2, uint32_t n_streams, const TailArgs& a, hipEvent_t ev_stop)
 {
 #define HD_TAIL_CASE(NT, D, T)                                                                                        \
     if (lanes == NT && ratio2 == D && ntaps2 == T) {                                                                  \
-        hipLaunchKernelGGL((k_tail<NT, tail_op(NT), D, T>), dim3(n_streams), dim3(NT), a.lds_bytes, st, a);           \
+        if (ev_stop) hipExtLaunchKernelGGL((k_tail<NT, tail_op(NT), D, T>), dim3(n_streams), dim3(NT), a.lds_bytes, st, nullptr, ev_stop, 0u, a); \
+        else hipLaunchKernelGGL((k_tail<NT, tail_op(NT), D, T>), dim3(n_streams), dim3(NT), a.lds_bytes, st, a);      \
         return true;                                                                                                  \
     }
     HD_TAIL_CASE(64, 2, 69) HD_TAIL_CASE(64, 4, 139) HD_TAIL_CASE(256, 2, 69) HD_TAIL_CASE(256, 4, 139)
