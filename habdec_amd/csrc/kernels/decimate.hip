@@ -762,7 +762,7 @@ __global__ __launch_bounds__(64) void k_dc_remove(float2* __restrict__ fbuf, siz
         const uint32_t i = base + lane;
         float2 v = i < c.n2 ? x[i] : make_float2(0.f, 0.f);
         float yr = 0.f, yi = 0.f;
-#pragma unroll
+#pragma unroll 8                                 // (fully unrolled the compiler hoisted all 128 broadcasts to the front: 130 spilled SGPRs)
         for (int k = 0; k < 64; ++k) {
             const float xr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.x), k));
             const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v.y), k));
