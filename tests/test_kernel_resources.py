@@ -49,3 +49,5 @@ def test_step_and_stage1_kernels_do_not_spill(tmp_path):
     assert t[k]["spill"] == 0 and t[k]["scratch"] <= 32 and t[k]["vgpr"] <= 256, (k, t[k])
     # the single-wave fallback of the step launch is allowed its two spilled registers (12 bytes of scratch), no more
     assert t["k_step<32,212,2,69>"]["spill"] <= 2 and t["k_step<32,212,2,69>"]["scratch"] <= 12, t["k_step<32,212,2,69>"]
+    # the DC blocker's 64-lane recurrence: a handful of registers, nothing spilled (fully unrolled it had parked 130 scalars)
+    assert t["k_dc_remove"]["spill"] == 0 and t["k_dc_remove"]["scratch"] == 0 and t["k_dc_remove"]["vgpr"] <= 32, t["k_dc_remove"]
