@@ -48,7 +48,7 @@ VALU_NONFMA_TFLOPS = 78.6      # FP32 vector peak with separately rounded multip
 WORKLOADS = {
     # name: fs, decimation, baud, bits, stops, streams/GPU, chunk, lowpass_bw, lowpass_trans, ungated, carrier offsets
     "cfg4": dict(fs=2.048e6, D=64, baud=50, bits=7, stops=2, S=1024, C=65536, lp_bw=1500.0, lp_trans=0.025, ungated=False, offsets=True,
-                 desc="BASELINE configs[3] per GPU: 1024 streams @ 2.048 MS/s, /64 (/32 212 taps + /2 69 taps), 50 baud 7N2, 161-tap low-pass, spectrum+AFC every call"),
+                 desc="BASELINE configs[3] per GPU: 1024 streams @ 2.048 MS/s, /64 (/32 212 taps + /2 69 taps), 50 baud 7N2, 161-tap low-pass, spectrum+AFC on every completed 4096-sample buffer (every 4th call)"),
     "cfg1": dict(fs=2.048e6, D=64, baud=300, bits=8, stops=2, S=1024, C=65536, lp_bw=1500.0, lp_trans=0.025, ungated=False, offsets=False,
                  desc="configs[0] batched: 1024 streams @ 2.048 MS/s, /64, 300 baud 8N2"),
     "cfg2": dict(fs=2.5e6, D=16, baud=300, bits=8, stops=2, S=1024, C=65536, lp_bw=3000.0, lp_trans=0.025, ungated=False, offsets=False,
