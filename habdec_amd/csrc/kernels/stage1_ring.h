@@ -70,8 +70,12 @@ extern "C" void hd_debug_ring_stamps(unsigned long long* host, size_t n) { (void
 #endif
 
 #ifdef HD_RING_FAULT
-__device__ unsigned int g_ring_fault_fired;
-extern "C" void hd_debug_ring_fault_arm() { const unsigned int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ring_fault_fired), &z, sizeof z); }   // (one fault per arming)
+__device__ unsigned int g_ring_fault_fired, g_ring_fault_mode;
+// (one fault per arming.  Mode 0: a loader never publishes its second tile and stops.  Mode 1: a computing wave naps with its ticket drawn until its
+// publication word has been overwritten by a later one.)
+static void ring_fault_arm(unsigned int mode) { const unsigned int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ring_fault_mode), &mode, sizeof mode); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ring_fault_fired), &z, sizeof z); }
+extern "C" void hd_debug_ring_fault_arm() { ring_fault_arm(0u); }
+extern "C" void hd_debug_ring_fault_arm_nap() { ring_fault_arm(1u); }
 #endif
 
 struct RingCtl {
@@ -275,12 +279,10 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
         hist_off[r] = (uint32_t)(h < 0 ? 0 : h) * 8u + (lane & 1u) * 4u;
     }
 
-    // ---- runs of tiles: drawn from this XCD's counter by the feeding consumer (ring_consumer), handed over through ctl->run_q.  (A loader
+    // ---- runs of tiles: drawn from the XCDs' counters by the feeding consumer (ring_consumer), handed over through ctl->run_q.  (A loader
     // issues nothing but LDS-DMA: a returning GLOBAL atomic among them would have to be counted by hand too, and its destination register is
     // the compiler's to move before the value has arrived.  The LDS atomics below return through the other counter.)
-    const uint32_t xcd0 = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // XCC_ID
-    const uint32_t xcd = xcd0 < a.claim.n_xcd ? xcd0 : a.claim.n_xcd - 1;
-    const uint32_t runs = a.claim.runs_per_xcd, run_len = a.claim.run_len;
+    const uint32_t run_len = a.claim.run_len;
     bool have = false, ended = false, claimed = false;
     uint32_t s = 0, tile = 0, left = 0, my_run = 0;
     uint32_t issued = 0, landed = 0;                // my tiles
@@ -309,7 +311,7 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
             inflight_instr -= oldest; fifo >>= 8; sfifo >>= 8;
             ++landed;
 #ifdef HD_RING_FAULT   // fault-injection build (libhabdec_amd_fault.so, tests/test_gpu_fault.py): ONE loader of the process never publishes its second tile and stops
-            if (landed == 2u) {
+            if (landed == 2u && g_ring_fault_mode == 0u) {
                 unsigned int won = 1u;
                 if (lane == 0) won = atomicCAS(&g_ring_fault_fired, 0u, 1u);
                 if ((unsigned int)__builtin_amdgcn_readfirstlane((int)won) == 0u) { RSTAMP_WRITE(stamp_row, issued); return; }   // (still counted in `live`: the consumers' waits run out)
@@ -332,8 +334,8 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
             if ((int32_t)(tail - my_run) > 0) {
                 const uint32_t rr = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctl->run_q[my_run & 3u]);
                 claimed = false;
-                if (rr < runs) {
-                    const uint32_t g0 = (xcd * runs + rr) * run_len;
+                if (rr != 0xFFFFFFFFu) {
+                    const uint32_t g0 = rr * run_len;                  // (rr: the run's number in the launch, whichever XCD's share it was drawn from)
                     s = g0 / a.ntiles; tile = g0 - s * a.ntiles; left = run_len; have = true;
                 } else {
                     ended = true;
@@ -507,6 +509,9 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
                                                     // as long as this wave lives -- and it lives until every loader has counted itself out
     const uint32_t xcd0 = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // XCC_ID
     const uint32_t xcd = xcd0 < a.claim.n_xcd ? xcd0 : a.claim.n_xcd - 1;
+    // The runs of a launch are dealt to the XCDs in equal shares, one counter each, and an XCD's CUs draw from their own share only (the queue entry is the
+    // run's number in the whole launch).  Round 4 let a CU whose XCD had run dry go on with the neighbours' counters: bit-identical once the feeder tried one
+    // counter per visit, and 1 % SLOWER (NOTES.md) -- the XCDs that end late are the ones whose tails end late, not the ones with tiles left.
     unsigned int* my_ctr = a.claim.ctr + (size_t)xcd * 32;
     unsigned int* next_ctr = a.claim.ctr_next + (size_t)xcd * 32;
     auto feed = [&]() {
@@ -515,12 +520,14 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
             if ((int32_t)(fed - head) >= 2) break;  // two unclaimed entries are ready (entries are reused four later: a claimed one has been read long before)
             uint32_t v = 0xFFFFFFFFu;
             if (!exhausted) {
+                // (ONE returning agent-scope atomic per visit, a microsecond or two: this wave is a consumer with a ticket of its own, and the publication
+                // word it waits for is overwritten sixteen publications later -- see the check in the wait loop below)
                 unsigned int t = 0;
                 if (lane == 0) t = __hip_atomic_fetch_add(my_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
                 // the first ticket past the end -- exactly one per XCD and launch -- resets the XCD's counter of the other set for the next step launch
                 if (t == a.claim.runs_per_xcd && lane == 0) (void)__hip_atomic_exchange(next_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (t < a.claim.runs_per_xcd) v = t; else exhausted = true;
+                if (t < a.claim.runs_per_xcd) v = xcd * a.claim.runs_per_xcd + t; else exhausted = true;
             }
             if (lane == 0) {
                 ctl->run_q[fed & 3u] = v;
@@ -537,9 +544,25 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
         if (lane == 0) g = __hip_atomic_fetch_add(&ctl->taken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
         unsigned long long pw = 0;
+#ifdef HD_RING_FAULT   // fault mode 1: ONE computing wave of the process sleeps through more than sixteen publications with its ticket drawn
+        if (g == 8u && g_ring_fault_mode == 1u) {
+            unsigned int won = 1u;
+            if (lane == 0) won = atomicCAS(&g_ring_fault_fired, 0u, 1u);
+            if ((unsigned int)__builtin_amdgcn_readfirstlane((int)won) == 0u) {
+                while (__hip_atomic_load(&ctl->pub_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < g + 17u &&
+                       __hip_atomic_load(&ctl->live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(8);
+            }
+        }
+#endif
         for (uint32_t spin = 0;; ++spin) {
             pw = __hip_atomic_load(&ctl->pub[g & 15u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if ((uint32_t)(pw >> 40) == g) break;
+            if (pw != ~0ull && (int32_t)((((uint32_t)(pw >> 40)) - g) << 8) > 0) {
+                // a LATER publication sits in my word: mine came and went while I was not looking (sixteen publications ago) -- its tile is lost.  Never in a
+                // correct run (a waiting consumer looks every few hundred cycles); reported like the other bounded waits instead of leaving a stale tile behind.
+                if (lane == 0) __hip_atomic_store(a.gave_up, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
             if (__hip_atomic_load(&ctl->live, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
                 // no loader will publish any more -- unless publication g went out between the two reads (a loader publishes, THEN counts itself out)
                 pw = __hip_atomic_load(&ctl->pub[g & 15u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -30,3 +30,15 @@ for wv in (1, 2, 3, 4, 5, 6, 7):
     print("consumer %d: tiles p0/50/100 %s; per tile: wait %.0f compute %.0f store+take %.0f; lifetime us p50 %.1f end us p100 %.1f" % (
         wv, np.percentile(c[:, 5], [0, 50, 100]).tolist(), np.median(c[:, 0] / c[:, 5]), np.median(c[:, 1] / c[:, 5]), np.median(c[:, 2] / c[:, 5]),
         np.median((c[:, 7] - c[:, 6]) / 100), ((c[:, 7] - t0) / 100).max()))
+# when does each CU (workgroup) run out of work, and when did its tails hand over?  (realtime counter: 100 ticks per microsecond)
+ok = st[:, :, 7] > 0
+end_cu = np.where(ok, st[:, :, 7], 0).max(axis=1)
+start_cu = np.where(ok, st[:, :, 6], np.inf).min(axis=1)
+print("workgroup start us p0/50/100", np.percentile((start_cu - t0) / 100, [0, 50, 100]).round(1).tolist(),
+      " end us p0/10/50/90/100", np.percentile((end_cu - t0) / 100, [0, 10, 50, 90, 100]).round(1).tolist())
+tl = st[:, 4:8]
+tstart = tl[:, :, 6]
+print("late waves (tails first): became computing waves at us p0/50/100", np.percentile((tstart[tstart > 0] - t0) / 100, [0, 50, 100]).round(1).tolist(),
+      " last of a CU p50/100", np.percentile((tstart.max(axis=1) - t0) / 100, [50, 100]).round(1).tolist())
+per_xcd = [np.percentile((end_cu[x::8] - t0) / 100, 100) for x in range(8)]
+print("end us of the last workgroup per blockIdx %% 8:", np.round(per_xcd, 1).tolist())
