@@ -42,3 +42,11 @@ print("late waves (tails first): became computing waves at us p0/50/100", np.per
       " last of a CU p50/100", np.percentile((tstart.max(axis=1) - t0) / 100, [50, 100]).round(1).tolist())
 per_xcd = [np.percentile((end_cu[x::8] - t0) / 100, 100) for x in range(8)]
 print("end us of the last workgroup per blockIdx %% 8:", np.round(per_xcd, 1).tolist())
+if os.environ.get("PER_CU"):
+    # one line per workgroup of two XCDs: when its waves ended (us), tiles taken by its first loader, when its tail waves turned to stage 1
+    for x in (0, 1):
+        print(f"-- workgroups with blockIdx % 8 == {x} (sorted by end): end us | loader-0 tiles | loader-0 end | tails done at us (four waves)")
+        rows = []
+        for b in range(x, 256, 8):
+            rows.append(((end_cu[b] - t0) / 100, int(st[b, 0, 5]), (st[b, 0, 7] - t0) / 100, sorted(((st[b, 4:8, 6] - t0) / 100).round(0).tolist())))
+        for r in sorted(rows): print("   %6.1f | %3d | %6.1f | %s" % r)
