@@ -13,6 +13,10 @@ calls are undelivered and each call's text is delivered, in order, while the nex
 inside the timed region (hd_flush before the closing barrier).  --sync delivers every step's text before the next step
 starts, like Decoder::operator().  Metric: input complex samples consumed per second over all GPUs (IQ Msamples/s).
 
+In front of the W warm-up steps the loop runs --prewarm untimed steps of itself (default: one pass over the ring): its first
+~150 launches run about 10 % below the rate it then sustains, whatever kept the GPU busy before, and the driver's timed
+region is 20 steps long.  The line says so (`prewarm_steps`); --prewarm 0 gives the old behaviour.
+
 The default workload is BASELINE.json configs[3] per GPU: 1024 streams @ 2.048 MS/s, /64, 50 baud 7N2, spectrum +
 AFC every call ("cfg4" in SURVEY.md's 1-based numbering) -- the batched 2.048 MS/s configuration that exists at
 1/2/4/8 GPUs, sharded 1024 streams per GPU (weak scaling).  Each stream carries its own CRC-valid telemetry
@@ -295,7 +299,7 @@ class Shard:
         self.t_end = time.perf_counter()
 
 
-def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync, cpu_leg, threads=0):
+def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync, cpu_leg, threads=0, prewarm=None):
     """Time K steps of one workload (after W warm-up steps) and describe the result; rank 0 gets the full dictionary.
     cpu_leg: "full" = the CPU baseline (oracle timed on the host cores) + the self-check; "check" = the self-check alone (a few streams through
     the oracle, compared with the engine's output: every line carries it); threads = N > 0: one process, a Shard + host thread per device."""
@@ -322,6 +326,12 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     sh = shards[0]
     eng, ring, ring_chunks, texts = sh.eng, sh.ring, sh.ring_chunks, sh.texts
     K = K or ring_chunks
+    # Untimed steps in front of the W warm-up steps -- by default one pass over the ring.  The step loop needs its first ~150 launches (20 ms) to reach the
+    # rate it then sustains: 20 timed steps take 0.156-0.162 ms each behind 5 warm-up steps, 0.154-0.161 behind 40, 0.142-0.145 behind 150, 0.136-0.142
+    # behind 500 (one box, tools/micro/ab_step.py) -- whichever slabs they read, and a busy GPU beforehand does not replace them.  The
+    # driver's command (--warmup 5, 20 steps = 3 ms) would otherwise time nothing but that ramp.  The self-check covers these steps too.
+    P = min(ring_chunks, 256) if prewarm is None else max(0, int(prewarm))
+    Wt = P + W
     base = sh.base
 
     def barrier():
@@ -331,15 +341,15 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
             torch.cuda.synchronize(x.dev)
 
     for x in shards:
-        x.warm(W)
+        x.warm(Wt)
     barrier()
     t0 = time.perf_counter()
     if threads > 1:
-        th = [threading.Thread(target=x.timed, args=(W, K, 3)) for x in shards]
+        th = [threading.Thread(target=x.timed, args=(Wt, K, 3)) for x in shards]
         for t in th: t.start()
         for t in th: t.join()
     else:
-        sh.timed(W, K)
+        sh.timed(Wt, K)
     barrier()
     dt = time.perf_counter() - t0
     if threads > 1:
@@ -388,6 +398,7 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     valu = w["D"] == 4                                      # configs[2]: the FIR chain's multiply-adds bind, not HBM
     tflops = value / world * 1e6 * flops_per_sample(w) / 1e12
     res = {
+        "prewarm_steps": P,
         "value": round(value, 1), "ms_per_step": round(dt / K * 1e3, 4), "steps": K, "S": S, "C": C, "ring_chunks": ring_chunks, "w": w,
         "timed_region_ms": round(dt * 1e3, 2),
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -438,13 +449,14 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
                            "frac_of_measured_copy_peak": round(iso_bw / HBM_COPY_GBS, 4),
                            "note": "stage 1 alone: synchronous calls (nothing else on the GPU), 24 launches after the timed region"}
     res["box"] = box_identity(torch, dev)
-    chunks = [i % ring_chunks for i in range(W + K)]
+    chunks = [i % ring_chunks for i in range(Wt + K)]           # what the engine consumed: pre-warm + warm-up + timed steps (the self-check follows all of it)
+    chunks_cpu = [i % ring_chunks for i in range(W + K)]       # the CPU baseline's bounded sample of the same workload
     if cpu_leg == "full":
         nproc = os.cpu_count() or 1
         nthreads = int(min(nproc, S))
         nuse = min(ring_chunks, W + K)                         # (the chunks the run touched: no need to bring the whole ring over)
         host_iq = [ring[:nuse, s].cpu().numpy().view(np.complex64).reshape(-1) for s in range(nthreads)]
-        v, c, sample, calib = cpu_baseline(w, host_iq, chunks, C)
+        v, c, sample, calib = cpu_baseline(w, host_iq, chunks_cpu, C)
         del host_iq
         res["cpu_baseline"] = {"value": round(v, 1), "unit": "MS/s", "cores": min(c, physical_cores() or c), "threads": c, "nproc": nproc,
                                "physical_cores": physical_cores(), "kind": "port", "sample": sample,
@@ -465,6 +477,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="timed steps (default: one pass over the HBM-resident ring)")
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--prewarm", type=int, default=None, help="untimed steps in front of the warm-up steps (default: one pass over the ring, at most 256; 0 = none)")
     ap.add_argument("--workload", default="cfg4", choices=list(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -495,7 +508,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     r = run_workload(torch, dist, dev, rank, local_rank, world, args.workload, args.steps, args.warmup, args.streams, args.sync,
-                     cpu_leg="check" if args.no_cpu_baseline else "full", threads=threads)
+                     cpu_leg="check" if args.no_cpu_baseline else "full", threads=threads, prewarm=args.prewarm)
     if threads:
         world = threads
     also = None
@@ -517,6 +530,8 @@ def main():
         "config": {"workload": f"{args.workload}: {w['desc']}", "streams_per_gpu": r["S"], "chunk_samples": r["C"], "ring_chunks": r["ring_chunks"],
                    "sharding": f"{r['S']} independent streams per GPU, no data-path collective"},
         "timed_region_ms": r["timed_region_ms"],
+        "prewarm_steps": r["prewarm_steps"],
+        "prewarm_note": "untimed steps of the same loop in front of the --warmup steps (one pass over the ring): the loop's first ~150 launches run 10 % below the rate it sustains (DESIGN.md section 6); --prewarm 0 times that ramp instead",
         "roofline": r["roofline"], "pipeline": r["pipeline"], "box": r.get("box"),
     }
     if threads:

@@ -549,8 +549,12 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
             unsigned int won = 1u;
             if (lane == 0) won = atomicCAS(&g_ring_fault_fired, 0u, 1u);
             if ((unsigned int)__builtin_amdgcn_readfirstlane((int)won) == 0u) {
-                while (__hip_atomic_load(&ctl->pub_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < g + 17u &&
-                       __hip_atomic_load(&ctl->live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(8);
+                for (;;) {                                   // (until the word itself carries a later publication: the counter runs ahead of the store)
+                    const unsigned long long w_ = __hip_atomic_load(&ctl->pub[g & 15u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (w_ != ~0ull && (int32_t)((((uint32_t)(w_ >> 40)) - g) << 8) > 0) break;
+                    if (__hip_atomic_load(&ctl->live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
             }
         }
 #endif

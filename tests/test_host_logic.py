@@ -81,6 +81,33 @@ def test_rtty_framing_matches_oracle(L, O, nbits, nstops):
     L.hd_host_rtty_free(h)
 
 
+@pytest.mark.parametrize("nbits,nstops", [(7, 2), (8, 1), (8, 1.5)])
+def test_rtty_framer_forgets_what_can_never_frame(L, O, nbits, nstops):
+    """Long stretches that never frame (one level for thousands of bits, a start bit whose stop bit never comes) in front of, between and behind real
+    characters, pushed one to a few bits at a time: the bytes are the reference's, although the framer keeps only the bits that can still start a frame
+    (the reference keeps every unframed bit for ever and scans them all on every push)."""
+    r = np.random.default_rng(int(nbits * 7 + nstops * 3))
+    chars = synth.rtty_bits("$$IDLE,4,2*1F2E\n", nbits, int(np.ceil(nstops)), 0, 0)
+    ones, zeros = np.ones(3000, np.uint8), np.zeros(2500, np.uint8)
+    broken = np.tile(np.concatenate([[0], r.integers(0, 2, nbits), [0, 0]]).astype(np.uint8), 150)       # start bits whose stop bits are wrong
+    bits = np.concatenate([ones, chars, zeros, chars[:-2], broken, ones[:777], chars, r.integers(0, 2, 1500).astype(np.uint8), zeros[:40], chars])
+    ro = O.rtty(nbits, nstops)
+    h = L.hd_host_rtty_new(nbits, nstops)
+    pos, out_ref, out_got = 0, b"", b""
+    while pos < len(bits):
+        step = int(r.integers(1, 12))
+        chunk = bits[pos:pos + step]
+        pos += step
+        ro.push(chunk)
+        want = ro.run()
+        buf = C.create_string_buffer(1 << 12)
+        n = L.hd_host_rtty_push_run(h, np.ascontiguousarray(chunk), len(chunk), buf, len(buf))
+        assert buf.raw[:n] == want, pos
+        out_ref += bytes(want); out_got += buf.raw[:n]
+    assert out_got == out_ref and out_got.count(b"IDLE") >= 2
+    L.hd_host_rtty_free(h)
+
+
 def _extract(L, s):
     b = s.encode("latin-1")
     cap = len(b) + 1
@@ -166,6 +193,66 @@ def test_text_stage_matches_oracle_text_rules(L, O):
     assert [x for x in get(2).split("\n") if x] == ok and len(ok) >= 30
     assert [x for x in get(3).split("\n") if x] == matches and len(matches) > len(ok)
     assert get(4) == chars
+    L.hd_host_text_free(h)
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_text_stage_on_noise_with_sentences_arriving_a_character_at_a_time(L, O, seed):
+    """The text stage scans its stream only when the new characters can have completed a sentence (a terminator and four word characters, or the '*' the
+    reference insists on): same text, sentences and logs as the reference's scan-after-every-push, on mostly-noise input rich in '$', ',' and '*', with
+    sentences (good and bad CRC, '$'-terminated ones waiting for a '*') embedded, pushed a few bits at a time."""
+    r = np.random.default_rng(seed)
+    alphabet = np.frombuffer(b"$$$,,,**ABCDEFabcdef0123456789_- \n;:!?", dtype=np.uint8)
+    pieces = []
+    for i in range(60):
+        noise = bytes(r.choice(alphabet, int(r.integers(0, 90)))).decode("latin-1")
+        kind = int(r.integers(0, 5))
+        if kind == 0: sent = synth.make_sentence("NOISY", f"{i},1.{i},2.{i}")
+        elif kind == 1: sent = "$$BAD,%d,9*12AB\n" % i
+        elif kind == 2: sent = "$$DOLLAR,%d,7$ABCD" % i            # terminator '$': matches only once a '*' is somewhere in the stream
+        elif kind == 3: sent = "$,*,$" * int(r.integers(1, 4))
+        else: sent = ""
+        pieces.append(noise + sent)
+    text = "".join(pieces)
+    bits = synth.rtty_bits(text, 8, 2, 0, 0)
+    h = L.hd_host_text_new(8, 2.0)
+    ro = O.rtty(8, 2)
+    stream, last, ok, matches, chars = "", "", [], [], ""
+    pos = 0
+    while pos < len(bits):
+        step = int(r.integers(1, 30))
+        chunk = np.ascontiguousarray(bits[pos:pos + step])
+        pos += step
+        L.hd_host_text_push_bits(h, chunk, len(chunk))
+        ro.push(chunk)
+        raw = ro.run()
+        if not raw:
+            continue
+        printable = "".join(chr(c) for c in raw if 0x20 <= c <= 0x7e or c == 0x0a)
+        stream += printable
+        chars += printable
+        if len(stream) > 20:
+            while True:
+                m = O.extract_sentence(stream)
+                if m is None:
+                    break
+                stream = m["stream"]
+                last = m["callsign"] + "," + m["data"] + "*" + m["crc"]
+                matches.append(last)
+                if m["crc"] == O.crc16(m["callsign"] + "," + m["data"]):
+                    ok.append(last)
+        if len(stream) > 1000:
+            k = stream.rfind("$")
+            stream = "" if k < 0 else stream[k:]
+
+    def get(which):
+        buf = C.create_string_buffer(1 << 20)
+        n = L.hd_host_text_get(h, which, buf, len(buf))
+        return buf.raw[:n].decode("latin-1")
+    assert get(4) == chars and len(chars) > 2000
+    assert [x for x in get(3).split("\n") if x] == matches and len(matches) >= 8
+    assert [x for x in get(2).split("\n") if x] == ok and len(ok) >= 2
+    assert get(0) == stream and get(1) == last
     L.hd_host_text_free(h)
 
 
