@@ -10,10 +10,10 @@ d=$(for x in /sys/class/drm/card*/device; do grep -q "PCI_SLOT_NAME=$bus" $x/uev
 h=$(ls -d $d/hwmon/hwmon* | head -1)
 series() { # $1 = seconds
   for i in $(seq 1 $(( $1 * 2 ))); do printf "%s/%s " $(( $(cat $h/freq1_input)/1000000 )) $(( $(cat $h/power1_average 2>/dev/null || cat $h/power1_input)/1000000 )); sleep 0.5; done; echo; }
-for args in "--steps 80000" "--sync --steps 40000" "--workload cfg3 --steps 16000" "--workload cfg2 --steps 40000"; do
+for args in "--steps 40000" "--sync --steps 20000" "--workload cfg3 --steps 8000" "--workload cfg2 --steps 20000"; do
   echo "== bench.py $args : sclk MHz / power W every 0.5 s"
-  (timeout 110 python3 bench.py $args --warmup 5 --no-cpu-baseline --no-also > /tmp/o.json 2>/dev/null) &
-  series 42
+  (timeout 170 python3 bench.py $args --warmup 5 --no-cpu-baseline --no-also > /tmp/o.json 2>/dev/null) &
+  series 30
   wait
   python3 -c "
 import json; d=json.loads(open('/tmp/o.json').read().strip().splitlines()[-1]); print('  ->', d['value'], d['ms_per_step'])"
