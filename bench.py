@@ -13,7 +13,7 @@ calls are undelivered and each call's text is delivered, in order, while the nex
 inside the timed region (hd_flush before the closing barrier).  --sync delivers every step's text before the next step
 starts, like Decoder::operator().  Metric: input complex samples consumed per second over all GPUs (IQ Msamples/s).
 
-In front of the W warm-up steps the loop runs --prewarm untimed steps of itself (default: one pass over the ring): its first
+In front of the W warm-up steps the loop runs --prewarm untimed steps of itself (default: whole passes over the ring, at least 120 steps): its first
 ~150 launches run about 10 % below the rate it then sustains, whatever kept the GPU busy before, and the driver's timed
 region is 20 steps long.  The line says so (`prewarm_steps`); --prewarm 0 gives the old behaviour.
 
@@ -330,7 +330,7 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     # rate it then sustains: 20 timed steps take 0.156-0.162 ms each behind 5 warm-up steps, 0.154-0.161 behind 40, 0.142-0.145 behind 150, 0.136-0.142
     # behind 500 (one box, tools/micro/ab_step.py) -- whichever slabs they read, and a busy GPU beforehand does not replace them.  The
     # driver's command (--warmup 5, 20 steps = 3 ms) would otherwise time nothing but that ramp.  The self-check covers these steps too.
-    P = min(ring_chunks, 256) if prewarm is None else max(0, int(prewarm))
+    P = min(ring_chunks * -(-120 // ring_chunks), 512) if prewarm is None else max(0, int(prewarm))     # (whole passes over the ring, at least 120 steps)
     Wt = P + W
     base = sh.base
 
@@ -477,7 +477,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="timed steps (default: one pass over the HBM-resident ring)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--prewarm", type=int, default=None, help="untimed steps in front of the warm-up steps (default: one pass over the ring, at most 256; 0 = none)")
+    ap.add_argument("--prewarm", type=int, default=None, help="untimed steps in front of the warm-up steps (default: whole passes over the ring, at least 120 steps; 0 = none)")
     ap.add_argument("--workload", default="cfg4", choices=list(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -531,7 +531,7 @@ def main():
                    "sharding": f"{r['S']} independent streams per GPU, no data-path collective"},
         "timed_region_ms": r["timed_region_ms"],
         "prewarm_steps": r["prewarm_steps"],
-        "prewarm_note": "untimed steps of the same loop in front of the --warmup steps (one pass over the ring): the loop's first ~150 launches run 10 % below the rate it sustains (DESIGN.md section 6); --prewarm 0 times that ramp instead",
+        "prewarm_note": "untimed steps of the same loop in front of the --warmup steps (whole passes over the ring, at least 120 steps): the loop's first ~150 launches run 10 % below the rate it sustains (DESIGN.md section 6); --prewarm 0 times that ramp instead",
         "roofline": r["roofline"], "pipeline": r["pipeline"], "box": r.get("box"),
     }
     if threads:
