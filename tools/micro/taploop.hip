@@ -6,6 +6,9 @@
 //   MODE 1: taps from an LDS table with broadcast ds_read_b128 (in-order returns: counted waits), same chunking
 //   MODE 2: MODE 1 on two tiles at once (two independent sums per lane, 2 x 18 KB of LDS)
 //   MODE 3: MODE 0 with the sixteen-tap chunk scheduled by hand (ring_mac16_asm of stage1_ring.h): products three taps ahead of the adds
+//   MODE 4: the SYSTOLIC loop (round 4's candidate for round 5): a lane reads only ITS row (16 x 16 bytes instead of 106), the accumulators travel -- output o
+//           starts in lane o and after the taps that fall on row o + r moves to the next lane with one DPP rotate per component; same products in the same
+//           order.  (Timing only here: the wrap at lane 63 is not handled -- a real version computes 57 outputs per 64 rows.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -129,6 +132,35 @@ __global__ __launch_bounds__(64) void k(unsigned long long* out, float2* res, co
             mac16_asm(acc, xb, kb);
             acc = acc + xa[0].xy * ka[0].x;
             total = total + acc;
+        } else if constexpr (MODE == 4) {
+            f32x2 acc = {0.f, 0.f};
+            f32x4 xa[8], xb[8]; f32x2 ka[8], kb[8], na[8], nb[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { xa[q] = *reinterpret_cast<const f32x4*>(p + 16 * q); xb[q] = *reinterpret_cast<const f32x4*>(p + 128 + 16 * q); }
+            auto ld = [&](f32x2 (&kk)[8], int c) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { kk[j].x = taps[c * 16 + 2 * j]; kk[j].y = taps[c * 16 + 2 * j + 1]; }
+            };
+            auto rot = [&]() {                                      // lane l takes lane l-1's accumulator (wave_ror:1)
+                acc.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc.x), 0x13C, 0xF, 0xF, false));
+                acc.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc.y), 0x13C, 0xF, 0xF, false));
+            };
+            ld(ka, 0); ld(kb, 1);
+            acc = acc + xa[6].zw * ka[6].y; acc = acc + xa[7].xy * ka[7].x; acc = acc + xa[7].zw * ka[7].y;      // step 0: slots 13..15 of chunk 0
+            ld(na, 2); ld(nb, 3);
+            mac16_asm(acc, xb, kb);
+            rot();
+#pragma unroll
+            for (int r = 1; r <= 6; ++r) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { ka[j] = na[j]; kb[j] = nb[j]; }
+                if (r < 6) { ld(na, 2 * r + 2); ld(nb, 2 * r + 3); } else ld(na, 14);
+                mac16_asm(acc, xa, ka);
+                mac16_asm(acc, xb, kb);
+                rot();
+            }
+            acc = acc + xa[0].xy * na[0].x;                         // step 7: slot 224
+            total = total + acc;
         } else if constexpr (MODE == 1) {
             f32x2 acc = {0.f, 0.f};
             f32x4 xa[8], xb[8]; f32x4 ka[4], kb[4];
@@ -220,5 +252,6 @@ int main()
     run<1>("taps via LDS broadcast", d_taps);
     run<2>("LDS taps, two tiles per wave", d_taps);
     run<3>("s_load taps, hand-scheduled", d_taps);
+    run<4>("systolic (own row only)", d_taps);
     return 0;
 }
