@@ -963,8 +963,8 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     auto make_claim = [&](uint32_t lin_wgs /* stage 1 as a launch of its own: the workgroup count of its linear split (which needs four tiles per workgroup); 0 = step launch */,
                           uint32_t run_len_cu = 0 /* != 0: runs for a per-CU ring kernel's loaders */) {
         hd::StepClaim claim{};
-        // (tiles: 64 outputs of a single-wave /32 or /64 first stage; 2048 input samples -- 64 lanes x one row of 32 -- for the per-CU ring kernels)
-        const uint32_t ntiles = run_len_cu ? max_in / 2048u : (max_n1 + 63) / 64, n_xcd = e->n_cus / 32u, run_len = run_len_cu ? run_len_cu : e->step_run >= 2 ? e->step_run : 4u;   // (a run must hold the tile in front of which the next draw is issued: at least two; four re-read fewer halos than two)
+        // (tiles: 64 outputs of a single-wave /32 or /64 first stage; for the per-CU ring kernels hd::ring_tiles -- 64 rows of 32 samples advancing by 57 or 58 at /32, 2048 input samples at the smaller ratios)
+        const uint32_t ntiles = run_len_cu ? hd::ring_tiles((int)R1, (int)T1, max_in) : (max_n1 + 63) / 64, n_xcd = e->n_cus / 32u, run_len = run_len_cu ? run_len_cu : e->step_run >= 2 ? e->step_run : 4u;   // (a run must hold the tile in front of which the next draw is issued: at least two; four re-read fewer halos than two)
         const uint64_t runs = (uint64_t)S * ntiles / run_len;
         const bool shape_ok = run_len_cu ? (hd::stage1_cu_supported((int)R1, (int)T1) && max_in % 2048u == 0) : ((R1 == 32 || R1 == 64) && max_n1 % 64 == 0);
         if (!e->no_claim && (nst == 2 || (run_len_cu && nst == 1)) && shape_ok && min_in == max_in && max_in && !any_zero1 && n_xcd && e->n_cus % 32u == 0 && n_xcd <= 16 &&
@@ -975,6 +975,19 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             ++e->step_launches;
         }
         return claim;
+    };
+    // Tiles per drawn run of a per-CU ring kernel's loaders: consecutive tiles of one stream (the rows neighbouring tiles share are re-read from the
+    // XCD's L2), so it must divide the stream's tile count, and the launch's runs must divide among the XCDs.  Eight measured best among 4 / 8 / 16
+    // (round 4); the nearest usable length to that, the longer one first (36 systolic tiles per 65536-sample push: nine).
+    auto pick_ring_run = [&](const uint32_t ntiles) -> uint32_t {
+        const uint32_t n_xcd = e->n_cus / 32u ? e->n_cus / 32u : 1u;
+        auto ok = [&](uint32_t r) { return r >= 2u && r <= ntiles && ntiles % r == 0 && ((uint64_t)S * ntiles / r) % n_xcd == 0; };
+        if (e->ring_run >= 2 && ok(e->ring_run)) return e->ring_run;
+        for (uint32_t d = 0; d <= 6u; ++d) {
+            if (ok(8u + d)) return 8u + d;
+            if (d && d < 7u && ok(8u - d)) return 8u - d;
+        }
+        return 2u;                                     // (k_step treats shorter runs as "not drawn" while the counter sets have already alternated; make_claim refuses what does not divide)
     };
     if (step) {
         // One launch: [tails of the previous call | this call's stage 1].  Stage 1 reads its parameters from the mapped host block and
@@ -998,10 +1011,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         uint32_t wgs = e->step_wgs ? e->step_wgs : 32u * e->n_cus;   // short runs of tiles: the dispatcher evens out the tail of the launch
         // One workgroup per CU (loader + consumer waves for stage 1, the tails in the other four waves) where the plan and the sizes allow it
         const uint32_t cu_tail = hd::step_cu_tail_lds((int)R1, (int)T1);
-        const uint32_t ntiles1 = (max_n1 + 63) / 64;
-        uint32_t ring_run = e->ring_run >= 2 ? e->ring_run : 8u;
-        while (ring_run > 2 && (ntiles1 % ring_run || ((uint64_t)S * ntiles1 / ring_run) % (e->n_cus / 32u ? e->n_cus / 32u : 1u))) ring_run >>= 1;
-        if (ring_run < 2u) ring_run = 2u;                      // (k_step treats shorter runs as "not drawn" while the counter sets have already alternated)
+        const uint32_t ring_run = pick_ring_run(hd::ring_tiles((int)R1, (int)T1, max_in));
         static const int cu_exp0 = getenv("HD_CU_EXP") ? atoi(getenv("HD_CU_EXP")) : 0;
         const bool want_cu = cu_shape && cu_tail && ((cu_exp0 & 1) || (ta_step.lds_bytes <= cu_tail &&
                              (!prev.valid || prev.ta.lds_bytes <= cu_tail)));
@@ -1026,11 +1036,17 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             e->last_timing.step_variant = launched ? 1u : 0u;
         }
         else if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
-        if (!launched)
-        if (!hd::launch_step(qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, max_n1, iq, stride, e->hist1[hin].p,
-                             e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, wgs, prev.ta, prev.valid ? S : 0u,
-                             any_zero1 ? 0u : max_in, claim))
-            return fail(HD_ERR_INVALID, "no step kernel for this decimation plan");
+        if (!launched) {
+            hd::StepClaim fb = claim;
+            if (want_cu && claim.ctr) {                        // (runs cut for the ring kernel's tiles are not k_step's: fixed shares, and the counter set was not drawn from)
+                --e->step_launches; fb = hd::StepClaim{};
+                if (!e->step_wgs) wgs = 32u * e->n_cus;
+            }
+            if (!hd::launch_step(qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, max_n1, iq, stride, e->hist1[hin].p,
+                                 e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, wgs, prev.ta, prev.valid ? S : 0u,
+                                 any_zero1 ? 0u : max_in, fb))
+                return fail(HD_ERR_INVALID, "no step kernel for this decimation plan");
+        }
         if (sl.timed && !ev_on_dispatch) HD_HIP(hipEventRecord(sl.t2, qa));
         if (ps) {
             if (!prev.ta.fft_tw) { if (const int r = run_spectrum(e, qa, *ps, prev.any_fft)) return r; }
@@ -1075,10 +1091,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         // A /32 first stage over equally sized pushes: one workgroup per CU, LDS-DMA loader waves + computing waves (k_stage1_cu, stage1_ring.h)
         bool s1_cu = false;
         if ((single ? R1 == 4 : R1 != 4) && min_in == max_in && max_in && !e->no_cu_step && !any_zero1 && max_in % 2048u == 0 && hd::stage1_cu_supported((int)R1, (int)T1)) {
-            const uint32_t ntiles1 = max_in / 2048u;
-            uint32_t ring_run = e->ring_run >= 2 ? e->ring_run : 8u;
-            while (ring_run > 2 && (ntiles1 % ring_run || ((uint64_t)S * ntiles1 / ring_run) % (e->n_cus / 32u ? e->n_cus / 32u : 1u))) ring_run >>= 1;
-            const hd::StepClaim cl = make_claim(0, ring_run);
+            const hd::StepClaim cl = make_claim(0, pick_ring_run(hd::ring_tiles((int)R1, (int)T1, max_in)));
             if (cl.ctr) {
                 if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
                 s1_cu = hd::launch_stage1_cu(qa, (int)R1, (int)T1, e->n_cus, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,

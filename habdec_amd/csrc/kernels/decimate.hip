@@ -725,7 +725,7 @@ __global__ __launch_bounds__(D == 8 ? 512 : 1024) void k_stage1_cu(const RingArg
     }
     const RingGeom geom{ring, n_slots, nullptr, 0u, 0u, 0u};
     const uint32_t h0 = n_slots / 2u;                                    // two loaders: [0, h0) and [h0, n_slots)
-    if (w < n_loaders) ring_loader<T>(ra, geom, ctl, (n_loaders == 1u || w == 0u) ? 0u : h0, n_loaders == 1u ? n_slots : (w == 0u ? h0 : n_slots - h0), w);
+    if (w < n_loaders) ring_loader<T, D == 32 && kRingSystolic>(ra, geom, ctl, (n_loaders == 1u || w == 0u) ? 0u : h0, n_loaders == 1u ? n_slots : (w == 0u ? h0 : n_slots - h0), w);
     else ring_consumer<T, D>(ra, geom, ctl, w == 2, w);
 }
 
@@ -846,11 +846,20 @@ bool launch_step(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, u
     return false;
 }
 
-// what a publication word of the ring protocol can name (stage1_ring.h, RingCtl::pub): 24 bits of sequence number, 20 of stream, 12 of tile
-static bool ring_limits_ok(uint32_t uniform_n, const StepClaim& claim)
+// Tiles per stream and call of the per-CU ring kernels: a /32 stage runs the systolic tap loop, whose 64-row tiles advance by 64 - HR rows
+// (stage1_ring.h: ring_adv); the smaller ratios keep tiles of 64 rows + halo, 2048 input samples each.
+uint32_t ring_tiles(int ratio, int ntaps, uint32_t n)
 {
-    const uint64_t ntiles = uniform_n / 2048u, total = (uint64_t)claim.runs_per_xcd * claim.n_xcd * claim.run_len;
-    return ntiles && ntiles <= 4096u && total < (1ull << 24) && total / ntiles <= (1ull << 20);
+    if (ratio != 32 || !kRingSystolic) return n / 2048u;
+    const uint32_t adv = 64u - (uint32_t)((ntaps - 1 + 31) / 32);
+    return n / 32u >= 64u ? ring_sys_tiles(n, adv) : 0u;
+}
+
+// what a publication word of the ring protocol can name (stage1_ring.h, RingCtl::pub): 24 bits of sequence number, 20 of stream, 12 of tile
+static bool ring_limits_ok(uint32_t ntiles, const StepClaim& claim)
+{
+    const uint64_t total = (uint64_t)claim.runs_per_xcd * claim.n_xcd * claim.run_len;
+    return ntiles && ntiles <= 4096u && claim.run_len && ntiles % claim.run_len == 0 && total < (1ull << 24) && total / ntiles <= (1ull << 20);
 }
 
 uint32_t step_cu_tail_lds(int ratio, int ntaps, uint32_t n_slots)
@@ -871,8 +880,9 @@ bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2
     if (n_slots != 5u || n_loaders != 1u) n_slots = 2u * (uint32_t)kRingNSL;
     if (!n_tail && n_loaders == 1u && n_slots == 5u) n_slots = 8u;          // a launch without tails (the first after a flush): the whole CU's LDS is tile slots
     if (ratio != 32 || !claim.ctr || !uniform_n || uniform_n % 2048u) return false;
-    if (!ring_limits_ok(uniform_n, claim)) return false;
-    RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, uniform_n / 2048u, claim, gave_up, nullptr, 0u, nullptr};
+    const uint32_t ntiles = ring_tiles(ratio, ntaps, uniform_n);
+    if (!ring_limits_ok(ntiles, claim)) return false;
+    RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, ntiles, claim, gave_up, nullptr, 0u, nullptr};
 #define HD_CU_CASE(T, D2, T2)                                                                                                         \
     if (ntaps == T && ratio2 == D2 && ntaps2 == T2) {                                                                                 \
         const uint32_t lds = n_slots * (uint32_t)ring_slot_bytes<T>() + (uint32_t)kRingCtlBytes + (n_tail ? 4u * tail_bytes : 0u);        \
@@ -918,9 +928,10 @@ bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, cons
     if (n_slots < 2u * n_loaders || n_slots > 8u) n_slots = 8u;
     if (n_waves < 8u || n_waves > 16u) n_waves = 8u;
     if (!claim.ctr || !uniform_n || uniform_n % 2048u) return false;
-    if (!ring_limits_ok(uniform_n, claim)) return false;
+    const uint32_t ntiles = ring_tiles(ratio, ntaps, uniform_n);
+    if (!ring_limits_ok(ntiles, claim)) return false;
     if ((ratio <= 4) != (final_call != nullptr)) return false;               // /4 exists as a FINAL stage only (the only stage of a plan), the others as first stages only
-    RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, uniform_n / 2048u, claim, gave_up, final_call, fir_hist_cap, fft_in};
+    RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, ntiles, claim, gave_up, final_call, fir_hist_cap, fft_in};
 #define HD_S1_CASE(D, T)                                                                                                              \
     if (ratio == D && ntaps == T) {                                                                                                   \
         static_assert((uint32_t)ring_bytes<T, kRingNSLAlone>() <= 163840u, "eight tile slots must fit a CU's LDS");                   \

@@ -117,6 +117,7 @@ bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2
                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr /* signalled by the dispatch itself (hipExtLaunchKernel), not by a packet behind it */);
 // Stage 1 alone in the same shape (eight tile slots, one loader wave and seven computing waves by default): a /32 or /8 first stage, equally sized pushes that are a multiple of 2048
 // samples, drawn runs, no history restart; false otherwise (the caller then launches k_decimate).  The call's parameter block is not copied.
+uint32_t ring_tiles(int ratio, int ntaps, uint32_t n);   // tiles per stream and call of the per-CU ring kernels for n input samples (0: none); the drawn runs must divide it
 bool step_cu_supported(int ratio, int ntaps, int ratio2, int ntaps2);   // plans k_step_cu is instantiated for: /64 (/32 212 + /2 69), /128 (/32 174 + /4 139)
 bool stage1_cu_supported(int ratio, int ntaps);   // stages k_stage1_cu exists for: /32 (212, 174 taps), /8 (54 taps) as first stages; /4 (139 taps) as the only stage of a plan
 bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, const float2* in, size_t in_stride, const float2* hist_in, float2* hist_out,

@@ -22,18 +22,21 @@
 // first output's stride) are two more -- or, for a stream's first tile, HR dword-wide LDS-DMA rows out of the stage history, whose
 // samples sit at odd 8-byte offsets.
 //
-// Protocol (LDS words, RingCtl).  A loader owns a range of tile slots.  It puts its next tile into any of them that is free (never used, or
-// slot_done counts as many finished tiles as the loader has put there; a slot inside a tail's LDS slice only once that tail is done), issues the
-// DMA, and -- when IB_STS.VM_CNT shows the tile has arrived -- PUBLISHES it: it draws the next global sequence number g from pub_tail and stores
-// the 64-bit word (g, slot, stream, tile) into pub[g & 15].  Consumers draw g = taken++, sleep until pub[g & 15] carries the tag g -- the word is
-// the whole descriptor: no second LDS round trip between waking up and the first sample read -- compute, and add one to slot_done.  One
-// publication order for all loaders: how many loader waves there are, and when they join, is nobody else's business -- stage 1 alone runs two from
-// the start, a step launch starts with one and the first stream tail that finishes becomes the second (round 4: one loader's 6-bit vmcnt holds
-// three tiles' DMA instructions, and three tiles in flight per CU are what bounded a launch once the tails were out of the way).  `live` counts
-// the loaders that may still publish: a consumer whose sequence number is not published and sees live == 0 is done.  Runs of tiles come from the
-// per-XCD counters of the step launches (StepClaim, launch.h): the feeding consumer draws them -- a returning atomic, which a wave without DMA in
-// flight can simply wait for -- and hands them to the loaders through run_q, "no more" sentinels included, for as long as it lives.  No s_barrier
-// after the start: the stream tails in the workgroup's other waves never take part; every wait is bounded and reported (RingArgs::gave_up).
+// Protocol (LDS words, RingCtl; round 5's version).  Every tile slot has ONE 64-bit word: (state, descriptor).  A loader owns a range of slots.  It puts
+// its next tile into any of them whose word says FREE (a slot inside a tail's LDS slice only once that tail is done), issues the DMA, and -- when
+// IB_STS.VM_CNT shows the tile has arrived -- stores (READY, stream, tile) into the slot's word: a plain store, nothing to wait for.  A computing wave reads
+// all slot words at once (lane j reads word j), picks a READY one and takes it with ONE compare-and-swap of the whole word (READY, descriptor) -> TAKEN:
+// whoever wins has the descriptor already; whoever loses looks again.  When its lanes' rows are in registers it stores FREE.  A word is written by the
+// slot's loader (FREE -> READY), by the one consumer whose swap succeeded (READY -> TAKEN -> FREE) and by nobody else, so there is no publication queue to
+// overflow and nothing to acknowledge (rounds 3-4 published through a sixteen-entry queue of sequence numbers: a loader paid two returning LDS atomics per
+// tile for it -- in-kernel clocks: a lone loader wave spent its whole launch in that chain and the computing waves waited 40 % of theirs -- and a
+// consumer that did not look for sixteen publications could find its word overwritten).  How many loader waves there are, and when they
+// join, is nobody else's business -- stage 1 alone runs two from the start, a step launch starts with one and the first stream tail that finishes becomes
+// the second (one loader's 6-bit vmcnt holds three tiles' DMA instructions).  `live` counts the loaders that may still publish: a consumer that finds
+// no READY word and sees live == 0 is done.  Runs of tiles come from the per-XCD counters of the step launches (StepClaim, launch.h): the feeding consumer
+// draws them -- a returning atomic, which a wave without DMA in flight can simply wait for -- and hands them to the loaders through run_q, "no more"
+// sentinels included, for as long as it lives.  No s_barrier after the start: the stream tails in the workgroup's other waves never take part; every
+// wait is bounded and reported (RingArgs::gave_up).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -55,6 +58,18 @@ constexpr uint32_t kRingSpinLimit = 1u << 22;   // polls before a waiting wave g
 template <int T> constexpr int ring_halo_rows() { return (T - 1 + 31) / 32; }
 template <int T> constexpr int ring_slot_bytes() { return (64 + ring_halo_rows<T>()) * kRingRowBytes; }
 template <int T, int NSL = kRingNSL> constexpr int ring_bytes() { return 2 * NSL * ring_slot_bytes<T>() + kRingCtlBytes; }   // NSL ring slots per loader
+// The /32 stages run the SYSTOLIC tap loop (ring_consumer): a lane keeps only ITS row of 32 samples in registers and the accumulators travel from
+// lane to lane, so the 64 rows of a tile yield 64 - HR outputs (the sums that would wrap past lane 63 belong to the next tile) and consecutive
+// tiles of a stream advance by that many rows: tile k holds rows [origin, origin + 64) of the stream's history-extended row sequence (rows 0 .. HR-1
+// are the stage history), origin = min(k * ADV, R - ADV) with R = n / 32 rows in the call -- the last tile is pulled back so that it ends with the
+// call's last row and never reads past the stream's input; the outputs it shares with its neighbour are computed twice, identically.
+template <int T> constexpr int ring_adv() { return 64 - ring_halo_rows<T>(); }
+#ifdef HD_RING_CLASSIC
+constexpr bool kRingSystolic = false;
+#else
+constexpr bool kRingSystolic = true;
+#endif
+__host__ __device__ constexpr uint32_t ring_sys_tiles(uint32_t n, uint32_t adv) { return (n / 32u + adv - 1u) / adv; }
 
 #ifdef HD_STAMP_RING   // diagnostic build only (tools/micro/ring_stamps.py): where the loader and the consumers of k_step_cu spend their cycles
 __device__ unsigned long long g_ring_stamps[512 * 8 * 8];
@@ -71,43 +86,33 @@ extern "C" void hd_debug_ring_stamps(unsigned long long* host, size_t n) { (void
 
 #ifdef HD_RING_FAULT
 __device__ unsigned int g_ring_fault_fired, g_ring_fault_mode;
-// (one fault per arming.  Mode 0: a loader never publishes its second tile and stops.  Mode 1: a computing wave naps with its ticket drawn until its
-// publication word has been overwritten by a later one.)
+// (one fault per arming.  Mode 0: a loader never publishes its second tile and stops -- the computing waves' waits run out.  Mode 1: the feeding wave
+// stops handing out runs after its second -- the loaders' waits run out.)
 static void ring_fault_arm(unsigned int mode) { const unsigned int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ring_fault_mode), &mode, sizeof mode); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ring_fault_fired), &z, sizeof z); }
 extern "C" void hd_debug_ring_fault_arm() { ring_fault_arm(0u); }
-extern "C" void hd_debug_ring_fault_arm_nap() { ring_fault_arm(1u); }
+extern "C" void hd_debug_ring_fault_arm_starve() { ring_fault_arm(1u); }
 #endif
 
+constexpr uint32_t kSlotFree = 0u, kSlotReady = 1u, kSlotTaken = 2u;     // state (high word) of a tile slot's word
 struct RingCtl {
-    uint32_t pub_tail;      // tiles published so far = the next publication's sequence number
+    unsigned long long slot[16];   // per tile slot (global slot number, RingGeom): (state << 32) | (stream << 12) | tile.  Limits (checked by the launcher):
+                            // 2^20 streams, 4096 tiles per stream and call.  Zero = FREE.
     uint32_t live;          // loader waves that may still publish
-    uint32_t taken;         // next sequence number a consumer draws
     uint32_t run_tail;      // runs the feeding consumer has put into run_q so far
     uint32_t run_head;      // runs the loaders have claimed (fetch-add)
     uint32_t late_loader;   // step launch: finished tail waves that have asked to become the second loader (the first one does)
-    uint32_t _pad[2];
     uint32_t run_q[4];      // drawn run numbers (0xFFFFFFFF: no more)
-    uint32_t slot_done[8];  // per slot: tiles finished in it so far (free when that equals what its loader has put there)
-    unsigned long long pub[16];   // publication g: high word (g << 8) | slot, low word (stream << 12) | tile -- stored, as one 8-byte write, when tile g has
-                            // landed (tag 0xFFFFFF: nothing yet).  Sixteen entries for at most eight slots: publication g + 16 needs a free slot while the
-                            // tile of g -- whose consumer has not even read pub yet -- and everything published after it hold theirs, i.e. more than
-                            // eight.  Limits (checked by the launcher): fewer than 2^24 tiles per launch, 2^20 streams, 4096 tiles per stream and call.
     uint32_t simd_rank[4];  // waves of the workgroup that have arrived on each SIMD (role assignment, k_step_cu)
     uint32_t roles_taken;   // bit w: role w has a wave
     uint32_t tail_mask;     // bit k: tail slice k holds no tail any more (or never did): the loaders may land tiles in the extra slots that lie in it
-    uint32_t _pad2[2];
+    uint32_t _pad[2];
 };
 static_assert(sizeof(RingCtl) <= kRingCtlBytes, "ring control block");
-// first thing in the kernel, before the workgroup's first barrier: everything zero, `live` = the loaders that exist from the start, no publications
+// first thing in the kernel, before the workgroup's first barrier: everything zero (every slot FREE), `live` = the loaders that exist from the start
 __device__ __forceinline__ void ring_ctl_init(RingCtl* ctl, const uint32_t n_live)
 {
     const uint32_t i = threadIdx.x;
-    if (i < (uint32_t)kRingCtlBytes / 4u) {
-        uint32_t v = 0u;
-        if (i == (uint32_t)offsetof(RingCtl, live) / 4u) v = n_live;
-        if (i >= (uint32_t)offsetof(RingCtl, pub) / 4u && i < (uint32_t)offsetof(RingCtl, pub) / 4u + 32u) v = 0xFFFFFFFFu;
-        reinterpret_cast<uint32_t*>(ctl)[i] = v;
-    }
+    if (i < (uint32_t)kRingCtlBytes / 4u) reinterpret_cast<uint32_t*>(ctl)[i] = i == (uint32_t)offsetof(RingCtl, live) / 4u ? n_live : 0u;
 }
 
 // Where the tile slots are.  Global slot j < nb: ring + j * SLOT, the ring region proper; slot nb + i (i < ne), inside a step launch: the i-th
@@ -247,11 +252,12 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p)
 // ---------------------------------------------------------------------------------------------------------------- a loader wave
 // The calling wave has been counted in RingCtl::live (ring_ctl_init for the loaders that exist from the start; a late one counts itself in,
 // k_step_cu).  It owns the global slots [slot0, slot0 + nslots), nslots <= 8.
-template <int T>
+template <int T, bool SYS = kRingSystolic /* tiles of the systolic tap loop (the /32 stages): 64 rows advancing by ring_adv<T>() */>
 __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& geo, RingCtl* __restrict__ ctl, const uint32_t slot0, const uint32_t nslots,
                                             const uint32_t stamp_row /* diagnostic builds */)
 {
     constexpr int HR = ring_halo_rows<T>();
+    constexpr uint32_t ADV = (uint32_t)ring_adv<T>();
     constexpr int SLOT = ring_slot_bytes<T>();
     constexpr int NBODY = 17;                       // 64 rows x 17 chunks = 17 x 64 chunks
     constexpr int NHALO = (HR * 17 + 63) / 64;      // halo rows out of the stream itself (every tile but a stream's first)
@@ -289,12 +295,23 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
     uint32_t inflight_instr = 0;                    // vector-memory instructions of my tiles in flight (at most three tiles: the counter holds 63)
     unsigned long long fifo = 0, sfifo = 0;         // ... per tile, oldest in the low byte; and the slots they are going to
     const uint32_t max_fly = nslots >= 3u ? 3u : 2u;
-    uint32_t my_cnt = 0, my_desc = 0;               // lane j < nslots: tiles I have put into my slot j; (stream << 12) | tile of the one there now
+    uint32_t my_state = 0, my_desc = 0;             // lane j < nslots, my slot j: 0 = mine to fill, 1 = a tile is on its way into it, 2 = published (until its word says FREE again);
+                                                    // (stream << 12) | tile of the tile there now
     uint32_t idle_spins = 0;
     RSTAMP_DECL;
 
     for (;;) {
         RSTAMP(0);
+        // ---- one look at my slots' words (and at which tails are done, for the slots that lie in their slices): the only LDS round trip of an iteration
+        unsigned long long w = 0;
+        uint32_t tm = 0;
+        if (lane < nslots) {
+            w = __hip_atomic_load(&ctl->slot[gs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (my_need) tm = __hip_atomic_load(&ctl->tail_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        // A published slot is mine again once its consumer has stored FREE (its lanes' rows are in registers by then).  (Looked at BEFORE this iteration
+        // publishes anything: the word of a slot whose tile is still on its way says FREE too -- the loader writes nothing when it issues.)
+        if (my_state == 2u && (uint32_t)(w >> 32) == kSlotFree) my_state = 0u;
         // ---- publish what has landed, without blocking: the wave's count of outstanding vector-memory instructions is readable
         // (IB_STS.VM_CNT, low four bits in [3:0], high two in [23:22]); the oldest tile in flight has landed once no more than the
         // instructions issued after it are outstanding.
@@ -302,12 +319,8 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
             const uint32_t ib = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 7);
             const uint32_t oldest = (uint32_t)(fifo & 0xFFu), younger = inflight_instr - oldest;
             if (((ib & 15u) | (((ib >> 22) & 3u) << 4)) > younger) break;
-#ifndef HD_RING_NO_WAITCNT
             wait_vmcnt(younger);                                       // (returns at once -- the counter has said so -- but it is the instruction whose completion semantics the hand-off relies on)
-#else
-            asm volatile("" ::: "memory");
-#endif
-            const uint32_t lslot = (uint32_t)(sfifo & 0xFFu), ldesc = (uint32_t)__builtin_amdgcn_readlane((int)my_desc, (int)(lslot - slot0));
+            const uint32_t lslot = (uint32_t)(sfifo & 0xFFu) - slot0;   // my slot number
             inflight_instr -= oldest; fifo >>= 8; sfifo >>= 8;
             ++landed;
 #ifdef HD_RING_FAULT   // fault-injection build (libhabdec_amd_fault.so, tests/test_gpu_fault.py): ONE loader of the process never publishes its second tile and stops
@@ -317,10 +330,11 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
                 if ((unsigned int)__builtin_amdgcn_readfirstlane((int)won) == 0u) { RSTAMP_WRITE(stamp_row, issued); return; }   // (still counted in `live`: the consumers' waits run out)
             }
 #endif
-            uint32_t g = 0;
-            if (lane == 0) g = __hip_atomic_fetch_add(&ctl->pub_tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
-            if (lane == 0) __hip_atomic_store(&ctl->pub[g & 15u], ((unsigned long long)((g << 8) | lslot) << 32) | ldesc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // the lane that watches the slot stores its word: (READY, descriptor) -- a plain store, in order behind everything this wave has done to LDS
+            if (lane == lslot) {
+                __hip_atomic_store(&ctl->slot[gs], ((unsigned long long)kSlotReady << 32) | my_desc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                my_state = 2u;
+            }
         }
         RSTAMP(2);
         if (!have && !ended) {                                         // the current run is used up: take the next one the feeder has drawn
@@ -342,23 +356,29 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
                 }
             }
         }
+        // which of my slots can take a tile?  (a slot in the tails' slices only once those tails are done)
         unsigned long long free_mask = 0;
-        if (have && issued - landed < max_fly && inflight_instr + (uint32_t)(NBODY + (HR > NHALO ? HR : NHALO)) <= 63u) {
-            // which of my slots are free?  (never used, or its consumer has finished; a slot in the tails' slices only once those tails are done)
-            bool ok = false;
-            if (lane < nslots) {
-                const uint32_t dn = __hip_atomic_load(&ctl->slot_done[gs], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                ok = dn == my_cnt;
-                if (ok && my_need) ok = (__hip_atomic_load(&ctl->tail_mask, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & my_need) == my_need;
-            }
-            free_mask = __ballot(ok);
-        }
+        if (have && issued - landed < max_fly && inflight_instr + (uint32_t)(NBODY + (HR > NHALO ? HR : NHALO)) <= 63u)
+            free_mask = __ballot(lane < nslots && my_state == 0u && (tm & my_need) == my_need);
         if (free_mask) {
             const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(free_mask));      // my slot number; global slot slot0 + slot
             const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)my_dst, (int)slot);
-            const unsigned char* body = reinterpret_cast<const unsigned char*>(a.in + (size_t)s * a.in_stride) + (size_t)tile * (64u * 256u);
-            if (lane == slot) { ++my_cnt; my_desc = (s << 12) | tile; }
+            if (lane == slot) { my_state = 1u; my_desc = (s << 12) | tile; }
             uint32_t cnt = NBODY;
+            if constexpr (SYS) {
+                // a systolic tile is 64 consecutive rows of the stream: the stage history + the call's first rows for tile 0 (which lands HR rows
+                // deeper in the slot: the slot's last HR rows are there for that), seventeen back-to-back instructions out of the input otherwise
+                const unsigned char* in_s = reinterpret_cast<const unsigned char*>(a.in + (size_t)s * a.in_stride);
+                if (tile == 0) {
+                    glds4_rows<HR>(reinterpret_cast<const unsigned char*>(a.hist_in + (size_t)s * (T - 1)), hist_off, dst);
+                    glds16_x17(in_s, boff, dst + (uint32_t)(HR * kRingRowBytes));
+                    cnt += HR;
+                } else {
+                    const uint32_t rows = a.n / 32u, origin = tile * ADV < rows - ADV ? tile * ADV : rows - ADV;
+                    glds16_x17(in_s + (size_t)(origin - (uint32_t)HR) * 256u, boff, dst);
+                }
+            } else {
+            const unsigned char* body = reinterpret_cast<const unsigned char*>(a.in + (size_t)s * a.in_stride) + (size_t)tile * (64u * 256u);
             if (tile == 0) {
                 const unsigned char* hb = reinterpret_cast<const unsigned char*>(a.hist_in + (size_t)s * (T - 1));
                 glds4_rows<HR>(hb, hist_off, dst);
@@ -372,6 +392,7 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
                 cnt += NHALO;
             }
             glds16_x17(body, boff, dst + (uint32_t)(HR * kRingRowBytes));
+            }
             fifo |= (unsigned long long)cnt << (8u * (issued - landed));
             sfifo |= (unsigned long long)(slot0 + slot) << (8u * (issued - landed));
             inflight_instr += cnt;
@@ -505,6 +526,9 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
     // compiler counts and waits for, which a wave without DMA in flight can afford -- and keeps two of them ready in ctl->run_q.
     const bool feeding = feeder;
     uint32_t fed = 0;
+#ifdef HD_RING_FAULT
+    uint32_t starving = 0;                          // 0: not decided, 1: this is the wave that starves its loaders, 2: another one is
+#endif
     bool exhausted = false;                         // the XCD's counter has run out: from here on the loaders are fed "no more" sentinels, on demand, for
                                                     // as long as this wave lives -- and it lives until every loader has counted itself out
     const uint32_t xcd0 = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // XCC_ID
@@ -520,8 +544,13 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
             if ((int32_t)(fed - head) >= 2) break;  // two unclaimed entries are ready (entries are reused four later: a claimed one has been read long before)
             uint32_t v = 0xFFFFFFFFu;
             if (!exhausted) {
-                // (ONE returning agent-scope atomic per visit, a microsecond or two: this wave is a consumer with a ticket of its own, and the publication
-                // word it waits for is overwritten sixteen publications later -- see the check in the wait loop below)
+                // (ONE returning agent-scope atomic per visit, a microsecond or two)
+#ifdef HD_RING_FAULT   // fault mode 1: ONE feeding wave of the process stops handing out runs after its second -- its loaders starve, their bounded waits run out
+                if (fed >= 2u && g_ring_fault_mode == 1u) {
+                    if (!starving) { unsigned int won = 1u; if (lane == 0) won = atomicCAS(&g_ring_fault_fired, 0u, 1u); starving = (unsigned int)__builtin_amdgcn_readfirstlane((int)won) == 0u ? 1u : 2u; }
+                    if (starving == 1u) break;
+                }
+#endif
                 unsigned int t = 0;
                 if (lane == 0) t = __hip_atomic_fetch_add(my_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
@@ -537,56 +566,135 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
         }
     };
 
+    const uint32_t n_slots_all = geo.nb + geo.ne;   // (at most sixteen: RingCtl::slot)
+    const uint32_t look_from = (role * 5u) & 15u;   // the waves of a CU start looking at different slots: fewer of them go for the same READY word
     for (;;) {
         RSTAMP(2);
-        feed();
-        uint32_t g = 0;
-        if (lane == 0) g = __hip_atomic_fetch_add(&ctl->taken, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
         unsigned long long pw = 0;
-#ifdef HD_RING_FAULT   // fault mode 1: ONE computing wave of the process sleeps through more than sixteen publications with its ticket drawn
-        if (g == 8u && g_ring_fault_mode == 1u) {
-            unsigned int won = 1u;
-            if (lane == 0) won = atomicCAS(&g_ring_fault_fired, 0u, 1u);
-            if ((unsigned int)__builtin_amdgcn_readfirstlane((int)won) == 0u) {
-                for (;;) {                                   // (until the word itself carries a later publication: the counter runs ahead of the store)
-                    const unsigned long long w_ = __hip_atomic_load(&ctl->pub[g & 15u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (w_ != ~0ull && (int32_t)((((uint32_t)(w_ >> 40)) - g) << 8) > 0) break;
-                    if (__hip_atomic_load(&ctl->live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
-                    __builtin_amdgcn_s_sleep(8);
-                }
-            }
-        }
-#endif
+        uint32_t slot = 0;
+        bool last_look = false;
         for (uint32_t spin = 0;; ++spin) {
-            pw = __hip_atomic_load(&ctl->pub[g & 15u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((uint32_t)(pw >> 40) == g) break;
-            if (pw != ~0ull && (int32_t)((((uint32_t)(pw >> 40)) - g) << 8) > 0) {
-                // a LATER publication sits in my word: mine came and went while I was not looking (sixteen publications ago) -- its tile is lost.  Never in a
-                // correct run (a waiting consumer looks every few hundred cycles); reported like the other bounded waits instead of leaving a stale tile behind.
-                if (lane == 0) __hip_atomic_store(a.gave_up, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            feed();
+            // every slot's word at once (lane j reads word j); a READY one is taken by swapping the WHOLE word -- state and descriptor -- for TAKEN: the
+            // wave whose swap succeeds holds the descriptor already, a wave that was beaten to it looks again
+            unsigned long long w = 0;
+            if (lane < n_slots_all) w = __hip_atomic_load(&ctl->slot[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t ready = (uint32_t)__ballot((uint32_t)(w >> 32) == kSlotReady) & 0xFFFFu;
+            if (ready) {
+                const uint32_t rot = ((ready >> look_from) | (ready << (16u - look_from))) & 0xFFFFu;
+                slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)__builtin_ctz(rot) + look_from)) & 15u;
+                pw = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), (int)slot) << 32) |
+                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, (int)slot);
+                uint32_t won = 0;
+                if (lane == 0) {
+                    unsigned long long expect = pw;
+                    won = __hip_atomic_compare_exchange_strong(&ctl->slot[slot], &expect, (unsigned long long)kSlotTaken << 32, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+                }
+                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)won)) break;
+                continue;
+            }
+            if (last_look) {                        // nothing READY after every loader had counted itself out: done
+                RSTAMP(0); RSTAMP_WRITE(my_wave, n_done);
                 return;
             }
             if (__hip_atomic_load(&ctl->live, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
-                // no loader will publish any more -- unless publication g went out between the two reads (a loader publishes, THEN counts itself out)
-                pw = __hip_atomic_load(&ctl->pub[g & 15u], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if ((uint32_t)(pw >> 40) == g) break;
-                RSTAMP(0); RSTAMP_WRITE(my_wave, n_done);
-                return;
+                last_look = true;                   // no loader will publish any more -- but one may have between my look and its count-down (it publishes, THEN counts itself out)
+                continue;
             }
             if (spin > kRingSpinLimit) {            // (never in a correct run: a bounded wait cannot hang the device, and the engine reports it)
                 if (lane == 0) __hip_atomic_store(a.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 return;
             }
-            feed();
             __builtin_amdgcn_s_sleep(1);
         }
         RSTAMP(0);
-        const uint32_t phi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pw >> 32)), plo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pw);
-        const uint32_t slot = phi & 0xFFu, s = plo >> 12, tile = plo & 0xFFFu;
+        const uint32_t plo = (uint32_t)pw, s = plo >> 12, tile = plo & 0xFFFu;
         const unsigned char* p = (slot < geo.nb ? geo.ring + slot * (uint32_t)ring_slot_bytes<T>() : geo.extra + ring_extra_off(geo, slot - geo.nb)) + lane * (uint32_t)kRingRowBytes;
 
-        if constexpr (D == 32) {
+        if constexpr (D == 32 && kRingSystolic) {
+        // The SYSTOLIC tap loop.  Output o of the stream is the sum over the rows o .. o + HR of the history-extended row sequence (its window starts at
+        // slot JS of row o and ends with slot 0 of row o + HR).  Lane l holds row origin + l of the tile -- ITS 32 samples, sixteen 16-byte LDS reads, all
+        // that is read of the tile (a lane that walks its output's whole window reads 6.6 x as much: round 4 counted 63 % of a CU's LDS traffic there) --
+        // and the ACCUMULATORS move: the sum of output origin + o starts in lane o, takes the taps that fall on that lane's row, and is handed to lane
+        // o + 1 (one DPP rotate per component) for the next row.  Every sum still receives its T products in ascending tap order, separately rounded:
+        // bit-identical to the lane-owns-the-window loop by construction.  After HR hand-overs lane l >= HR holds output origin + l - HR; the sums that
+        // wrapped past lane 63 are the next tile's (ring_adv).  Measured bare (tools/micro/taploop.hip, mode 4): 2510 ticks per 64 rows against 3280.
+        constexpr uint32_t ADV = (uint32_t)ring_adv<T>();
+        const uint32_t rows = a.n / 32u, origin = tile * ADV < rows - ADV ? tile * ADV : rows - ADV;
+        // taps of the sixteen slots [16 c, 16 c + 16) of the lane-relative slot sequence as eight scalar pairs; slots outside [JS, NS) carry no tap
+        auto ldk = [&](r_f32x2 (&k)[8], auto cc) {
+            constexpr int c = decltype(cc)::value;
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+                k[j >> 1].x = (16 * c + j >= JS && 16 * c + j < NS) ? taps[16 * c + j] : 0.f;
+                k[j >> 1].y = (16 * c + j + 1 >= JS && 16 * c + j + 1 < NS) ? taps[16 * c + j + 1] : 0.f;
+            }
+        };
+        r_f32x2 kk[2][2][8];                            // [step parity][half row][pair]
+        r_f32x4 x[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = *reinterpret_cast<const r_f32x4*>(p + 16 * q);
+        ldk(kk[0][0], std::integral_constant<int, 0>{}); ldk(kk[0][1], std::integral_constant<int, 1>{});   // (step 0's taps travel with the row)
+        __builtin_amdgcn_sched_barrier(0);
+        // The slot goes back to its loader as soon as the row is in registers -- before the arithmetic, not behind it: a slot is busy while its tile lands
+        // and for these sixteen reads.  (DS instructions of a wave execute in order: the store below cannot pass the reads; the statement keeps the compiler
+        // from moving it, or the reads, either way.)
+        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                          "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) :: "memory");
+        if (lane == 0) __hip_atomic_store(&ctl->slot[slot], (unsigned long long)kSlotFree << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        RSTAMP(3);
+        r_f32x2 acc = {0.f, 0.f};
+        // chunk c of the slot sequence = half h = c & 1 of the row of step c >> 1: all sixteen taps (the hand-scheduled form), or the few that exist
+        auto mac_chunk = [&](const r_f32x2 (&k)[8], auto cc) {
+            constexpr int c = decltype(cc)::value, j0 = JS > 16 * c ? JS - 16 * c : 0, j1 = NS < 16 * c + 16 ? NS - 16 * c : 16;
+            const r_f32x4 (&xh)[8] = reinterpret_cast<const r_f32x4 (&)[8]>(x[8 * (c & 1)]);
+            if constexpr (j0 == 0 && j1 == 16) ring_mac16_asm(acc, xh, k);
+            else {
+#pragma unroll
+                for (int j = j0; j < j1; ++j) {
+                    const r_f32x2 smp = (j & 1) ? xh[j >> 1].zw : xh[j >> 1].xy;
+                    acc = acc + smp * ((j & 1) ? k[j >> 1].y : k[j >> 1].x);
+                }
+            }
+        };
+        auto rot = [&]() {                              // lane l takes lane l - 1's sum (wave_ror:1)
+            // (through scalars: __builtin_bit_cast of an ext-vector ELEMENT reads the vector's first element whichever was named -- clang 20)
+            const float re = acc.x, im = acc.y;
+            acc.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, re), 0x13C, 0xF, 0xF, false));
+            acc.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, im), 0x13C, 0xF, 0xF, false));
+        };
+        // A step's taps are requested a step ahead through the scalar cache.  Scalar loads return out of order, so waiting for any of them waits for all
+        // that are outstanding: the wait for step r's taps (forced by `arrived`) therefore sits IN FRONT of the request for step r + 1's, which then has
+        // the whole of step r's arithmetic to come back; the scheduling barrier keeps the compiler from sinking the request to its use.
+        auto arrived = [&](const r_f32x2 (&k)[2][8]) {
+            asm volatile("" :: "s"(k[0][0]), "s"(k[0][1]), "s"(k[0][2]), "s"(k[0][3]), "s"(k[0][4]), "s"(k[0][5]), "s"(k[0][6]), "s"(k[0][7]),
+                               "s"(k[1][0]), "s"(k[1][1]), "s"(k[1][2]), "s"(k[1][3]), "s"(k[1][4]), "s"(k[1][5]), "s"(k[1][6]), "s"(k[1][7]));
+        };
+        ring_for_each_index([&](auto ri) {
+            constexpr int r = decltype(ri)::value;      // step r: the row's slots [32 r, 32 r + 32) of the slot sequence
+            arrived(kk[r & 1]);
+            if constexpr (r < HR) {
+                ldk(kk[(r + 1) & 1][0], std::integral_constant<int, 2 * r + 2>{});
+                ldk(kk[(r + 1) & 1][1], std::integral_constant<int, 2 * r + 3>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (JS < 32 * r + 16) mac_chunk(kk[r & 1][0], std::integral_constant<int, 2 * r>{});
+            if constexpr (32 * r + 16 < NS && JS < 32 * r + 32) mac_chunk(kk[r & 1][1], std::integral_constant<int, 2 * r + 1>{});
+            if constexpr (r < HR) rot();
+        }, std::make_integer_sequence<int, HR + 1>{});
+#ifdef HD_STAMP_RING
+        asm volatile("" : "+v"(acc));
+        ++n_done;
+#endif
+        RSTAMP(1);
+        if (lane >= (uint32_t)HR) a.out[(size_t)s * a.out_stride + origin + lane - (uint32_t)HR] = make_float2(acc.x, acc.y);
+        if (tile + 1 == a.ntiles) {                 // the stream's last tile: carry the last T-1 inputs (Decimator.h:140-143)
+            const float2* in_s = a.in + (size_t)s * a.in_stride;
+            float2* hout = a.hist_out + (size_t)s * (T - 1);
+            for (uint32_t j = lane; j < (uint32_t)(T - 1); j += 64u) hout[j] = in_s[a.n - (T - 1) + j];
+        }
+        } else if constexpr (D == 32) {      // -DHD_RING_CLASSIC (A/B builds): a lane walks its output's whole window, tiles of 64 outputs
         // the T-term sum in tap order: 16-slot chunks (half rows), the next chunk's samples and taps requested before the current one is summed
         r_f32x2 acc = {0.f, 0.f};
         r_f32x4 xa[8], xb[8];
@@ -642,7 +750,7 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
 #endif
         RSTAMP(1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) (void)__hip_atomic_fetch_add(&ctl->slot_done[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_store(&ctl->slot[slot], (unsigned long long)kSlotFree << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         a.out[(size_t)s * a.out_stride + (size_t)tile * 64u + lane] = make_float2(acc.x, acc.y);
         if (tile + 1 == a.ntiles) {                 // the stream's last tile: carry the last T-1 inputs (Decimator.h:140-143)
             const float2* in_s = a.in + (size_t)s * a.in_stride;
@@ -727,7 +835,7 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
         }, std::make_integer_sequence<int, CW1 - C0 + 1>{});
         RSTAMP(1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) (void)__hip_atomic_fetch_add(&ctl->slot_done[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_store(&ctl->slot[slot], (unsigned long long)kSlotFree << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint32_t o0 = (tile * 64u + lane) * (uint32_t)OPL;                                 // the lane's first output of the stream's chunk
         if (!a.call) {
             float2* dst = a.out + (size_t)s * a.out_stride + o0;                                     // (16-byte aligned: the stride is even)

@@ -1,6 +1,6 @@
 """The give-up path of the per-CU ring kernels, end to end: a fault-injection build of the SAME sources
 (habdec_amd/libhabdec_amd_fault.so, -DHD_RING_FAULT: one LDS-DMA loader of the process never publishes its second tile and stops; or -- the second
-mode -- one computing wave sleeps with its ticket drawn until a later publication has overwritten its word) must
+mode -- one feeding wave stops handing out runs, so that its CU's loaders starve) must
 
   * not hang the device: every wait in stage1_ring.h is bounded, the launch ends by itself;
   * report: the waves whose wait ran out set the mapped host word, collect() fails the call with HD_ERR_DEVICE;
@@ -66,17 +66,18 @@ def test_a_dropped_publish_is_reported_and_the_engine_stays_failed(pipeline):
 
 
 @pytest.mark.parametrize("pipeline", [1, 0])
-def test_an_overwritten_publication_is_reported_not_left_as_a_stale_tile(pipeline):
-    """Round 4 found the one way a tile could be lost silently: a computing wave that does not look at its publication word for sixteen publications
-    (a feeder that drew from eight counters in a row did) finds a LATER tile's word there, and used to leave when the loaders were done -- the tile's
-    outputs kept what the buffer held three calls earlier.  The wave now recognises the later sequence number and reports; this build makes one wave nap."""
+def test_starved_loaders_report_instead_of_waiting_forever(pipeline):
+    """The other bounded wait: a CU's feeding wave stops handing out runs after its second (the fault build's second mode), so that CU's loaders find
+    nothing to issue -- their wait runs out, they report and count themselves out, the computing waves leave, the launch ends; the engine fails the
+    call and stays failed.  (Round 4's second mode -- a computing wave napping until its publication word had been overwritten -- tested a hazard the
+    sixteen-entry publication queue had; round 5's per-slot words have no queue to overflow: a READY word is replaced only by the wave that took it.)"""
     torch = pytest.importorskip("torch")
     from habdec_amd import capi
     L = load_fault_lib()
-    if not hasattr(L, "hd_debug_ring_fault_arm_nap"):
-        pytest.skip("fault-injection library without the nap mode (rebuild it)")
-    L.hd_debug_ring_fault_arm_nap()
-    S, CH, fs = 1024, 65536, 2.048e6                     # 128 tiles per CU: far more than sixteen publications behind the napping wave's ticket
+    if not hasattr(L, "hd_debug_ring_fault_arm_starve"):
+        pytest.skip("fault-injection library without the starvation mode (rebuild it)")
+    L.hd_debug_ring_fault_arm_starve()
+    S, CH, fs = 1024, 65536, 2.048e6                     # 144 tiles per CU: far more than two runs
     cfg = capi.hd_engine_config()
     L.hd_engine_config_default(C.byref(cfg))
     cfg.n_streams, cfg.max_chunk, cfg.sampling_rate, cfg.decimation, cfg.pipeline = S, CH, fs, 64, pipeline
@@ -90,7 +91,7 @@ def test_an_overwritten_publication_is_reported_not_left_as_a_stale_tile(pipelin
     assert t.step_variant == 1, "the per-CU ring kernel did not run: nothing was injected"
     assert HD_ERR_DEVICE in codes, codes
     assert all(c == HD_ERR_DEVICE for c in codes[codes.index(HD_ERR_DEVICE):]), codes
-    assert b"word 2" in L.hd_last_error() or b"bounded wait" in L.hd_last_error(), L.hd_last_error()
+    assert b"bounded wait" in L.hd_last_error(), L.hd_last_error()
     L.hd_engine_destroy(h)
     del iq
     torch.cuda.empty_cache()

@@ -27,8 +27,8 @@ for wv in (1, 2, 3, 4, 5, 6, 7):
     c = st[:, wv]
     if not (c[:, 5] > 0).any(): continue
     c = c[c[:, 5] > 0]
-    print("consumer %d: tiles p0/50/100 %s; per tile: wait %.0f compute %.0f store+take %.0f; lifetime us p50 %.1f end us p100 %.1f" % (
-        wv, np.percentile(c[:, 5], [0, 50, 100]).tolist(), np.median(c[:, 0] / c[:, 5]), np.median(c[:, 1] / c[:, 5]), np.median(c[:, 2] / c[:, 5]),
+    print("consumer %d: tiles p0/50/100 %s; per tile: wait %.0f row reads %.0f compute %.0f store+take %.0f; lifetime us p50 %.1f end us p100 %.1f" % (
+        wv, np.percentile(c[:, 5], [0, 50, 100]).tolist(), np.median(c[:, 0] / c[:, 5]), np.median(c[:, 3] / c[:, 5]), np.median(c[:, 1] / c[:, 5]), np.median(c[:, 2] / c[:, 5]),
         np.median((c[:, 7] - c[:, 6]) / 100), ((c[:, 7] - t0) / 100).max()))
 # when does each CU (workgroup) run out of work, and when did its tails hand over?  (realtime counter: 100 ticks per microsecond)
 ok = st[:, :, 7] > 0
