@@ -132,10 +132,7 @@ struct hd_engine {
     bool no_claim = false;     // HD_NO_CLAIM: step launches with fixed shares of tiles (A/B measurements)
     uint32_t step_run = 0;     // HD_STEP_RUN: tiles per drawn run (default 4, minimum 2)
     bool no_cu_step = false;   // HD_NO_CU_STEP: step launches as single-wave workgroups (k_step) instead of one workgroup per CU (k_step_cu)
-    uint32_t last_step_slots = 0;   // tile slots of the last k_step_cu launch (diagnostic)
-    bool cu_slots4 = false;         // HD_CU_SLOTS=4: never five tile slots in a step launch (A/B measurements)
-    uint32_t ring_run = 0;     // HD_RING_RUN: tiles per drawn run of k_step_cu's loader (default 8)
-    uint32_t ring_loaders = 1; // HD_RING_LOADERS: LDS-DMA waves per CU in a step launch (1 or 2; one leaves SIMD 1 two computing waves: 0.157 against 0.160 ms per launch)
+    uint32_t ring_run = 0;     // HD_RING_RUN: tiles per drawn run of the per-CU ring kernels (default: pick_ring_run)
     uint32_t s1_loaders = 2;   // HD_S1_LOADERS: ... when stage 1 is a launch of its own.  Two since round 4: with the nt policy on the body rows one loader's 3 tiles in
                                // flight (its 6-bit vmcnt holds 57 DMA instructions) are what bounds the launch -- 102.7 us with one loader, 94.7 with two (one box, alternating)
     uint32_t s1_waves = 8;     // HD_S1_WAVES: waves per workgroup of k_stage1_cu (8 .. 16)
@@ -330,8 +327,6 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     if (const char* v = getenv("HD_STEP_RUN")) e->step_run = (uint32_t)atoi(v);
     e->no_cu_step = getenv("HD_NO_CU_STEP") != nullptr;
     if (const char* v = getenv("HD_RING_RUN")) e->ring_run = (uint32_t)atoi(v);
-    if (const char* v = getenv("HD_RING_LOADERS")) e->ring_loaders = atoi(v) == 1 ? 1u : 2u;
-    if (const char* v = getenv("HD_CU_SLOTS")) e->cu_slots4 = atoi(v) == 4;
     if (const char* v = getenv("HD_S1_LOADERS")) e->s1_loaders = atoi(v) == 1 ? 1u : 2u;
     if (const char* v = getenv("HD_S1_WAVES")) e->s1_waves = (uint32_t)atoi(v);
     if (const char* v = getenv("HD_S1_SLOTS")) e->s1_slots = (uint32_t)atoi(v);
@@ -546,9 +541,6 @@ int hd_engine_timing(hd_engine* e, hd_timing* out)
     *out = e->last_timing;
     return HD_OK;
 }
-
-// diagnostic (not in include/habdec_amd.h): tile slots the last k_step_cu launch ran with (4 or 5; 0 = none yet)
-extern "C" unsigned int hd_debug_step_slots(hd_engine* e) { return e ? e->last_step_slots : 0u; }
 
 // diagnostic (not in include/habdec_amd.h): the two sets of per-XCD run counters of the step launches, [2][16] (after a device-wide wait)
 extern "C" int hd_debug_step_counters(hd_engine* e, unsigned int* out32)
@@ -976,30 +968,32 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         }
         return claim;
     };
-    // Tiles per drawn run of a per-CU ring kernel's loaders: consecutive tiles of one stream (the rows neighbouring tiles share are re-read from the
-    // XCD's L2), so it must divide the stream's tile count, and the launch's runs must divide among the XCDs.  Eight measured best among 4 / 8 / 16
-    // (round 4); the nearest usable length to that, the longer one first (36 systolic tiles per 65536-sample push: nine).
+    // Tiles per drawn run of the per-CU ring kernels: consecutive tiles of one stream (the rows neighbouring tiles share are re-read from the XCD's L2), so it
+    // must divide the stream's tile count, and the launch's runs must divide among the XCDs.  The /32 stages' worker waves draw their own runs and the
+    // last runs of a launch are its ragged end: four measured best among 3 / 4 / 6 / 9 / 12 (0.1360-0.1368 ms per step against 0.1386 with nine, one box,
+    // alternating); the loader / consumer kernels of the smaller ratios keep eight (round 4).  The nearest usable length, the longer one first.
     auto pick_ring_run = [&](const uint32_t ntiles) -> uint32_t {
-        const uint32_t n_xcd = e->n_cus / 32u ? e->n_cus / 32u : 1u;
+        const uint32_t n_xcd = e->n_cus / 32u ? e->n_cus / 32u : 1u, want = R1 == 32 ? 4u : 8u;
         auto ok = [&](uint32_t r) { return r >= 2u && r <= ntiles && ntiles % r == 0 && ((uint64_t)S * ntiles / r) % n_xcd == 0; };
         if (e->ring_run >= 2 && ok(e->ring_run)) return e->ring_run;
-        for (uint32_t d = 0; d <= 6u; ++d) {
-            if (ok(8u + d)) return 8u + d;
-            if (d && d < 7u && ok(8u - d)) return 8u - d;
+        for (uint32_t d = 0; d <= 8u; ++d) {
+            if (ok(want + d)) return want + d;
+            if (d && d < want && ok(want - d)) return want - d;
         }
         return 2u;                                     // (k_step treats shorter runs as "not drawn" while the counter sets have already alternated; make_claim refuses what does not divide)
     };
     if (step) {
         // One launch: [tails of the previous call | this call's stage 1].  Stage 1 reads its parameters from the mapped host block and
         // leaves the device copy the tails (next launch) and the spectrum commit read.
-        // Five tile slots instead of four where the tails' windows fit what that leaves (one loader; the compact 64-lane carve of tail.hip at 161
-        // taps and R = 160 fits with a few dozen bytes to spare): this call's tails are laid out for it now, the launch that runs them decides.
-        // (... and only where k_step_cu can serve the plan and the sizes at all: the single-wave fallback would run its tails with smaller caches for nothing)
+        // Where the per-CU step kernel can serve the plan and the sizes, this call's tails are laid out for ITS slice of LDS -- a quarter of what four
+        // worker slots leave of the CU's 160 KB (23 KB: larger caches for the search phase than the 20 KB slot of the single-wave fallback) -- now; the
+        // launch that runs them decides.
         const bool cu_shape = !e->no_cu_step && !e->no_claim && !any_zero1 && max_in % 2048u == 0 && hd::step_cu_supported((int)R1, (int)T1, (int)R2, (int)T2);
-        const uint32_t cu_tail5 = (cu_shape && e->ring_loaders == 1u && !e->cu_slots4) ? hd::step_cu_tail_lds((int)R1, (int)T1, 5u) : 0u;
-        if (cu_tail5) {
-            hd::TailArgs ta5{};
-            if (hd::tail_layout(ta5, 64, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, cu_tail5)) ta_step = ta5;
+        uint32_t cu_tail = cu_shape ? hd::step_cu_tail_lds((int)R1, (int)T1) : 0u;
+        if (const char* v = getenv("HD_CU_TAIL_LDS")) cu_tail = std::min<uint32_t>(cu_tail, (uint32_t)atoi(v));      // (A/B: the tails' LDS carve inside the per-CU step kernel)
+        if (cu_tail) {
+            hd::TailArgs tacu{};
+            if (hd::tail_layout(tacu, 64, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, cu_tail)) ta_step = tacu;
         }
         fill_tail(ta_step);
         hd_engine::PendingTail prev = e->pend;
@@ -1009,30 +1003,25 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         static const bool ext_events = !getenv("HD_STEP_PACKET_EVENTS");
         bool ev_on_dispatch = false;
         uint32_t wgs = e->step_wgs ? e->step_wgs : 32u * e->n_cus;   // short runs of tiles: the dispatcher evens out the tail of the launch
-        // One workgroup per CU (loader + consumer waves for stage 1, the tails in the other four waves) where the plan and the sizes allow it
-        const uint32_t cu_tail = hd::step_cu_tail_lds((int)R1, (int)T1);
+        // One workgroup per CU (four stage-1 worker waves, the tails in the other four) where the plan and the sizes allow it
         const uint32_t ring_run = pick_ring_run(hd::ring_tiles((int)R1, (int)T1, max_in));
-        static const int cu_exp0 = getenv("HD_CU_EXP") ? atoi(getenv("HD_CU_EXP")) : 0;
-        const bool want_cu = cu_shape && cu_tail && ((cu_exp0 & 1) || (ta_step.lds_bytes <= cu_tail &&
-                             (!prev.valid || prev.ta.lds_bytes <= cu_tail)));
+        static const int cu_exp0 = getenv("HD_CU_EXP") ? atoi(getenv("HD_CU_EXP")) : 0;   // timing experiments only (results wrong): 1 = no tails, 2 = no stage 1
+        const bool want_cu = cu_tail && ((cu_exp0 & 1) || (ta_step.lds_bytes <= cu_tail && (!prev.valid || prev.ta.lds_bytes <= cu_tail)));
         const hd::StepClaim claim = make_claim(0, want_cu ? ring_run : 0u);
         if (claim.ctr && !e->step_wgs) wgs = 8u * e->n_cus;
         bool launched = false;
         e->last_timing.step_variant = 0;
         if (want_cu && claim.ctr) {
             const uint32_t tb = std::max(ta_step.lds_bytes, prev.valid ? prev.ta.lds_bytes : 0u);
-            static const int cu_exp = getenv("HD_CU_EXP") ? atoi(getenv("HD_CU_EXP")) : 0;   // timing experiments only (results wrong): 1 = no tails, 2 = no stage 1
-            const uint32_t n_slots = (cu_tail5 && ((tb + 15u) & ~15u) <= cu_tail5) ? 5u : 4u;
             hd::StepClaim cl = claim;
-            if (cu_exp & 2) cl.runs_per_xcd = 0;
+            if (cu_exp0 & 2) cl.runs_per_xcd = 0;
             ev_on_dispatch = ext_events && (!ps || prev.ta.fft_tw || !prev.any_fft);
             if (sl.timed && !ev_on_dispatch) HD_HIP(hipEventRecord(sl.t1, qa));
             launched = hd::launch_step_cu(qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, e->n_cus, iq, stride,
                                           e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, prev.ta,
-                                          (prev.valid && !(cu_exp & 1)) ? S : 0u, max_in, cl, (tb + 15u) & ~15u, e->ring_gave_up.dev, e->ring_loaders, n_slots,
+                                          (prev.valid && !(cu_exp0 & 1)) ? S : 0u, max_in, cl, tb,
                                           ev_on_dispatch && sl.timed ? sl.t1 : nullptr, !ev_on_dispatch ? nullptr : sl.timed ? sl.t2 : ps ? ps->ev_done : nullptr);
             if (!launched && ev_on_dispatch) { ev_on_dispatch = false; if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa)); }
-            if (launched) e->last_step_slots = n_slots;
             e->last_timing.step_variant = launched ? 1u : 0u;
         }
         else if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));

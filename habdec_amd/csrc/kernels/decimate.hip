@@ -579,48 +579,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 64 ? 1 
                             blockIdx.x - n_tail, 0u, gridDim.x - n_tail, tile4, uniform_n, claim);
 }
 
-// The step launch as ONE workgroup per CU (512 threads, all of the CU's LDS), roles by wave: role 0 (and role 1 with two loaders) streams
-// this call's stage-1 tiles into LDS slots with LDS-DMA, roles up to 3 compute them (stage1_ring.h), roles 4-7 run the previous call's
-// stream tails -- four streams per CU at 1024 streams, each in its own slice of LDS -- leave the device copy of their streams' parameter
-// blocks for the next launch, and then join the computing waves.  Compared with k_step (single-wave workgroups, dispatcher-scheduled) the loads of stage 1 never stop
-// while the tails hold half of the CU's wave slots, and what runs where does not depend on the dispatcher.
-#ifndef HD_CU_WAVES
-#define HD_CU_WAVES 8          // waves of the step workgroup: 8 (two per SIMD at <= 256 VGPRs); 12 = the three-per-SIMD experiment (<= 168 VGPRs)
-#endif
+// The step launch as ONE workgroup per CU (512 threads, all of the CU's LDS), two waves per SIMD: a stage-1 WORKER (stage1_ring.h: ring_worker --
+// it loads its own tiles with LDS-DMA into its own 64-row slot and sums them with the systolic tap loop) and a stream tail of the previous call --
+// four streams per CU at 1024 streams, each in its own slice of LDS -- which leaves the device copy of its stream's parameter block for the next
+// launch and then becomes a worker too, its slice the slot.  Compared with k_step
+// (single-wave workgroups, dispatcher-scheduled) stage 1's loads never stop while the tails hold half of the CU's wave slots, a tile in flight costs
+// no registers, and what runs where does not depend on the dispatcher; compared with rounds 3-4 (one loader wave feeding computing waves through
+// shared slots) nothing is shared between the waves of a CU and the loads in flight grow with the waves that exist.
 template <int T, int D2, int T2>
-__global__ __launch_bounds__(64 * HD_CU_WAVES) void k_step_cu(const RingArgs ra, const StreamCall* __restrict__ call, StreamCall* __restrict__ call_copy,
-                                                 const TailArgs ta, const uint32_t n_tail, const uint32_t n_streams, const uint32_t tail_bytes,
-                                                 const uint32_t n_loaders /* 2: a loader on SIMD 0 and on SIMD 1; 1: SIMD 1 computes with both of its waves */,
-                                                 const uint32_t n_slots /* tile slots in the ring region: 4, or (one loader, tails that fit beside them) 5, or (no tails in the launch) 8 */)
+__global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const StreamCall* __restrict__ call, StreamCall* __restrict__ call_copy,
+                                                 const TailArgs ta, const uint32_t n_tail, const uint32_t n_streams, const uint32_t tail_bytes /* >= kWorkSlotBytes */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char cu_lds[];
-    unsigned char* ring = cu_lds;
-    RingCtl* ctl = reinterpret_cast<RingCtl*>(cu_lds + n_slots * ring_slot_bytes<T>());
-    unsigned char* tails = cu_lds + n_slots * ring_slot_bytes<T>() + kRingCtlBytes;
-    ring_ctl_init(ctl, n_loaders);
+    RingCtl* ctl = reinterpret_cast<RingCtl*>(cu_lds);
+    unsigned char* slots = cu_lds + kRingCtlBytes;                           // worker slots of roles 0-3 (0-7 in a launch without tails)
+    unsigned char* tails = slots + 4 * kWorkSlotBytes;                       // four tail slices of tail_bytes each
+    ring_ctl_init(ctl, 0u);
     __syncthreads();
     // Roles by SIMD, not by wave number.  A 512-thread workgroup at 256 VGPRs puts exactly two waves on each of the CU's four SIMDs; which two
-    // is the hardware's choice.  The tap loops and the tails are both VALU work, the loaders are not: SIMDs 0 and 1 each get a loader and a
-    // computing wave (which then has its SIMD's vector pipe to itself), SIMDs 2 and 3 two tails each (latency chains that leave each other
-    // most of the issue slots).  The first wave to arrive on a SIMD (an LDS counter) takes the first role.
-#ifndef HD_CU_ROLES_BY_WAVE
+    // is the hardware's choice.  The first wave to arrive on a SIMD (an LDS counter) takes the SIMD's first role.
     const uint32_t simd = (__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4)) & 3u;                    // HW_ID.SIMD_ID
     uint32_t rank = 0;
     if ((threadIdx.x & 63u) == 0) rank = __hip_atomic_fetch_add(&ctl->simd_rank[simd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)rank);
-#if HD_CU_WAVES == 12
-    // three waves per SIMD: a tail on every SIMD (role 8 + simd), the loader on SIMD 0 beside two computing waves, two computing waves on the others
-    constexpr uint32_t kPerSimd = 3u, kTailBase = 8u, kFeeder = 4u;
-    uint32_t w = rank == 0u ? 8u + simd : rank == 1u ? simd : 4u + simd;                                   // 0 loader, 1-7 computing, 8-11 tails
-#else
-    constexpr uint32_t kPerSimd = 2u, kTailBase = 4u, kFeeder = 2u;
-    uint32_t w = simd < 2u ? (rank ? 2u + simd : simd) : 4u + 2u * (simd - 2u) + rank;                     // 0-1 loaders, 2-3 computing, 4-7 tails
-#endif
-    // (kPerSimd waves per SIMD is what the register budget gives; should the hardware ever place one more on a SIMD, that wave takes one of the roles
+    // Every SIMD gets ONE worker and ONE tail: two tails on a SIMD slow each other by a fifth (83 against 102 us alone, round 3), two workers on a SIMD halve
+    // the second one's tap loop (the arbiter prefers the older wave: 2.4k against 4.8k ticks per tile, in-kernel clocks) -- a tail and a worker fill each
+    // other's gaps (one box, alternating, sustained: 0.1300-0.1311 ms per step against 0.1318-0.1326 with workers on SIMDs 0-1 and tails on 2-3).
+    uint32_t w = rank ? 4u + simd : simd;                                                                  // workers 0-3, tails 4-7
+    // (two waves per SIMD is what the register budget gives; should the hardware ever place a third on a SIMD, that wave takes one of the roles
     // nobody claimed -- every role must be filled exactly once, whatever the placement.)
-    if (rank < kPerSimd && (threadIdx.x & 63u) == 0) (void)__hip_atomic_fetch_or(&ctl->roles_taken, 1u << w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (rank < 2u && (threadIdx.x & 63u) == 0) (void)__hip_atomic_fetch_or(&ctl->roles_taken, 1u << w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
-    if (rank >= kPerSimd) {
+    if (rank >= 2u) {
         uint32_t pick = 0;
         if ((threadIdx.x & 63u) == 0) {
             for (;;) {                                                       // claim the lowest role still free
@@ -631,80 +621,41 @@ __global__ __launch_bounds__(64 * HD_CU_WAVES) void k_step_cu(const RingArgs ra,
         }
         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)pick);
     }
-#else
-    constexpr uint32_t kTailBase = HD_CU_WAVES - 4u, kFeeder = 2u;
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#endif
-    // Tile slots: the ring region's (four, five beside the compact tails, eight in a launch without tails), and -- as the tails finish -- slots inside
-    // the tails' LDS slices (stage1_ring.h: ring_extra_slots), up to eight in all per loader pair.
-    RingGeom geom{ring, n_slots, tails, 0u, 0u, 0u};
-#ifndef HD_CU_NO_EXTRA_SLOTS
-    ring_extra_slots(geom, tail_bytes, (uint32_t)ring_slot_bytes<T>(), n_slots < 8u ? 8u - n_slots : 0u, n_tail != 0);
-#endif
-    // Who loads into what.  One loader from the start owns the ring region; the extra slots -- which exist from the moment tails finish -- belong to a
-    // SECOND loader: the first tail wave that is done (three more tiles in flight for the launch's second half; HD_CU_NO_LATE_LOADER: the first loader
-    // takes them too, as in round 3).  Two loaders from the start (HD_RING_LOADERS=2) split the ring region and the extra slots evenly.
-#ifndef HD_CU_NO_LATE_LOADER
-    const bool late_loader = n_loaders == 1u && geom.ne != 0u;
-#else
-    const bool late_loader = false;
-#endif
-    if (w < n_loaders) {
-#ifdef HD_RING_LOADER_PRIO
-        __builtin_amdgcn_s_setprio(HD_RING_LOADER_PRIO);
-#endif
-        if (n_loaders == 1u) ring_loader<T>(ra, geom, ctl, 0u, late_loader ? geom.nb : geom.nb + geom.ne, w);
-        else {   // loader w: its half of the ring region; the extra slots go to loader 1 as a block when the halves would not be whole slots of one kind
-            const uint32_t hb = geom.nb / 2u;
-            if (w == 0u) ring_loader<T>(ra, geom, ctl, 0u, hb, w); else ring_loader<T>(ra, geom, ctl, hb, geom.nb - hb + geom.ne, w);
-        }
-    } else if (w < kTailBase) {
-        ring_consumer<T>(ra, geom, ctl, w == kFeeder, w);                // (the wave beside loader 0 draws the runs)
+    if (w < 4u) {
+        ring_worker<T>(ra, slots + w * (uint32_t)kWorkSlotBytes, w);
     } else {
-        __builtin_amdgcn_s_setprio(HD_STEP_PRIO);
-        const uint32_t k = w - kTailBase, lane = threadIdx.x & 63u;
+        const uint32_t k = w - 4u, lane = threadIdx.x & 63u;
         const uint32_t s = blockIdx.x * 4u + k;                          // (the grid has at least n_streams / 4 workgroups)
         if (s < n_streams) {
-        if (s < n_tail) tail_body<64, 4, D2, T2>(ta, s, tails + k * tail_bytes, k & 1u);    // (k & 1: the wave's rank on its SIMD -- the two tails of a SIMD take turns at the higher priority)
-        // this call's parameters live in mapped host memory; the tails of this call (next launch) read the device copy
-        if (call_copy && lane < 4) reinterpret_cast<uint4*>(call_copy + s)[lane] = reinterpret_cast<const uint4*>(call + s)[lane];
-        }
-        // my slice of LDS is free from here on: a tile slot for the loaders (every LDS access of the tail has completed: its results are stored)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) (void)__hip_atomic_fetch_or(&ctl->tail_mask, 1u << k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __builtin_amdgcn_s_setprio(0);
-        if (late_loader) {
-            // The first tail wave that is done becomes the second loader -- if a loader is still at work: `live` is only ever raised from a non-zero
-            // value (a consumer that saw zero may already have left; raising it from zero would be a promise nobody is left to hear).
-            uint32_t first = 1u, was = 0u;
-            if (lane == 0) first = __hip_atomic_fetch_add(&ctl->late_loader, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)first) == 0u) {
-                if (lane == 0) {
-                    was = __hip_atomic_load(&ctl->live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    while (was != 0u && !__hip_atomic_compare_exchange_strong(&ctl->live, &was, was + 1u, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { }
-                }
-                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)was) != 0u) ring_loader<T>(ra, geom, ctl, geom.nb, geom.ne, w);
+            if (s < n_tail) {
+                __builtin_amdgcn_s_setprio(HD_STEP_PRIO);
+                tail_body<64, 4, D2, T2>(ta, s, tails + k * tail_bytes);           // (the latency chain of the SIMD at the higher priority; the worker beside it takes the issue slots it leaves)
+                __builtin_amdgcn_s_setprio(0);
             }
+            // this call's parameters live in mapped host memory; the tails of this call (next launch) read the device copy
+            if (call_copy && lane < 4) reinterpret_cast<uint4*>(call_copy + s)[lane] = reinterpret_cast<const uint4*>(call + s)[lane];
         }
-#ifndef HD_CU_NO_LATE_CONSUMERS
-        ring_consumer<T>(ra, geom, ctl, false, w);                       // the tail is done (and, for one of them, the loading): one more wave for the tap loops
-#endif
+        // the tail is done: one more worker -- its slot is the tail's own slice (a launch without tails: the ring region's slots 4-7)
+        ring_worker<T>(ra, n_tail ? tails + k * tail_bytes : slots + w * (uint32_t)kWorkSlotBytes, w);
     }
 }
 
-// Stage 1 ALONE in the same shape (synchronous delivery, the first half of a call whose tails run as a launch of their own): one
-// workgroup per CU, an LDS-DMA loader wave (n_loaders = 2: two, four slots each) with eight tile slots -- without tails in the CU's LDS there is
-// room for eight -- and computing waves in all the others.  512 MiB of IQ in 107-112 us where the single-wave grid (k_decimate<32,212,64>) takes
-// 118-123.  D = 8: the same kernel for the /8 first stage of /16 plans (ring_consumer: four outputs per lane row).
+// Stage 1 ALONE in the same shape (synchronous delivery, the first half of a call whose tails run as a launch of their own): one workgroup per CU.
+// D = 32: eight worker waves, each with its own slot (ring_worker).  D = 8 (the /8 first stage of /16 plans, four outputs per lane row) and D = 4 (the
+// only stage of a /4 plan, eight outputs per lane): a lane's window spans several rows there and the slot stays busy while it is summed, so these keep
+// the loader / consumer arrangement -- one or two LDS-DMA loader waves with up to eight tile slots between them, computing waves in all the others.
 template <int T, int D>
-__global__ __launch_bounds__(D == 8 ? 512 : 1024) void k_stage1_cu(const RingArgs ra, const uint32_t n_loaders, const uint32_t n_slots /* 2 .. 8 */)
+__global__ __launch_bounds__(D == 4 ? 1024 : 512) void k_stage1_cu(const RingArgs ra, const uint32_t n_loaders, const uint32_t n_slots /* 2 .. 8 */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char cu_lds[];
+    if constexpr (D == 32) {
+        ring_worker<T>(ra, cu_lds + (threadIdx.x >> 6) * (uint32_t)kWorkSlotBytes, threadIdx.x >> 6);
+    } else {
     unsigned char* ring = cu_lds;
     RingCtl* ctl = reinterpret_cast<RingCtl*>(cu_lds + n_slots * ring_slot_bytes<T>());
     ring_ctl_init(ctl, n_loaders);
     __syncthreads();
-    // one loader per SIMD pair, the first computing wave beside a loader feeds the runs (roles as in k_step_cu; any placement fills every role)
+    // one loader per SIMD pair, the first computing wave beside a loader feeds the runs (roles by SIMD; any placement fills every role)
     const uint32_t simd = (__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4)) & 3u;
     uint32_t rank = 0;
     if ((threadIdx.x & 63u) == 0) rank = __hip_atomic_fetch_add(&ctl->simd_rank[simd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -723,10 +674,11 @@ __global__ __launch_bounds__(D == 8 ? 512 : 1024) void k_stage1_cu(const RingArg
         }
         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)pick);
     }
-    const RingGeom geom{ring, n_slots, nullptr, 0u, 0u, 0u};
+    const RingGeom geom{ring, n_slots};
     const uint32_t h0 = n_slots / 2u;                                    // two loaders: [0, h0) and [h0, n_slots)
-    if (w < n_loaders) ring_loader<T, D == 32 && kRingSystolic>(ra, geom, ctl, (n_loaders == 1u || w == 0u) ? 0u : h0, n_loaders == 1u ? n_slots : (w == 0u ? h0 : n_slots - h0), w);
+    if (w < n_loaders) ring_loader<T>(ra, geom, ctl, (n_loaders == 1u || w == 0u) ? 0u : h0, n_loaders == 1u ? n_slots : (w == 0u ? h0 : n_slots - h0), w);
     else ring_consumer<T, D>(ra, geom, ctl, w == 2, w);
+    }
 }
 
 // XCC ids seen by a grid of single-wave workgroups: the run counters of the step launches are per XCD and indexed by the hardware's id
@@ -850,7 +802,7 @@ bool launch_step(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, u
 // (stage1_ring.h: ring_adv); the smaller ratios keep tiles of 64 rows + halo, 2048 input samples each.
 uint32_t ring_tiles(int ratio, int ntaps, uint32_t n)
 {
-    if (ratio != 32 || !kRingSystolic) return n / 2048u;
+    if (ratio != 32) return n / 2048u;
     const uint32_t adv = 64u - (uint32_t)((ntaps - 1 + 31) / 32);
     return n / 32u >= 64u ? ring_sys_tiles(n, adv) : 0u;
 }
@@ -862,30 +814,26 @@ static bool ring_limits_ok(uint32_t ntiles, const StepClaim& claim)
     return ntiles && ntiles <= 4096u && claim.run_len && ntiles % claim.run_len == 0 && total < (1ull << 24) && total / ntiles <= (1ull << 20);
 }
 
-uint32_t step_cu_tail_lds(int ratio, int ntaps, uint32_t n_slots)
+uint32_t step_cu_tail_lds(int ratio, int ntaps)
 {
-    auto lim = [&](int slot) { const uint32_t rb = n_slots * (uint32_t)slot + (uint32_t)kRingCtlBytes, left = rb < 163840u ? (163840u - rb) / 4u : 16u; return (left < kStepLdsBytes ? left : kStepLdsBytes) & ~15u; };
-    if (n_slots != 4u && n_slots != 5u) return 0;
-    if (ratio == 32 && ntaps == 212) return lim(ring_slot_bytes<212>());
-    if (ratio == 32 && ntaps == 174) return lim(ring_slot_bytes<174>());
-    return 0;
+    if (ratio != 32 || (ntaps != 212 && ntaps != 174)) return 0;
+    return ((163840u - (uint32_t)kRingCtlBytes - 4u * (uint32_t)kWorkSlotBytes) / 4u) & ~15u;      // four worker slots + four tail slices fill the CU's 160 KB
 }
 
 bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, uint32_t n_streams, uint32_t n_cus, const float2* in, size_t in_stride,
                     const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
-                    StreamCall* call_copy, const TailArgs& ta, uint32_t n_tail, uint32_t uniform_n, const StepClaim& claim, uint32_t tail_bytes, unsigned int* gave_up, uint32_t n_loaders, uint32_t n_slots,
+                    StreamCall* call_copy, const TailArgs& ta, uint32_t n_tail, uint32_t uniform_n, const StepClaim& claim, uint32_t tail_bytes,
                     hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    if (n_loaders != 1u) n_loaders = 2u;
-    if (n_slots != 5u || n_loaders != 1u) n_slots = 2u * (uint32_t)kRingNSL;
-    if (!n_tail && n_loaders == 1u && n_slots == 5u) n_slots = 8u;          // a launch without tails (the first after a flush): the whole CU's LDS is tile slots
     if (ratio != 32 || !claim.ctr || !uniform_n || uniform_n % 2048u) return false;
     const uint32_t ntiles = ring_tiles(ratio, ntaps, uniform_n);
     if (!ring_limits_ok(ntiles, claim)) return false;
-    RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, ntiles, claim, gave_up, nullptr, 0u, nullptr};
+    if (tail_bytes < (uint32_t)kWorkSlotBytes) tail_bytes = (uint32_t)kWorkSlotBytes;       // (a finished tail's slice is its wave's tile slot)
+    tail_bytes = (tail_bytes + 15u) & ~15u;
+    RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, ntiles, claim, nullptr, nullptr, 0u, nullptr};
 #define HD_CU_CASE(T, D2, T2)                                                                                                         \
     if (ntaps == T && ratio2 == D2 && ntaps2 == T2) {                                                                                 \
-        const uint32_t lds = n_slots * (uint32_t)ring_slot_bytes<T>() + (uint32_t)kRingCtlBytes + (n_tail ? 4u * tail_bytes : 0u);        \
+        const uint32_t lds = (uint32_t)kRingCtlBytes + (n_tail ? 4u * (uint32_t)kWorkSlotBytes + 4u * tail_bytes : 8u * (uint32_t)kWorkSlotBytes); \
         if (lds > 163840u) return false;                                                                                              \
         static bool attr_set[64] = {};                             /* per device: the attribute belongs to the function on the current device */ \
         int dev_ = 0;                                                                                                                 \
@@ -896,8 +844,8 @@ bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2
         }                                                                                                                             \
         const dim3 grid_(n_cus > (n_streams + 3u) / 4u ? n_cus : (n_streams + 3u) / 4u);                                             \
         /* events handed to the launch ride on the dispatch packet's own completion signal: no barrier packet behind the kernel */     \
-        if (ev_start || ev_stop) hipExtLaunchKernelGGL((k_step_cu<T, D2, T2>), grid_, dim3(64 * HD_CU_WAVES), lds, st, ev_start, ev_stop, 0u, ra, call, call_copy, ta, n_tail, n_streams, tail_bytes, n_loaders, n_slots); \
-        else hipLaunchKernelGGL((k_step_cu<T, D2, T2>), grid_, dim3(64 * HD_CU_WAVES), lds, st, ra, call, call_copy, ta, n_tail, n_streams, tail_bytes, n_loaders, n_slots); \
+        if (ev_start || ev_stop) hipExtLaunchKernelGGL((k_step_cu<T, D2, T2>), grid_, dim3(512), lds, st, ev_start, ev_stop, 0u, ra, call, call_copy, ta, n_tail, n_streams, tail_bytes); \
+        else hipLaunchKernelGGL((k_step_cu<T, D2, T2>), grid_, dim3(512), lds, st, ra, call, call_copy, ta, n_tail, n_streams, tail_bytes); \
         return true;                                                                                                                  \
     }
     HD_CU_CASE(212, 2, 69) HD_CU_CASE(174, 4, 139)
@@ -934,8 +882,8 @@ bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, cons
     RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, ntiles, claim, gave_up, final_call, fir_hist_cap, fft_in};
 #define HD_S1_CASE(D, T)                                                                                                              \
     if (ratio == D && ntaps == T) {                                                                                                   \
-        static_assert((uint32_t)ring_bytes<T, kRingNSLAlone>() <= 163840u, "eight tile slots must fit a CU's LDS");                   \
-        const uint32_t lds = n_slots * (uint32_t)ring_slot_bytes<T>() + (uint32_t)kRingCtlBytes;                                                        \
+        static_assert(D == 32 || (uint32_t)ring_bytes<T, kRingNSLAlone>() <= 163840u, "eight tile slots must fit a CU's LDS");       \
+        const uint32_t lds = D == 32 ? 8u * (uint32_t)kWorkSlotBytes : n_slots * (uint32_t)ring_slot_bytes<T>() + (uint32_t)kRingCtlBytes; \
         static bool attr_set[64] = {};                                                                                                \
         int dev_ = 0;                                                                                                                 \
         if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return false;                                                \
@@ -943,7 +891,7 @@ bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, cons
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_stage1_cu<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) return false; \
             attr_set[dev_] = true;                                                                                                    \
         }                                                                                                                             \
-        hipLaunchKernelGGL((k_stage1_cu<T, D>), dim3(n_cus), dim3(64u * (D == 8 ? 8u : n_waves)), lds, st, ra, n_loaders, n_slots);           \
+        hipLaunchKernelGGL((k_stage1_cu<T, D>), dim3(n_cus), dim3(64u * (D == 4 ? n_waves : 8u)), lds, st, ra, n_loaders, n_slots);   \
         return true;                                                                                                                  \
     }
     HD_S1_CASE(32, 212) HD_S1_CASE(32, 174) HD_S1_CASE(8, 54) HD_S1_CASE(4, 139)

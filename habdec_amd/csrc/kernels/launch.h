@@ -106,14 +106,13 @@ bool launch_step(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, u
                  StreamCall* call_copy, uint32_t stage1_wgs, const TailArgs& ta, uint32_t n_tail,
                  uint32_t uniform_n /* != 0: the streams' common sample count, and no stream restarts its stage-1 history this call */,
                  const StepClaim& claim = StepClaim{});
-// The same step as ONE 512-thread workgroup per CU (k_step_cu, decimate.hip): LDS-DMA loader + consumer waves for stage 1 (stage1_ring.h), the
-// tails in the other four waves.  Needs a /32 first stage, equally sized pushes that are a multiple of 2048 samples, drawn runs (claim.ctr) and
-// no history restart; returns false otherwise (the caller then launches k_step).  tail_bytes: LDS slice of one tail (<= step_cu_tail_lds).
+// The same step as ONE 512-thread workgroup per CU (k_step_cu, decimate.hip): four stage-1 worker waves (stage1_ring.h: ring_worker -- LDS-DMA into the
+// wave's own slot, systolic tap loop) and the tails in the other four waves, which become workers when they are done.  Needs a /32 first stage, equally
+// sized pushes that are a multiple of 2048 samples, drawn runs (claim.ctr) and no history restart; returns false otherwise (the caller then launches
+// k_step).  tail_bytes: LDS slice of one tail (<= step_cu_tail_lds).
 bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, uint32_t n_streams, uint32_t n_cus, const float2* in, size_t in_stride,
                     const float2* hist_in, float2* hist_out, const float* taps, float2* out, size_t out_stride, const StreamCall* call,
                     StreamCall* call_copy, const TailArgs& ta, uint32_t n_tail, uint32_t uniform_n, const StepClaim& claim, uint32_t tail_bytes,
-                    unsigned int* gave_up /* mapped host word, see RingArgs */, uint32_t n_loaders /* 1 or 2 LDS-DMA waves per CU */,
-                    uint32_t n_slots = 4 /* tile slots in the ring region */,
                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr /* signalled by the dispatch itself (hipExtLaunchKernel), not by a packet behind it */);
 // Stage 1 alone in the same shape (eight tile slots, one loader wave and seven computing waves by default): a /32 or /8 first stage, equally sized pushes that are a multiple of 2048
 // samples, drawn runs, no history restart; false otherwise (the caller then launches k_decimate).  The call's parameter block is not copied.
@@ -126,7 +125,7 @@ bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, cons
                       uint32_t n_slots = 8 /* tile slots (2 per loader .. 8): fewer leave LDS for the other queue's kernels */,
                       const StreamCall* final_call = nullptr /* /4 only: the stage is the final one of a single-stage plan -- per-stream pend_before / fft_take / fft_fill */,
                       uint32_t fir_hist_cap = 0, float2* fft_in = nullptr);
-uint32_t step_cu_tail_lds(int ratio, int ntaps, uint32_t n_slots = 4);   // LDS a tail may use inside k_step_cu beside n_slots (4, 5) tile slots of that first stage; 0 = no such kernel
+uint32_t step_cu_tail_lds(int ratio, int ntaps);   // LDS a tail may use inside k_step_cu beside the four worker slots of that first stage; 0 = no such kernel
 uint32_t probe_xcc_mask(hipStream_t st, uint32_t n_cus, unsigned int* d_word);   // bit x set = some workgroup of a chip-filling grid ran on XCC id x
 uint32_t step_lds_bytes(int ratio, int ntaps);   // LDS of a step-launch workgroup for that first stage (its tile, at least kStepLdsBytes); 0 = no step kernel
 constexpr uint32_t kStepLdsBytes = 20480;   // LDS of a stage-1 workgroup slot (eight per CU): what a tail riding in the stage-1 launch may use

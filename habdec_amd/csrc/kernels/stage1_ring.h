@@ -48,27 +48,20 @@ typedef float r_f32x2 __attribute__((ext_vector_type(2)));
 typedef float r_f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kRingRowBytes = 272;                  // 32 samples + one 16-byte pad
-#ifndef HD_RING_NSL
-#define HD_RING_NSL 2
-#endif
-constexpr int kRingNSL = HD_RING_NSL;                 // tile slots per loader wave in a step launch (beside four stream tails: what fits)
-constexpr int kRingNSLAlone = 4;                      // ... when stage 1 has the CU to itself (k_stage1_cu)
+constexpr int kRingNSLAlone = 4;                      // tile slots per loader wave of the loader / consumer kernels (k_stage1_cu at /8 and /4: eight slots)
+constexpr int kWorkSlotBytes = 64 * kRingRowBytes;    // a worker wave's tile slot (ring_worker: the /32 stages): 64 padded rows
 constexpr int kRingCtlBytes = 384;                 // (256 bytes of RingCtl; every 16 bytes count when a fifth tile slot has to fit beside four tails)
 constexpr uint32_t kRingSpinLimit = 1u << 22;   // polls before a waiting wave gives up (seconds; a correct run waits microseconds)
 template <int T> constexpr int ring_halo_rows() { return (T - 1 + 31) / 32; }
 template <int T> constexpr int ring_slot_bytes() { return (64 + ring_halo_rows<T>()) * kRingRowBytes; }
-template <int T, int NSL = kRingNSL> constexpr int ring_bytes() { return 2 * NSL * ring_slot_bytes<T>() + kRingCtlBytes; }   // NSL ring slots per loader
+template <int T, int NSL = kRingNSLAlone> constexpr int ring_bytes() { return 2 * NSL * ring_slot_bytes<T>() + kRingCtlBytes; }   // NSL ring slots per loader
 // The /32 stages run the SYSTOLIC tap loop (ring_consumer): a lane keeps only ITS row of 32 samples in registers and the accumulators travel from
 // lane to lane, so the 64 rows of a tile yield 64 - HR outputs (the sums that would wrap past lane 63 belong to the next tile) and consecutive
 // tiles of a stream advance by that many rows: tile k holds rows [origin, origin + 64) of the stream's history-extended row sequence (rows 0 .. HR-1
 // are the stage history), origin = min(k * ADV, R - ADV) with R = n / 32 rows in the call -- the last tile is pulled back so that it ends with the
 // call's last row and never reads past the stream's input; the outputs it shares with its neighbour are computed twice, identically.
 template <int T> constexpr int ring_adv() { return 64 - ring_halo_rows<T>(); }
-#ifdef HD_RING_CLASSIC
-constexpr bool kRingSystolic = false;
-#else
-constexpr bool kRingSystolic = true;
-#endif
+
 __host__ __device__ constexpr uint32_t ring_sys_tiles(uint32_t n, uint32_t adv) { return (n / 32u + adv - 1u) / adv; }
 
 #ifdef HD_STAMP_RING   // diagnostic build only (tools/micro/ring_stamps.py): where the loader and the consumers of k_step_cu spend their cycles
@@ -100,12 +93,11 @@ struct RingCtl {
     uint32_t live;          // loader waves that may still publish
     uint32_t run_tail;      // runs the feeding consumer has put into run_q so far
     uint32_t run_head;      // runs the loaders have claimed (fetch-add)
-    uint32_t late_loader;   // step launch: finished tail waves that have asked to become the second loader (the first one does)
+    uint32_t _pad0;
     uint32_t run_q[4];      // drawn run numbers (0xFFFFFFFF: no more)
     uint32_t simd_rank[4];  // waves of the workgroup that have arrived on each SIMD (role assignment, k_step_cu)
     uint32_t roles_taken;   // bit w: role w has a wave
-    uint32_t tail_mask;     // bit k: tail slice k holds no tail any more (or never did): the loaders may land tiles in the extra slots that lie in it
-    uint32_t _pad[2];
+    uint32_t _pad[3];
 };
 static_assert(sizeof(RingCtl) <= kRingCtlBytes, "ring control block");
 // first thing in the kernel, before the workgroup's first barrier: everything zero (every slot FREE), `live` = the loaders that exist from the start
@@ -115,46 +107,10 @@ __device__ __forceinline__ void ring_ctl_init(RingCtl* ctl, const uint32_t n_liv
     if (i < (uint32_t)kRingCtlBytes / 4u) reinterpret_cast<uint32_t*>(ctl)[i] = i == (uint32_t)offsetof(RingCtl, live) / 4u ? n_live : 0u;
 }
 
-// Where the tile slots are.  Global slot j < nb: ring + j * SLOT, the ring region proper; slot nb + i (i < ne), inside a step launch: the i-th
-// extra slot, xoff(i) bytes into the LDS slices of the stream tails, usable once every tail whose slice it touches is done (RingCtl::tail_mask).
-// A slice at least a slot long is a slot of its own (the four-slot layouts); shorter slices (the five-slot layout: 16 720-byte tails, 19 312-byte
-// slots) are taken in neighbouring pairs -- three slots out of four slices, the launch's second half on eight slots instead of five.  A loader owns
-// a contiguous range of global slots (ring_loader's slot0, nslots).
+// Where the tile slots of a loader / consumer kernel are: slot j < nb at ring + j * SLOT.  A loader owns a contiguous range of them.
 struct RingGeom {
     unsigned char* ring; uint32_t nb;
-    unsigned char* extra; uint32_t ne;
-    uint32_t xstride;       // extra slot i starts (i * xstride) & ~15 bytes into the tails' region (a formula, not a table: the struct must stay in registers)
-    uint32_t xslice;        // bytes per tail slice (which tails an extra slot waits for follows from where it lies)
 };
-
-// The extra slots of a step launch: `tail_bytes` per slice, four slices, `slot` bytes per tile slot, `room` = how many extra slots the loaders can watch
-__device__ __forceinline__ void ring_extra_slots(RingGeom& g, const uint32_t tail_bytes, const uint32_t slot, const uint32_t room, const bool tails_present)
-{
-    g.ne = 0; g.xstride = 0; g.xslice = tail_bytes;
-    if (!tails_present || !room) return;
-    uint32_t n = 0;
-    if (tail_bytes >= slot) {                               // a slice is a slot
-        n = room < 4u ? room : 4u;
-        g.xstride = tail_bytes;
-    } else {                                                // slots across neighbouring slices, spread over the region (first at its start, last at its end)
-        n = 4u * tail_bytes / slot;
-        if (n > room) n = room;
-        if (n > 4u) n = 4u;
-        g.xstride = n > 1u ? (4u * tail_bytes - slot) / (n - 1u) : 0u;
-    }
-    g.ne = n;
-}
-__device__ __forceinline__ uint32_t ring_extra_off(const RingGeom& g, const uint32_t i) { return (i * g.xstride) & ~15u; }
-template <int SLOT>
-__device__ __forceinline__ uint32_t ring_extra_need(const RingGeom& g, const uint32_t i)       // bits of RingCtl::tail_mask
-{
-    const uint32_t off = ring_extra_off(g, i);
-    uint32_t m = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (off < (uint32_t)(k + 1) * g.xslice && off + (uint32_t)SLOT > (uint32_t)k * g.xslice) m |= 1u << k;
-    return m;
-}
 
 struct RingArgs {
     const float2* in; size_t in_stride;             // this call's IQ slab
@@ -252,23 +208,18 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p)
 // ---------------------------------------------------------------------------------------------------------------- a loader wave
 // The calling wave has been counted in RingCtl::live (ring_ctl_init for the loaders that exist from the start; a late one counts itself in,
 // k_step_cu).  It owns the global slots [slot0, slot0 + nslots), nslots <= 8.
-template <int T, bool SYS = kRingSystolic /* tiles of the systolic tap loop (the /32 stages): 64 rows advancing by ring_adv<T>() */>
+template <int T>
 __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& geo, RingCtl* __restrict__ ctl, const uint32_t slot0, const uint32_t nslots,
                                             const uint32_t stamp_row /* diagnostic builds */)
 {
     constexpr int HR = ring_halo_rows<T>();
-    constexpr uint32_t ADV = (uint32_t)ring_adv<T>();
     constexpr int SLOT = ring_slot_bytes<T>();
     constexpr int NBODY = 17;                       // 64 rows x 17 chunks = 17 x 64 chunks
     constexpr int NHALO = (HR * 17 + 63) / 64;      // halo rows out of the stream itself (every tile but a stream's first)
     const uint32_t lane = threadIdx.x & 63u;
-    // lane j < nslots watches my slot j (global slot slot0 + j): where it is, and which tails must be done before it may be used (none for the ring region's slots)
+    // lane j < nslots watches my slot j (global slot slot0 + j)
     const uint32_t gs = slot0 + lane;
-    uint32_t my_dst = lds_addr_of(geo.ring) + gs * (uint32_t)SLOT, my_need = 0;
-    if (gs >= geo.nb && lane < nslots) {
-        my_dst = lds_addr_of(geo.extra) + ring_extra_off(geo, gs - geo.nb);
-        my_need = ring_extra_need<SLOT>(geo, gs - geo.nb);
-    }
+    const uint32_t my_dst = lds_addr_of(geo.ring) + gs * (uint32_t)SLOT;
 
     // per-lane source offsets (bytes from the tile's first body row / first halo row)
     uint32_t boff[NBODY], hoff[NHALO], hist_off[HR];
@@ -302,13 +253,9 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
 
     for (;;) {
         RSTAMP(0);
-        // ---- one look at my slots' words (and at which tails are done, for the slots that lie in their slices): the only LDS round trip of an iteration
+        // ---- one look at my slots' words: the only LDS round trip of an iteration
         unsigned long long w = 0;
-        uint32_t tm = 0;
-        if (lane < nslots) {
-            w = __hip_atomic_load(&ctl->slot[gs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (my_need) tm = __hip_atomic_load(&ctl->tail_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        if (lane < nslots) w = __hip_atomic_load(&ctl->slot[gs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // A published slot is mine again once its consumer has stored FREE (its lanes' rows are in registers by then).  (Looked at BEFORE this iteration
         // publishes anything: the word of a slot whose tile is still on its way says FREE too -- the loader writes nothing when it issues.)
         if (my_state == 2u && (uint32_t)(w >> 32) == kSlotFree) my_state = 0u;
@@ -356,28 +303,15 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
                 }
             }
         }
-        // which of my slots can take a tile?  (a slot in the tails' slices only once those tails are done)
+        // which of my slots can take a tile?
         unsigned long long free_mask = 0;
         if (have && issued - landed < max_fly && inflight_instr + (uint32_t)(NBODY + (HR > NHALO ? HR : NHALO)) <= 63u)
-            free_mask = __ballot(lane < nslots && my_state == 0u && (tm & my_need) == my_need);
+            free_mask = __ballot(lane < nslots && my_state == 0u);
         if (free_mask) {
             const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(free_mask));      // my slot number; global slot slot0 + slot
             const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)my_dst, (int)slot);
             if (lane == slot) { my_state = 1u; my_desc = (s << 12) | tile; }
             uint32_t cnt = NBODY;
-            if constexpr (SYS) {
-                // a systolic tile is 64 consecutive rows of the stream: the stage history + the call's first rows for tile 0 (which lands HR rows
-                // deeper in the slot: the slot's last HR rows are there for that), seventeen back-to-back instructions out of the input otherwise
-                const unsigned char* in_s = reinterpret_cast<const unsigned char*>(a.in + (size_t)s * a.in_stride);
-                if (tile == 0) {
-                    glds4_rows<HR>(reinterpret_cast<const unsigned char*>(a.hist_in + (size_t)s * (T - 1)), hist_off, dst);
-                    glds16_x17(in_s, boff, dst + (uint32_t)(HR * kRingRowBytes));
-                    cnt += HR;
-                } else {
-                    const uint32_t rows = a.n / 32u, origin = tile * ADV < rows - ADV ? tile * ADV : rows - ADV;
-                    glds16_x17(in_s + (size_t)(origin - (uint32_t)HR) * 256u, boff, dst);
-                }
-            } else {
             const unsigned char* body = reinterpret_cast<const unsigned char*>(a.in + (size_t)s * a.in_stride) + (size_t)tile * (64u * 256u);
             if (tile == 0) {
                 const unsigned char* hb = reinterpret_cast<const unsigned char*>(a.hist_in + (size_t)s * (T - 1));
@@ -392,7 +326,6 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
                 cnt += NHALO;
             }
             glds16_x17(body, boff, dst + (uint32_t)(HR * kRingRowBytes));
-            }
             fifo |= (unsigned long long)cnt << (8u * (issued - landed));
             sfifo |= (unsigned long long)(slot0 + slot) << (8u * (issued - landed));
             inflight_instr += cnt;
@@ -502,17 +435,15 @@ __device__ __forceinline__ void ring_slot1(r_f32x2& acc, const r_f32x2 smp, cons
 template <class F, int... I>
 __device__ __forceinline__ void ring_for_each_index(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 
-template <int T, int D = 32>
+template <int T, int D>
 __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom& geo, RingCtl* __restrict__ ctl, const bool feeder,
                                               const uint32_t role /* the wave's role number in the workgroup (diagnostic builds: its row in the stamp table) */)
 {
     constexpr int HR = ring_halo_rows<T>();
     constexpr int JS = HR * 32 - (T - 1);           // slot of tap 0, counted from column 0 of the lane's first row
-    constexpr int NS = JS + T;                      // taps sit on slots [JS, NS)
-    constexpr int C0 = JS / 16, C1 = (NS - 1) / 16; // first and last 16-slot chunk that carries taps
-    static_assert(D != 32 || C1 - C0 >= 3, "filter shorter than four chunks");
-    static_assert(D == 32 || D == 16 || D == 8 || D == 4 || D == 2, "a lane's row of 32 samples is 32 / D outputs");
-    static_assert(D == 32 || T <= 64 || (32 / D) % 8 == 0, "long filters of the small ratios: outputs in groups of eight");
+    constexpr int C0 = JS / 16;                     // first 16-slot chunk that carries taps
+    static_assert(D == 16 || D == 8 || D == 4 || D == 2, "a lane's row of 32 samples is 32 / D outputs (the /32 stages run ring_worker)");
+    static_assert(T <= 64 || (32 / D) % 8 == 0, "long filters of the small ratios: outputs in groups of eight");
     const uint32_t lane = threadIdx.x & 63u;
     typedef const float __attribute__((address_space(4)))* ctaps_t;
     const ctaps_t taps = (ctaps_t)(uintptr_t)a.taps - JS;                                   // taps[slot]
@@ -566,7 +497,7 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
         }
     };
 
-    const uint32_t n_slots_all = geo.nb + geo.ne;   // (at most sixteen: RingCtl::slot)
+    const uint32_t n_slots_all = geo.nb;            // (at most sixteen: RingCtl::slot)
     const uint32_t look_from = (role * 5u) & 15u;   // the waves of a CU start looking at different slots: fewer of them go for the same READY word
     for (;;) {
         RSTAMP(2);
@@ -610,154 +541,9 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
         }
         RSTAMP(0);
         const uint32_t plo = (uint32_t)pw, s = plo >> 12, tile = plo & 0xFFFu;
-        const unsigned char* p = (slot < geo.nb ? geo.ring + slot * (uint32_t)ring_slot_bytes<T>() : geo.extra + ring_extra_off(geo, slot - geo.nb)) + lane * (uint32_t)kRingRowBytes;
+        const unsigned char* p = geo.ring + slot * (uint32_t)ring_slot_bytes<T>() + lane * (uint32_t)kRingRowBytes;
 
-        if constexpr (D == 32 && kRingSystolic) {
-        // The SYSTOLIC tap loop.  Output o of the stream is the sum over the rows o .. o + HR of the history-extended row sequence (its window starts at
-        // slot JS of row o and ends with slot 0 of row o + HR).  Lane l holds row origin + l of the tile -- ITS 32 samples, sixteen 16-byte LDS reads, all
-        // that is read of the tile (a lane that walks its output's whole window reads 6.6 x as much: round 4 counted 63 % of a CU's LDS traffic there) --
-        // and the ACCUMULATORS move: the sum of output origin + o starts in lane o, takes the taps that fall on that lane's row, and is handed to lane
-        // o + 1 (one DPP rotate per component) for the next row.  Every sum still receives its T products in ascending tap order, separately rounded:
-        // bit-identical to the lane-owns-the-window loop by construction.  After HR hand-overs lane l >= HR holds output origin + l - HR; the sums that
-        // wrapped past lane 63 are the next tile's (ring_adv).  Measured bare (tools/micro/taploop.hip, mode 4): 2510 ticks per 64 rows against 3280.
-        constexpr uint32_t ADV = (uint32_t)ring_adv<T>();
-        const uint32_t rows = a.n / 32u, origin = tile * ADV < rows - ADV ? tile * ADV : rows - ADV;
-        // taps of the sixteen slots [16 c, 16 c + 16) of the lane-relative slot sequence as eight scalar pairs; slots outside [JS, NS) carry no tap
-        auto ldk = [&](r_f32x2 (&k)[8], auto cc) {
-            constexpr int c = decltype(cc)::value;
-#pragma unroll
-            for (int j = 0; j < 16; j += 2) {
-                k[j >> 1].x = (16 * c + j >= JS && 16 * c + j < NS) ? taps[16 * c + j] : 0.f;
-                k[j >> 1].y = (16 * c + j + 1 >= JS && 16 * c + j + 1 < NS) ? taps[16 * c + j + 1] : 0.f;
-            }
-        };
-        r_f32x2 kk[2][2][8];                            // [step parity][half row][pair]
-        r_f32x4 x[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) x[q] = *reinterpret_cast<const r_f32x4*>(p + 16 * q);
-        ldk(kk[0][0], std::integral_constant<int, 0>{}); ldk(kk[0][1], std::integral_constant<int, 1>{});   // (step 0's taps travel with the row)
-        __builtin_amdgcn_sched_barrier(0);
-        // The slot goes back to its loader as soon as the row is in registers -- before the arithmetic, not behind it: a slot is busy while its tile lands
-        // and for these sixteen reads.  (DS instructions of a wave execute in order: the store below cannot pass the reads; the statement keeps the compiler
-        // from moving it, or the reads, either way.)
-        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
-                          "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) :: "memory");
-        if (lane == 0) __hip_atomic_store(&ctl->slot[slot], (unsigned long long)kSlotFree << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        RSTAMP(3);
-        r_f32x2 acc = {0.f, 0.f};
-        // chunk c of the slot sequence = half h = c & 1 of the row of step c >> 1: all sixteen taps (the hand-scheduled form), or the few that exist
-        auto mac_chunk = [&](const r_f32x2 (&k)[8], auto cc) {
-            constexpr int c = decltype(cc)::value, j0 = JS > 16 * c ? JS - 16 * c : 0, j1 = NS < 16 * c + 16 ? NS - 16 * c : 16;
-            const r_f32x4 (&xh)[8] = reinterpret_cast<const r_f32x4 (&)[8]>(x[8 * (c & 1)]);
-            if constexpr (j0 == 0 && j1 == 16) ring_mac16_asm(acc, xh, k);
-            else {
-#pragma unroll
-                for (int j = j0; j < j1; ++j) {
-                    const r_f32x2 smp = (j & 1) ? xh[j >> 1].zw : xh[j >> 1].xy;
-                    acc = acc + smp * ((j & 1) ? k[j >> 1].y : k[j >> 1].x);
-                }
-            }
-        };
-        auto rot = [&]() {                              // lane l takes lane l - 1's sum (wave_ror:1)
-            // (through scalars: __builtin_bit_cast of an ext-vector ELEMENT reads the vector's first element whichever was named -- clang 20)
-            const float re = acc.x, im = acc.y;
-            acc.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, re), 0x13C, 0xF, 0xF, false));
-            acc.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, im), 0x13C, 0xF, 0xF, false));
-        };
-        // A step's taps are requested a step ahead through the scalar cache.  Scalar loads return out of order, so waiting for any of them waits for all
-        // that are outstanding: the wait for step r's taps (forced by `arrived`) therefore sits IN FRONT of the request for step r + 1's, which then has
-        // the whole of step r's arithmetic to come back; the scheduling barrier keeps the compiler from sinking the request to its use.
-        auto arrived = [&](const r_f32x2 (&k)[2][8]) {
-            asm volatile("" :: "s"(k[0][0]), "s"(k[0][1]), "s"(k[0][2]), "s"(k[0][3]), "s"(k[0][4]), "s"(k[0][5]), "s"(k[0][6]), "s"(k[0][7]),
-                               "s"(k[1][0]), "s"(k[1][1]), "s"(k[1][2]), "s"(k[1][3]), "s"(k[1][4]), "s"(k[1][5]), "s"(k[1][6]), "s"(k[1][7]));
-        };
-        ring_for_each_index([&](auto ri) {
-            constexpr int r = decltype(ri)::value;      // step r: the row's slots [32 r, 32 r + 32) of the slot sequence
-            arrived(kk[r & 1]);
-            if constexpr (r < HR) {
-                ldk(kk[(r + 1) & 1][0], std::integral_constant<int, 2 * r + 2>{});
-                ldk(kk[(r + 1) & 1][1], std::integral_constant<int, 2 * r + 3>{});
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (JS < 32 * r + 16) mac_chunk(kk[r & 1][0], std::integral_constant<int, 2 * r>{});
-            if constexpr (32 * r + 16 < NS && JS < 32 * r + 32) mac_chunk(kk[r & 1][1], std::integral_constant<int, 2 * r + 1>{});
-            if constexpr (r < HR) rot();
-        }, std::make_integer_sequence<int, HR + 1>{});
-#ifdef HD_STAMP_RING
-        asm volatile("" : "+v"(acc));
-        ++n_done;
-#endif
-        RSTAMP(1);
-        if (lane >= (uint32_t)HR) a.out[(size_t)s * a.out_stride + origin + lane - (uint32_t)HR] = make_float2(acc.x, acc.y);
-        if (tile + 1 == a.ntiles) {                 // the stream's last tile: carry the last T-1 inputs (Decimator.h:140-143)
-            const float2* in_s = a.in + (size_t)s * a.in_stride;
-            float2* hout = a.hist_out + (size_t)s * (T - 1);
-            for (uint32_t j = lane; j < (uint32_t)(T - 1); j += 64u) hout[j] = in_s[a.n - (T - 1) + j];
-        }
-        } else if constexpr (D == 32) {      // -DHD_RING_CLASSIC (A/B builds): a lane walks its output's whole window, tiles of 64 outputs
-        // the T-term sum in tap order: 16-slot chunks (half rows), the next chunk's samples and taps requested before the current one is summed
-        r_f32x2 acc = {0.f, 0.f};
-        r_f32x4 xa[8], xb[8];
-        r_f32x2 ka[8], kb[8];                       // the chunk's sixteen taps as eight pairs (wave-uniform: scalar registers)
-        auto rd = [&](r_f32x4 (&x)[8], r_f32x2 (&k)[8], const int c, auto j0, auto j1) {
-            const unsigned char* pc = p + coff(c);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) if (2 * q + 1 >= decltype(j0)::value && 2 * q < decltype(j1)::value) x[q] = *reinterpret_cast<const r_f32x4*>(pc + 16 * q);
-#pragma unroll
-            for (int j = 0; j < 16; j += 2) {
-                k[j >> 1].x = (j >= decltype(j0)::value && j < decltype(j1)::value) ? taps[c * 16 + j] : 0.f;
-                k[j >> 1].y = (j + 1 >= decltype(j0)::value && j + 1 < decltype(j1)::value) ? taps[c * 16 + j + 1] : 0.f;
-            }
-        };
-        auto mac_part = [&](const r_f32x4 (&x)[8], const r_f32x2 (&k)[8], auto j0, auto j1) {      // a chunk only part of whose slots carry taps
-#pragma unroll
-            for (int j = decltype(j0)::value; j < decltype(j1)::value; ++j) {
-                const r_f32x2 smp = (j & 1) ? x[j >> 1].zw : x[j >> 1].xy;
-                acc = acc + smp * ((j & 1) ? k[j >> 1].y : k[j >> 1].x);
-            }
-        };
-        using I0 = std::integral_constant<int, 0>;
-        using I16 = std::integral_constant<int, 16>;
-        using IFirst = std::integral_constant<int, JS % 16>;
-        using ILast = std::integral_constant<int, NS - 16 * C1>;
-        constexpr int NMID = C1 - C0 - 1;           // full chunks C0+1 .. C1-1
-        rd(xa, ka, C0, IFirst{}, I16{});
-        rd(xb, kb, C0 + 1, I0{}, I16{});
-        mac_part(xa, ka, IFirst{}, I16{});
-        int c = C0 + 1;                             // chunk c is in xb
-#pragma unroll 1
-        for (; c + 2 < C1; c += 2) {
-            rd(xa, ka, c + 1, I0{}, I16{});
-            ring_mac16_asm(acc, xb, kb);
-            rd(xb, kb, c + 2, I0{}, I16{});
-            ring_mac16_asm(acc, xa, ka);
-        }
-        if constexpr (NMID % 2 == 1) {              // chunk C1-1 is in xb, C1 follows
-            rd(xa, ka, C1, I0{}, ILast{});
-            ring_mac16_asm(acc, xb, kb);
-            mac_part(xa, ka, I0{}, ILast{});
-        } else {                                    // chunk C1-2 is in xb
-            rd(xa, ka, C1 - 1, I0{}, I16{});
-            ring_mac16_asm(acc, xb, kb);
-            rd(xb, kb, C1, I0{}, ILast{});
-            ring_mac16_asm(acc, xa, ka);
-            mac_part(xb, kb, I0{}, ILast{});
-        }
-        // every LDS read of the slot has returned (the sum used them): hand the slot back before the stores
-#ifdef HD_STAMP_RING
-        asm volatile("" : "+v"(acc));
-        ++n_done;
-#endif
-        RSTAMP(1);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&ctl->slot[slot], (unsigned long long)kSlotFree << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        a.out[(size_t)s * a.out_stride + (size_t)tile * 64u + lane] = make_float2(acc.x, acc.y);
-        if (tile + 1 == a.ntiles) {                 // the stream's last tile: carry the last T-1 inputs (Decimator.h:140-143)
-            const float2* in_s = a.in + (size_t)s * a.in_stride;
-            float2* hout = a.hist_out + (size_t)s * (T - 1);
-            for (uint32_t j = lane; j < (uint32_t)(T - 1); j += 64u) hout[j] = in_s[a.n - (T - 1) + j];
-        }
-        } else {
+        {
         // Smaller ratios: the lane's row of 32 samples is OPL = 32 / D adjacent outputs, output q taking the window that starts D * q
         // slots further on -- OPL independent sums (each its own T products in ascending tap order), one pass over the lane's
         // (OPL - 1) * D + T slots, the chunk loop unrolled with compile-time ranges (which taps of which output a 16-slot chunk carries).
@@ -870,6 +656,191 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
         }
         }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------- a worker wave (the /32 stages)
+// Round 5.  Rounds 3-4 split stage 1 into loader waves and computing waves around shared tile slots.  In-kernel clocks of a step launch said where that
+// ends: while the four stream tails of a CU run, its ONE loader wave is busy every cycle of the launch (two LDS round trips and seventeen DMA issues per
+// tile in one instruction stream, three tiles in flight at most: its 6-bit vmcnt) and the three computing waves wait for tiles 40 % of their time -- the
+// chip moves 2.8 TB/s of stage 1 until the tails are done, whatever the layout (NOTES.md, round 4).  With the systolic tap loop below a wave needs its
+// tile's LDS only until its lanes' rows are in registers, so every stage-1 wave can be its own loader: a WORKER owns one 64-row slot and walks runs of
+// tiles by itself --
+//     wait for my tile (s_waitcnt vmcnt(0)) -> sixteen ds_read_b128: my row -> issue the DMA of my NEXT tile into the same slot -> tap loop -> store
+// -- so the next tile is in flight while this one is summed, loads in flight scale with the waves that exist (four workers beside four tails, eight
+// once the tails are done: a finished tail wave becomes a worker whose slot is its own LDS slice), and there is NOTHING shared between the waves of a
+// CU: no publication words, no slot hand-over, no loader to feed, no wait that is not a hardware counter (the bounded-wait reports and the
+// fault-injection build concern the loader / consumer kernels of the smaller ratios only).  Runs of tiles come straight from the XCD's counter
+// (StepClaim): the draw for the next run is issued behind the DMA of the current run's last tile and read a tile later, behind the same wait.
+//
+// The SYSTOLIC tap loop.  Output o of the stream is the sum over the rows o .. o + HR of the history-extended row sequence (its window starts at slot JS
+// of row o and ends with slot 0 of row o + HR).  Lane l holds row origin + l of the tile -- ITS 32 samples, all that is read of the tile (a lane that
+// walks its output's whole window reads 6.6 x as much) -- and the ACCUMULATORS move: the sum of output origin + o starts in lane o, takes the taps that
+// fall on that lane's row, and is handed to lane o + 1 (one DPP rotate per component) for the next row.  Every sum still receives its T products in
+// ascending tap order, separately rounded: bit-identical to the lane-owns-the-window loop by construction.  After HR hand-overs lane l >= HR holds
+// output origin + l - HR; the sums that wrapped past lane 63 are the next tile's (ring_adv).
+template <int T>
+__device__ __forceinline__ void ring_worker(const RingArgs& a, unsigned char* __restrict__ slot, const uint32_t role /* diagnostic builds: the wave's row in the stamp table */)
+{
+    constexpr int HR = ring_halo_rows<T>();
+    constexpr uint32_t ADV = (uint32_t)ring_adv<T>();
+    constexpr int JS = HR * 32 - (T - 1);           // slot of tap 0, counted from column 0 of the lane's first row
+    constexpr int NS = JS + T;                      // taps sit on slots [JS, NS)
+    constexpr int NB0 = ((int)ADV * 17 + 63) / 64;  // DMA instructions for the ADV input rows of a stream's first tile
+    const uint32_t lane = threadIdx.x & 63u;
+    typedef const float __attribute__((address_space(4)))* ctaps_t;
+    const ctaps_t taps = (ctaps_t)(uintptr_t)a.taps - JS;                                   // taps[slot]
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr_of(slot));      // (wave-uniform: M0 takes it)
+    const unsigned char* p = slot + lane * (uint32_t)kRingRowBytes;
+    const uint32_t rows = a.n / 32u;
+    RSTAMP_DECL;
+    uint32_t n_done = 0; (void)n_done;
+
+    // per-lane source offsets of the seventeen DMA instructions of 64 rows (chunk P = 64 i + lane of the slot = column P % 17 of row P / 17; column 16,
+    // the pad, loads the row's last chunk again) and of the HR history rows of a stream's first tile (dword-wide: the history sits at odd 8-byte offsets)
+    uint32_t boff[17], hist_off[HR];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) { const uint32_t P = 64u * i + lane, row = P / 17u, col = P - row * 17u; boff[i] = row * 256u + (col < 16u ? col : 15u) * 16u; }
+#pragma unroll
+    for (int r = 0; r < HR; ++r) {
+        const int h = (r - HR) * 32 + (int)(lane >> 1) + (T - 1);                          // index into the T-1 history samples (< 0: in front of them, never read)
+        hist_off[r] = (uint32_t)(h < 0 ? 0 : h) * 8u + (lane & 1u) * 4u;
+    }
+    auto issue = [&](const uint32_t s, const uint32_t tile) {
+        const unsigned char* in_s = reinterpret_cast<const unsigned char*>(a.in + (size_t)s * a.in_stride);
+        if (tile == 0) {                            // rows 0 .. HR-1: the stage history; rows HR .. 63: the call's first ADV rows
+            glds4_rows<HR>(reinterpret_cast<const unsigned char*>(a.hist_in + (size_t)s * (T - 1)), hist_off, dst);
+#pragma unroll
+            for (int i = 0; i < NB0; ++i)
+                if (64 * (i + 1) <= (int)ADV * 17 || lane < (uint32_t)((int)ADV * 17 - 64 * i)) glds16(in_s, boff[i], dst + (uint32_t)(HR * kRingRowBytes) + 1024u * i);
+        } else {
+            const uint32_t origin = tile * ADV < rows - ADV ? tile * ADV : rows - ADV;
+            glds16_x17(in_s + (size_t)(origin - (uint32_t)HR) * 256u, boff, dst);
+        }
+    };
+
+    // runs of tiles from this XCD's counter (launch.h: StepClaim; the first ticket past the end resets the counter of the other set for the next launch)
+    const uint32_t xcd0 = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // XCC_ID
+    const uint32_t xcd = xcd0 < a.claim.n_xcd ? xcd0 : a.claim.n_xcd - 1;
+    unsigned int* my_ctr = a.claim.ctr + (size_t)xcd * 32;
+    unsigned int* next_ctr = a.claim.ctr_next + (size_t)xcd * 32;
+    const uint32_t runs = a.claim.runs_per_xcd, run_len = a.claim.run_len;
+    auto draw = [&]() -> unsigned int { unsigned int t = 0; if (lane == 0) t = __hip_atomic_fetch_add(my_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return t; };
+    uint32_t s = 0, tile = 0, left = 0;             // the run's cursor: (s, tile) is the next tile to issue, `left` of the run are still to be issued
+    auto take_run = [&](const unsigned int ticket) -> bool {          // the ticket's run, or false: the XCD's share is used up
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+        if (t == runs && lane == 0) (void)__hip_atomic_exchange(next_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t >= runs) return false;
+        const uint32_t g0 = (xcd * runs + t) * run_len;
+        s = g0 / a.ntiles; tile = g0 - s * a.ntiles; left = run_len;
+        return true;
+    };
+
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (a former tail wave: every LDS access of the tail has completed before DMA lands in its slice)
+    if (!take_run(draw())) { RSTAMP_WRITE(role, 0); return; }
+    uint32_t cs = s, ct = tile;                     // the tile in (or on its way into) my slot
+    issue(cs, ct); ++tile; --left;
+    unsigned int ticket = 0;                        // the draw in flight (lane 0's register) once the run's last tile has been issued
+    if (!left) ticket = draw();
+
+    // taps of the sixteen slots [16 c, 16 c + 16) of the lane-relative slot sequence as eight scalar pairs; slots outside [JS, NS) carry no tap
+    auto ldk = [&](r_f32x2 (&k)[8], auto cc) {
+        constexpr int c = decltype(cc)::value;
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            k[j >> 1].x = (16 * c + j >= JS && 16 * c + j < NS) ? taps[16 * c + j] : 0.f;
+            k[j >> 1].y = (16 * c + j + 1 >= JS && 16 * c + j + 1 < NS) ? taps[16 * c + j + 1] : 0.f;
+        }
+    };
+    for (;;) {
+        RSTAMP(2);
+        // my tile has landed (and my last store is acknowledged, and the ticket -- if one was drawn -- has arrived): the wave's only wait
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(ticket));            // (the compiler's scoreboard learns here, where it costs nothing, that the draw has returned -- or it waits for it
+                                                    // where the register is written next: behind the DMA of a run's last tile)
+        RSTAMP(0);
+        r_f32x2 kk[2][2][8];                        // [step parity][half row][pair]
+        r_f32x4 x[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = *reinterpret_cast<const r_f32x4*>(p + 16 * q);
+        ldk(kk[0][0], std::integral_constant<int, 0>{}); ldk(kk[0][1], std::integral_constant<int, 1>{});   // (step 0's taps travel with the row)
+        __builtin_amdgcn_sched_barrier(0);
+        // the rows are in registers: the slot can take the next tile at once -- its DMA flies while this tile is summed
+        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                          "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) :: "memory");
+        RSTAMP(3);
+        bool more = true;
+        if (!left) more = take_run(ticket);         // (drawn behind the DMA of the run's last tile: it arrived with that tile)
+        uint32_t ns = 0, nt = 0;
+        if (more) {
+            ns = s; nt = tile;
+            issue(ns, nt); ++tile; --left;
+            if (!left) ticket = draw();
+        }
+        RSTAMP(4);
+
+        const uint32_t origin = ct * ADV < rows - ADV ? ct * ADV : rows - ADV;
+        r_f32x2 acc = {0.f, 0.f};
+        // chunk c of the slot sequence = half h = c & 1 of the row of step c >> 1: all sixteen taps (the hand-scheduled form), or the few that exist
+        auto mac_chunk = [&](const r_f32x2 (&k)[8], auto cc) {
+            constexpr int c = decltype(cc)::value, j0 = JS > 16 * c ? JS - 16 * c : 0, j1 = NS < 16 * c + 16 ? NS - 16 * c : 16;
+            const r_f32x4 (&xh)[8] = reinterpret_cast<const r_f32x4 (&)[8]>(x[8 * (c & 1)]);
+            if constexpr (j0 == 0 && j1 == 16) ring_mac16_asm(acc, xh, k);
+            else {
+#pragma unroll
+                for (int j = j0; j < j1; ++j) {
+                    const r_f32x2 smp = (j & 1) ? xh[j >> 1].zw : xh[j >> 1].xy;
+                    acc = acc + smp * ((j & 1) ? k[j >> 1].y : k[j >> 1].x);
+                }
+            }
+        };
+        auto rot = [&]() {                              // lane l takes lane l - 1's sum (wave_ror:1)
+            // (through scalars: __builtin_bit_cast of an ext-vector ELEMENT reads the vector's first element whichever was named -- clang 20)
+            const float re = acc.x, im = acc.y;
+            acc.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, re), 0x13C, 0xF, 0xF, false));
+            acc.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, im), 0x13C, 0xF, 0xF, false));
+        };
+        // A step's taps are requested a step ahead through the scalar cache.  Scalar loads return out of order, so waiting for any of them waits for all
+        // that are outstanding: the wait for step r's taps (forced by `arrived`) therefore sits IN FRONT of the request for step r + 1's, which then has
+        // the whole of step r's arithmetic to come back; the scheduling barrier keeps the compiler from sinking the request to its use.
+        auto arrived = [&](const r_f32x2 (&k)[2][8]) {
+            asm volatile("" :: "s"(k[0][0]), "s"(k[0][1]), "s"(k[0][2]), "s"(k[0][3]), "s"(k[0][4]), "s"(k[0][5]), "s"(k[0][6]), "s"(k[0][7]),
+                               "s"(k[1][0]), "s"(k[1][1]), "s"(k[1][2]), "s"(k[1][3]), "s"(k[1][4]), "s"(k[1][5]), "s"(k[1][6]), "s"(k[1][7]));
+        };
+        ring_for_each_index([&](auto ri) {
+            constexpr int r = decltype(ri)::value;      // step r: the row's slots [32 r, 32 r + 32) of the slot sequence
+            arrived(kk[r & 1]);
+            if constexpr (r < HR) {
+                ldk(kk[(r + 1) & 1][0], std::integral_constant<int, 2 * r + 2>{});
+                ldk(kk[(r + 1) & 1][1], std::integral_constant<int, 2 * r + 3>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (JS < 32 * r + 16) mac_chunk(kk[r & 1][0], std::integral_constant<int, 2 * r>{});
+            if constexpr (32 * r + 16 < NS && JS < 32 * r + 32) mac_chunk(kk[r & 1][1], std::integral_constant<int, 2 * r + 1>{});
+            if constexpr (r < HR) rot();
+        }, std::make_integer_sequence<int, HR + 1>{});
+#ifdef HD_STAMP_RING
+        asm volatile("" : "+v"(acc));
+        ++n_done;
+#endif
+        RSTAMP(1);
+        if (lane >= (uint32_t)HR) a.out[(size_t)cs * a.out_stride + origin + lane - (uint32_t)HR] = make_float2(acc.x, acc.y);
+        if (ct + 1 == a.ntiles) {                   // the stream's last tile: carry the last T-1 inputs (Decimator.h:140-143)
+            // (all loads, then all stores: ONE wait -- which the DMA in flight has to see out anyway)
+            const float2* in_s = a.in + (size_t)cs * a.in_stride + (a.n - (uint32_t)(T - 1));
+            float2* hout = a.hist_out + (size_t)cs * (T - 1);
+            constexpr int NH = (T - 1 + 63) / 64;
+            float2 h[NH];
+#pragma unroll
+            for (int k = 0; k < NH; ++k) h[k] = in_s[lane + 64u * k < (uint32_t)(T - 1) ? lane + 64u * k : 0u];
+#pragma unroll
+            for (int k = 0; k < NH; ++k) if (lane + 64u * k < (uint32_t)(T - 1)) hout[lane + 64u * k] = h[k];
+        }
+        if (!more) break;
+        cs = ns; ct = nt;
+    }
+    RSTAMP(2);
+    RSTAMP_WRITE(role, n_done);
 }
 
 }  // namespace hd

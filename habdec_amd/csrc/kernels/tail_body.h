@@ -210,6 +210,39 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         prefetch(0);
         if (do_sums && (c0 & 63u)) carry_word = gmask[(c0 & rmask) >> 6] & ((1ull << (c0 & 63u)) - 1ull);
         constexpr int LB = 4;                                           // loads per lane in flight per batch
+        const bool special = c.fir_zero_hist || refold;               // history restarts from zeros / first run after a redesign
+        // The usual shape (a 161-tap low-pass, less than a batch pending, windows of a few hundred samples): EVERY load of the start-up goes out before the
+        // first of them is waited for -- one round trip.  Inside a step launch a global-memory instruction of this wave queues behind the stage-1 waves' tile
+        // loads (in-kernel clocks, round 5: the seven batches below, each waiting for its own loads before it stores them, took 27k of a tail's 200k cycles).
+        constexpr int NB2 = ((T2 + 7) / 4 * 4 + NT - 1) / NT;           // batches of NT for the stage-2 tap table
+        if (T + 8 <= 4u * NT && f_old <= 8u * NT && R <= 4u * NT && !special) {
+            float tt[4], t2[NB2], tv[4], tw[4];
+            float2 tf[8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t k = tid + u * NT; tt[u] = k < T ? tp[k] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < NB2; ++u) { const uint32_t k = tid + u * NT; t2[u] = k < (uint32_t)T2 ? a.taps2[k] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const uint32_t k = tid + u * NT; tf[u] = k < f_old ? cur[fhc - H + k] : make_float2(0.f, 0.f); }
+            if (do_sums) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const uint32_t k = tid + u * NT; tv[u] = k < take0 ? vring[(c0 + k) & rmask] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const uint32_t k = tid + u * NT; tw[u] = k < R ? gw[(c0 - R + k) & rmask] : 0.f; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t k = tid + u * NT; if (k < T + 8) TP[k] = tt[u]; }
+#pragma unroll
+            for (int u = 0; u < NB2; ++u) { const uint32_t k = tid + u * NT; if (k < (uint32_t)((T2 + 7) & ~3)) H2[k] = t2[u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const uint32_t k = tid + u * NT; if (k < f_old) F[k] = tf[u]; }
+            if (do_sums) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const uint32_t k = tid + u * NT; if (k < take0) V[k] = tv[u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const uint32_t k = tid + u * NT; if (k < R) WS[k] = tw[u]; }
+            }
+        } else {
 #pragma unroll 1
         for (uint32_t k0 = 0; k0 < T + 8; k0 += LB * NT) {
             float t[LB];
@@ -226,7 +259,6 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
 #pragma unroll
             for (int u = 0; u < LB; ++u) { const uint32_t k = k0 + tid + u * NT; if (k < (uint32_t)((T2 + 7) & ~3)) H2[k] = t[u]; }
         }
-        const bool special = c.fir_zero_hist || refold;               // history restarts from zeros / first run after a redesign
 #pragma unroll 1
         for (uint32_t k0 = 0; k0 < f_old; k0 += LB * NT) {
             float2 t[LB];
@@ -252,6 +284,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
 #pragma unroll
                 for (int u = 0; u < LB; ++u) { const uint32_t k = k0 + tid + u * NT; if (k < R) WS[k] = t[u]; }
             }
+        }
         }
 #pragma unroll
         for (int u = 0; u < HB; ++u) { const uint32_t k = tid + u * NT; if (k < (uint32_t)(T2 - 1)) X[k] = th[u]; }

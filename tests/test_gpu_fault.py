@@ -1,4 +1,5 @@
-"""The give-up path of the per-CU ring kernels, end to end: a fault-injection build of the SAME sources
+"""The give-up path of the loader / consumer ring kernels (k_stage1_cu at /8 and /4; the /32 stages' worker waves share nothing and wait for nothing
+but hardware counters), end to end, on a /16 plan: a fault-injection build of the SAME sources
 (habdec_amd/libhabdec_amd_fault.so, -DHD_RING_FAULT: one LDS-DMA loader of the process never publishes its second tile and stops; or -- the second
 mode -- one feeding wave stops handing out runs, so that its CU's loaders starve) must
 
@@ -36,10 +37,10 @@ def test_a_dropped_publish_is_reported_and_the_engine_stays_failed(pipeline):
     from habdec_amd import capi
     L = load_fault_lib()
     L.hd_debug_ring_fault_arm()                          # one loader of this process will drop one publish from here on
-    S, CH, fs = 64, 16384, 2.048e6
+    S, CH, fs = 64, 16384, 2.5e6
     cfg = capi.hd_engine_config()
     L.hd_engine_config_default(C.byref(cfg))
-    cfg.n_streams, cfg.max_chunk, cfg.sampling_rate, cfg.decimation, cfg.pipeline = S, CH, fs, 64, pipeline
+    cfg.n_streams, cfg.max_chunk, cfg.sampling_rate, cfg.decimation, cfg.pipeline = S, CH, fs, 16, pipeline
     h = C.c_void_p()
     assert L.hd_engine_create(C.byref(cfg), C.byref(h)) == 0, L.hd_last_error()
     iq = torch.randn((S, CH, 2), device="cuda", dtype=torch.float32) * 0.1
@@ -58,7 +59,7 @@ def test_a_dropped_publish_is_reported_and_the_engine_stays_failed(pipeline):
     L.hd_engine_destroy(h)
     # the device is fine: a fresh engine of the PRODUCT library decodes as usual right after
     import habdec_amd
-    eng = habdec_amd.Engine(n_streams=S, max_chunk=CH, sampling_rate=fs, decimation=64, pipeline=pipeline)
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=CH, sampling_rate=fs, decimation=16, pipeline=pipeline)
     for k in range(4):
         eng.process_device(iq.data_ptr(), CH, CH)
     eng.flush()
@@ -77,10 +78,10 @@ def test_starved_loaders_report_instead_of_waiting_forever(pipeline):
     if not hasattr(L, "hd_debug_ring_fault_arm_starve"):
         pytest.skip("fault-injection library without the starvation mode (rebuild it)")
     L.hd_debug_ring_fault_arm_starve()
-    S, CH, fs = 1024, 65536, 2.048e6                     # 144 tiles per CU: far more than two runs
+    S, CH, fs = 1024, 65536, 2.5e6                       # 128 tiles per CU: far more than two runs
     cfg = capi.hd_engine_config()
     L.hd_engine_config_default(C.byref(cfg))
-    cfg.n_streams, cfg.max_chunk, cfg.sampling_rate, cfg.decimation, cfg.pipeline = S, CH, fs, 64, pipeline
+    cfg.n_streams, cfg.max_chunk, cfg.sampling_rate, cfg.decimation, cfg.pipeline = S, CH, fs, 16, pipeline
     h = C.c_void_p()
     assert L.hd_engine_create(C.byref(cfg), C.byref(h)) == 0, L.hd_last_error()
     iq = torch.randn((S, CH, 2), device="cuda", dtype=torch.float32) * 0.1

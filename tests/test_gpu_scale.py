@@ -36,10 +36,11 @@ def headline_ring():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("shares", ["drawn", "drawn2", "fixed", "deep", "rocfft", "single_wave", "regs_run4", "two_loaders", "four_slots"])
+@pytest.mark.parametrize("shares", ["drawn", "drawn2", "fixed", "deep", "rocfft", "single_wave", "run9", "run12"])
 def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, shares):
-    """shares: which step kernel serves the batch and how its stage-1 tiles are handed out -- k_step_cu (one workgroup per CU: LDS-DMA loader
-    waves + computing waves, runs of eight tiles drawn from per-XCD counters: the default; "regs_run4": runs of four), or the single-wave
+    """shares: which step kernel serves the batch and how its stage-1 tiles are handed out -- k_step_cu (one workgroup per CU: stage-1 worker waves
+    that load their own tiles with LDS-DMA and sum them with the systolic tap loop, runs of four 57-output tiles drawn from per-XCD counters: the
+    default; "run9" / "run12": runs of nine / twelve), or the single-wave
     k_step ("single_wave"; "drawn2": with runs of two -- HD_STEP_RUN does not reach k_step_cu) -- or the fixed shares of HD_NO_CLAIM (the first call of a stream, which restarts its history, always takes fixed shares); "deep" = pipeline 2,
     three calls undelivered in the free-running stretch."""
     import habdec_amd
@@ -52,12 +53,8 @@ def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, s
         monkeypatch.setenv("HD_ROCFFT", "1")
     if shares == "single_wave":                              # round 2's step kernel (single-wave workgroups) instead of one workgroup per CU
         monkeypatch.setenv("HD_NO_CU_STEP", "1")
-    if shares == "regs_run4":                                # k_step_cu with four-tile runs (more run changes, more halo rows out of the history path)
-        monkeypatch.setenv("HD_RING_RUN", "4")
-    if shares == "two_loaders":                              # k_step_cu with an LDS-DMA wave on SIMD 0 and on SIMD 1, two slots each (the default is one loader)
-        monkeypatch.setenv("HD_RING_LOADERS", "2")
-    if shares == "four_slots":                               # one loader, four tile slots (the default since the tails' compact LDS carve is five)
-        monkeypatch.setenv("HD_CU_SLOTS", "4")
+    if shares in ("run9", "run12"):                          # k_step_cu with nine- / twelve-tile runs (fewer run changes; 36 tiles per stream and call)
+        monkeypatch.setenv("HD_RING_RUN", shares[3:])
     w, ring, ring_chunks = headline_ring
     S, fs = w["S"], w["fs"]
     # 7/8 of the streams are within +-200 Hz, every 8th is far off: sample both kinds (and the first / last stream of XCD blocks)
@@ -103,12 +100,8 @@ def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, s
             want[k][s] = (len(d), int(d.sum() & 0xFFFFFFFF), int((d * np.arange(1, len(d) + 1, dtype=np.uint64)).sum() & 0xFFFFFFFF))
         compare_delivered()
     assert eng.timing()["path"] == 3
-    # which step kernel: one workgroup per CU (loader + computing waves, stage1_ring.h) unless switched off or the runs are not drawn
+    # which step kernel: one workgroup per CU (worker waves, stage1_ring.h) unless switched off or the runs are not drawn
     assert eng.timing()["step_variant"] == (0 if shares in ("fixed", "single_wave") else 1), shares
-    # ... and with how many tile slots: five beside the compact 64-lane tails when one loader serves them, four with two loaders
-    import ctypes
-    slots = habdec_amd.lib().hd_debug_step_slots; slots.restype = ctypes.c_uint; slots.argtypes = [ctypes.c_void_p]
-    assert slots(eng.h) == (0 if shares in ("fixed", "single_wave") else 4 if shares in ("two_loaders", "four_slots") else 5), (shares, slots(eng.h))
     in_launch = min(len(v) for v in seen.values())           # calls whose tails rode in a step launch and were compared before the final flush
     assert in_launch >= n_free - 4, in_launch
     eng.flush()
@@ -125,7 +118,7 @@ def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, s
     eng.close()
 
 
-@pytest.mark.parametrize("kernel", ["per_cu", "per_cu_one_loader_12_waves", "single_wave_drawn", "single_wave"])
+@pytest.mark.parametrize("kernel", ["per_cu", "single_wave_drawn", "single_wave"])
 def test_stage1_alone_at_full_size(monkeypatch, headline_ring, kernel):
     """Synchronous calls (what the Decoder facade makes): stage 1 as a launch of its own, then the stream tails.  "per_cu": one workgroup per CU
     with two LDS-DMA loader waves, eight tile slots and six computing waves (k_stage1_cu, the default for a /32 first stage; one loader and twelve waves: the second variant); "single_wave_drawn":
@@ -135,9 +128,6 @@ def test_stage1_alone_at_full_size(monkeypatch, headline_ring, kernel):
     from oracle import pyoracle
     if not kernel.startswith("per_cu"):
         monkeypatch.setenv("HD_NO_CU_STEP", "1")
-    if kernel == "per_cu_one_loader_12_waves":
-        monkeypatch.setenv("HD_S1_LOADERS", "1")
-        monkeypatch.setenv("HD_S1_WAVES", "12")
     if kernel == "single_wave_drawn":
         monkeypatch.setenv("HD_CLAIM_ALONE", "1")
     w, ring, ring_chunks = headline_ring

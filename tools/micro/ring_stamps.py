@@ -17,19 +17,14 @@ n = 512 * 8 * 8
 st = np.zeros(n, np.uint64); f(st.ctypes.data, n); st = st.reshape(512, 8, 8).astype(np.float64)[:256]
 t0 = st[:, :, 6][st[:, :, 6] > 0].min()
 print("step kernel ms:", eng.timing()["ms_front"], "variant", eng.timing()["step_variant"])
-# rows: role 0 = the loader; roles 1-3 = computing waves; roles 4-7 = tail waves, of which the first to finish loads (its row then holds a loader's phases: the row
-# is written twice -- by ring_loader, then by ring_consumer -- and the consumer's record, written last, is what is read here)
-ld = st[:, 0]
-print("loader 0: tiles/CU p0/50/100", np.percentile(ld[:, 5], [0, 50, 100]).tolist(), " lifetime us p50/100", np.percentile((ld[:, 7] - ld[:, 6]) / 100, [50, 100]).round(1).tolist())
-tot = ld[:, :4].sum(axis=1)
-print("  cycles total p50 %.0f; per tile: publish %.0f issue %.0f take-run+check %.0f idle %.0f" % ((np.median(tot),) + tuple(np.median(ld[:, i] / np.maximum(ld[:, 5], 1)) for i in range(4))))
-for wv in (1, 2, 3, 4, 5, 6, 7):
+# rows: roles 0-3 = the stage-1 worker waves that exist from the start; roles 4-7 = the tail waves, workers once their tail is done (ring_worker's record)
+for wv in range(8):
     c = st[:, wv]
     if not (c[:, 5] > 0).any(): continue
     c = c[c[:, 5] > 0]
-    print("consumer %d: tiles p0/50/100 %s; per tile: wait %.0f row reads %.0f compute %.0f store+take %.0f; lifetime us p50 %.1f end us p100 %.1f" % (
-        wv, np.percentile(c[:, 5], [0, 50, 100]).tolist(), np.median(c[:, 0] / c[:, 5]), np.median(c[:, 3] / c[:, 5]), np.median(c[:, 1] / c[:, 5]), np.median(c[:, 2] / c[:, 5]),
-        np.median((c[:, 7] - c[:, 6]) / 100), ((c[:, 7] - t0) / 100).max()))
+    print("worker %d: tiles p0/50/100 %s; per tile: wait for landing %.0f row reads %.0f next run + DMA issue %.0f tap loop %.0f store + loop %.0f; lifetime us p50 %.1f end us p100 %.1f" % (
+        wv, np.percentile(c[:, 5], [0, 50, 100]).tolist(), np.median(c[:, 0] / c[:, 5]), np.median(c[:, 3] / c[:, 5]), np.median(c[:, 4] / c[:, 5]), np.median(c[:, 1] / c[:, 5]),
+        np.median(c[:, 2] / c[:, 5]), np.median((c[:, 7] - c[:, 6]) / 100), ((c[:, 7] - t0) / 100).max()))
 # when does each CU (workgroup) run out of work, and when did its tails hand over?  (realtime counter: 100 ticks per microsecond)
 ok = st[:, :, 7] > 0
 end_cu = np.where(ok, st[:, :, 7], 0).max(axis=1)
@@ -43,9 +38,9 @@ print("late waves (tails first): became computing waves at us p0/50/100", np.per
 per_xcd = [np.percentile((end_cu[x::8] - t0) / 100, 100) for x in range(8)]
 print("end us of the last workgroup per blockIdx %% 8:", np.round(per_xcd, 1).tolist())
 if os.environ.get("PER_CU"):
-    # one line per workgroup of two XCDs: when its waves ended (us), tiles taken by its first loader, when its tail waves turned to stage 1
+    # one line per workgroup of two XCDs: when its waves ended (us), tiles of worker 0, when its tail waves turned to stage 1
     for x in (0, 1):
-        print(f"-- workgroups with blockIdx % 8 == {x} (sorted by end): end us | loader-0 tiles | loader-0 end | tails done at us (four waves)")
+        print(f"-- workgroups with blockIdx % 8 == {x} (sorted by end): end us | worker-0 tiles | worker-0 end | tails done at us (four waves)")
         rows = []
         for b in range(x, 256, 8):
             rows.append(((end_cu[b] - t0) / 100, int(st[b, 0, 5]), (st[b, 0, 7] - t0) / 100, sorted(((st[b, 4:8, 6] - t0) / 100).round(0).tolist())))
