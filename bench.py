@@ -13,9 +13,16 @@ calls are undelivered and each call's text is delivered, in order, while the nex
 inside the timed region (hd_flush before the closing barrier).  --sync delivers every step's text before the next step
 starts, like Decoder::operator().  Metric: input complex samples consumed per second over all GPUs (IQ Msamples/s).
 
-In front of the W warm-up steps the loop runs --prewarm untimed steps of itself (default: whole passes over the ring, at least 120 steps): its first
-~150 launches run about 10 % below the rate it then sustains, whatever kept the GPU busy before, and the driver's timed
-region is 20 steps long.  The line says so (`prewarm_steps`); --prewarm 0 gives the old behaviour.
+TWO timed regions per run, in one process: `cold` -- K steps right behind the W warm-up steps, the protocol of rounds 1-3 --
+and the sustained one -- the same K steps behind --prewarm untimed steps of the same loop (default: whole passes over the ring, at least 120 steps)
+and W more warm-up steps.  The loop's first ~150 launches run about 10 % below the rate it then holds (the power controller settling at the
+1400 W cap), whatever kept the GPU busy before, and the driver's timed region is 20 steps long.  `value` is the sustained region; `cold` carries the
+other one; --prewarm 0 times the cold region only.  The kernel sample of `roofline` is taken in the sustained state: the timed steps that carried
+HIP events plus a sampling pass behind the timed region (at least 30 launches in all).
+
+`--gpus N` started WITHOUT torchrun (and without --threads) starts N ranks itself: the parent -- before it imports torch or touches HIP -- runs
+`python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>`, relays rank 0's line and exits with the children's code.
+A world size that differs from --gpus is an error, never a silently smaller run.
 
 The default workload is BASELINE.json configs[3] per GPU: 1024 streams @ 2.048 MS/s, /64, 50 baud 7N2, spectrum +
 AFC every call ("cfg4" in SURVEY.md's 1-based numbering) -- the batched 2.048 MS/s configuration that exists at
@@ -169,28 +176,42 @@ def cpu_baseline(w, host_iq, chunks, C, lookup_mode=1):
     return total / dt / 1e6, best, sample, {str(k): round(v, 1) for k, v in table.items()}
 
 
-def oracle_sample_check(w, eng, ring, chunks, C, streams, lookup_mode=1):
-    """The self-check every bench line carries: the oracle decodes the chunk sequence the engine consumed on a few streams (one pass, one
-    thread per stream) and the engine's symbols produced, characters and sentences per stream must equal the oracle's."""
+def oracle_sample_check(w, eng, ring, chunks, C, streams, lookup_mode=1, group=64):
+    """The self-check every bench line carries: the oracle decodes the chunk sequence the engine consumed on `streams` (one pass, one thread per
+    stream, `group` streams at a time: a group's share of the ring is transposed on the GPU and brought over in one copy) and the engine's symbols
+    produced, characters and sentences per stream must equal the oracle's.  The headline line checks EVERY stream of the shard."""
     from oracle import pyoracle
     kw = dict(fs=w["fs"], factor=w["D"], baud=w["baud"], bits=w["bits"], stops=w["stops"], lowpass_bw=w["lp_bw"],
               lowpass_trans=w["lp_trans"], mathh_context=lookup_mode, ungated=w["ungated"])
     nuse = max(chunks) + 1
-    host_iq = [ring[:nuse, s].cpu().numpy().view(np.complex64).reshape(-1) for s in streams]
-    _, logs = pyoracle.bench_run(host_iq, chunks, C, 1, **kw)
-    gpu_sent = [eng.take_sentences(s) for s in streams]
-    gpu_chars = [eng.take_chars(s) for s in streams]
-    gpu_bits = [eng.bits_total(s) for s in streams]
-    n_chars, n_bits = int(sum(len(x.chars) for x in logs)), int(sum(x.bits for x in logs))
-    same = gpu_sent == [list(x) for x in logs] and gpu_chars == [x.chars for x in logs] and gpu_bits == [x.bits for x in logs]
-    diff = [(int(s), f) for i, s in enumerate(streams) for f, g, o in (("sentences", gpu_sent[i], list(logs[i])), ("chars", gpu_chars[i], logs[i].chars), ("bits", gpu_bits[i], logs[i].bits)) if g != o]
-    if diff:
-        i = list(streams).index(diff[0][0])
-        sys.stderr.write(f"[bench] self-check mismatch {diff[:8]}: stream {diff[0][0]} gpu bits {gpu_bits[i]} chars {gpu_chars[i]!r} / oracle bits {logs[i].bits} chars {logs[i].chars!r}\n")
-    return {"gpu_matches_oracle_on_sample": (bool(same) if n_bits else None), "mismatches": diff[:8],
-            "compared": "per stream: symbols produced, characters emitted, sentences -- GPU engine vs oracle over warm-up + timed steps",
-            "streams_in_sample": [int(x) for x in streams] if len(streams) <= 8 else len(streams),
-            "bits_in_sample": n_bits, "chars_in_sample": n_chars, "sentences_in_sample": int(sum(len(x) for x in logs))}
+    streams = list(streams)
+    t0 = time.perf_counter()
+    n_chars = n_bits = n_sent = 0
+    diff = []
+    contiguous = streams == list(range(streams[0], streams[0] + len(streams)))
+    for g0 in range(0, len(streams), group):
+        grp = streams[g0:g0 + group]
+        if contiguous:      # [nuse, G, C, 2] -> [G, nuse * C] complex64 on the device, one D2H copy
+            blk = ring[:nuse, grp[0]:grp[0] + len(grp)].transpose(0, 1).contiguous().cpu().numpy().view(np.complex64).reshape(len(grp), -1)
+            host_iq = [blk[i] for i in range(len(grp))]
+        else:
+            host_iq = [ring[:nuse, s].cpu().numpy().view(np.complex64).reshape(-1) for s in grp]
+        _, logs = pyoracle.bench_run(host_iq, chunks, C, 1, **kw)
+        del host_iq
+        for s, lg in zip(grp, logs):
+            got = (eng.take_sentences(s), eng.take_chars(s), eng.bits_total(s))
+            want = (list(lg), lg.chars, lg.bits)
+            n_chars += len(lg.chars); n_bits += lg.bits; n_sent += len(lg)
+            for f, g_, o_ in zip(("sentences", "chars", "bits"), got, want):
+                if g_ != o_:
+                    if not diff:
+                        sys.stderr.write(f"[bench] self-check mismatch on stream {s} ({f}): gpu bits {got[2]} chars {got[1]!r} / oracle bits {want[2]} chars {want[1]!r}\n")
+                    diff.append((int(s), f))
+    return {"gpu_matches_oracle_on_sample": ((not diff) if n_bits else None), "mismatches": diff[:8],
+            "compared": "per stream: symbols produced, characters emitted, sentences -- GPU engine vs oracle over every step the engine took (both timed regions, pre-warm, warm-up, sampling pass)",
+            "streams_in_sample": [int(x) for x in streams] if len(streams) <= 8 else len(streams), "all_streams_of_the_shard": len(streams) == eng.S,
+            "bits_in_sample": n_bits, "chars_in_sample": n_chars, "sentences_in_sample": n_sent, "steps_checked": len(chunks),
+            "check_seconds": round(time.perf_counter() - t0, 1)}
 
 
 def box_identity(torch, dev):
@@ -269,24 +290,27 @@ class Shard:
         self.eng.set_timing(3)     # HIP-event brackets on every 3rd call (each record is a barrier packet worth microseconds of queue time; 3, not 4: every 4th
                                    # launch carries the streams' spectra, and the sample must see light and heavy launches in their true proportion)
         self.base = self.ring.data_ptr()
-        self.front_ms, self.total_ms, self.host_us = [], [], []
+        self.i = 0
+        self.front_ms, self.total_ms, self.host_us, self.sensors = [], [], [], None
 
-    def step(self, i):
-        self.eng.process_device(self.base + (i % self.ring_chunks) * self.S * self.C * 8, self.C, self.C)
+    def step(self):
+        self.eng.process_device(self.base + (self.i % self.ring_chunks) * self.S * self.C * 8, self.C, self.C)
+        self.i += 1                  # (steps taken so far: the engine has consumed chunks [0, i) of the ring, taken modulo its length)
 
     def warm(self, W):
-        for i in range(W):
-            self.step(i)
+        for _ in range(W):
+            self.step()
         self.eng.flush()
 
-    def timed(self, W, K, every=1):
+    def timed(self, K, every=1):
         """K steps and the flush that delivers the last step's text; `every`: how often the loop asks the engine for its timing record (a thread
         per device shares the interpreter with its siblings: there the loop body is the bare C call on two steps out of three)."""
         eng = self.eng
         seen = eng.timing()["timed_calls"]
-        for i in range(W, W + K):
-            self.step(i)
-            if every == 1 or (i - W) % every == every - 1:
+        self.front_ms, self.total_ms, self.host_us = [], [], []
+        for j in range(K):
+            self.step()
+            if every == 1 or j % every == every - 1:
                 t = eng.timing()
                 if t["timed_calls"] != seen:          # (a call that carried the HIP-event brackets)
                     seen = t["timed_calls"]
@@ -297,6 +321,32 @@ class Shard:
         eng.flush()          # the last step's text is delivered inside the timed region
         self.torch.cuda.synchronize(self.dev)
         self.t_end = time.perf_counter()
+
+
+def gpu_sensor_reader(torch, dev):
+    """A function that reads this device's shader clock and average board power from sysfs (hwmon freq1_input / power1_average of the card with the
+    device's PCI address) -- file reads only: a child process from a process that has initialised the GPU is refused on this pool."""
+    import glob
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        want = "%04x:%02x:%02x." % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1) & 0xFF, getattr(pr, "pci_device_id", 0))
+        card = next((c for c in glob.glob("/sys/class/drm/card[0-9]*/device") if want in os.path.realpath(c)), None)
+        hw = (glob.glob(f"{card}/hwmon/hwmon*") or [None])[0] if card else None
+    except Exception:
+        hw = None
+
+    def rd(name, scale):
+        try:
+            return round(int(open(f"{hw}/{name}").read().strip()) / scale, 1)
+        except Exception:
+            return None
+
+    def read():
+        if not hw:
+            return {"sclk_mhz": None, "power_w": None}
+        pw = rd("power1_average", 1e6)
+        return {"sclk_mhz": rd("freq1_input", 1e6), "power_w": pw if pw is not None else rd("power1_input", 1e6)}
+    return read
 
 
 def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync, cpu_leg, threads=0, prewarm=None):
@@ -326,13 +376,13 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     sh = shards[0]
     eng, ring, ring_chunks, texts = sh.eng, sh.ring, sh.ring_chunks, sh.texts
     K = K or ring_chunks
-    # Untimed steps in front of the W warm-up steps -- by default one pass over the ring.  The step loop needs its first ~150 launches (20 ms) to reach the
+    # Untimed steps between the two timed regions -- by default one pass over the ring.  The step loop needs its first ~150 launches (20 ms) to reach the
     # rate it then sustains: 20 timed steps take 0.156-0.162 ms each behind 5 warm-up steps, 0.154-0.161 behind 40, 0.142-0.145 behind 150, 0.136-0.142
     # behind 500 (one box, tools/micro/ab_step.py) -- whichever slabs they read, and a busy GPU beforehand does not replace them.  The
-    # driver's command (--warmup 5, 20 steps = 3 ms) would otherwise time nothing but that ramp.  The self-check covers these steps too.
+    # driver's command (--warmup 5, 20 steps = 3 ms) behind nothing else times that ramp: it is reported as `cold`.  The self-check covers every step.
     P = min(ring_chunks * -(-120 // ring_chunks), 512) if prewarm is None else max(0, int(prewarm))     # (whole passes over the ring, at least 120 steps)
-    Wt = P + W
     base = sh.base
+    sensors = [gpu_sensor_reader(torch, x.dev) for x in shards]
 
     def barrier():
         if dist is not None:
@@ -340,23 +390,62 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
         for x in shards:
             torch.cuda.synchronize(x.dev)
 
-    for x in shards:
-        x.warm(Wt)
-    barrier()
-    t0 = time.perf_counter()
-    if threads > 1:
-        th = [threading.Thread(target=x.timed, args=(Wt, K, 3)) for x in shards]
-        for t in th: t.start()
-        for t in th: t.join()
+    def region():
+        """W untimed warm-up steps, then EXACTLY K timed steps between barriers; the whole job's time (MAX over ranks / shards)."""
+        for x in shards:
+            x.warm(W)
+        barrier()
+        t0 = time.perf_counter()
+        if threads > 1:
+            th = [threading.Thread(target=x.timed, args=(K, 3)) for x in shards]
+            for t in th: t.start()
+            for t in th: t.join()
+        else:
+            sh.timed(K, 1)
+        barrier()
+        d = time.perf_counter() - t0
+        if threads > 1:
+            d = max(x.t_end for x in shards) - t0      # (the slowest device's region: MAX over shards, as job_time does over ranks)
+        return job_time(dist, d, dev)
+
+    dt_cold = region()                                  # behind --warmup only: what rounds 1-3 timed
+    cold = {"value": round(world * S * C * K / dt_cold / 1e6, 1), "ms_per_step": round(dt_cold / K * 1e3, 4), "timed_region_ms": round(dt_cold * 1e3, 2),
+            "steps": K, "warmup": W, "note": "the same K steps timed right behind the --warmup steps, before the pre-warm pass (the protocol of rounds 1-3)"}
+    cold_kernel_ms = list(sh.front_ms)
+    if P:
+        for x in shards:
+            x.warm(P)
+        dt = region()                                   # the sustained region: `value`
     else:
-        sh.timed(Wt, K)
-    barrier()
-    dt = time.perf_counter() - t0
-    if threads > 1:
-        dt = max(x.t_end for x in shards) - t0      # (the slowest device's region: MAX over shards, as job_time does over ranks)
+        dt = dt_cold
     drain_ms = (sh.t_end - sh.t_loop) * 1e3
-    dt = job_time(dist, dt, dev)
-    front_ms, total_ms, host_us = sh.front_ms, sh.total_ms, sh.host_us
+    front_ms, total_ms, host_us = list(sh.front_ms), list(sh.total_ms), list(sh.host_us)
+    # The kernel sample of `roofline`: the timed steps that carried HIP events, topped up -- outside the timed region, same loop, same state -- to at
+    # least 32 launches (the driver's 20 steps alone carry six or seven).  The device's shader clock and board power are read at the end of that pass,
+    # with its last launches still queued (two sysfs reads, ~0.3 ms of driver time: NOT inside a timed region).
+    n_region = len(front_ms)
+    need = max(0, 32 - n_region)
+    if not threads:
+        seen = eng.timing()["timed_calls"]
+        for _ in range(max(3 * need + 3, 48)):
+            sh.step()
+            t = eng.timing()
+            if t["timed_calls"] != seen:
+                seen = t["timed_calls"]
+                front_ms.append(t["ms_front"]); total_ms.append(t["ms_total"])
+        sh.sensors = sensors[0]()
+        eng.flush()
+        torch.cuda.synchronize(sh.dev)
+    else:
+        for x, rd in zip(shards, sensors):
+            x.sensors = rd()
+    rank_sensors = [x.sensors or {"sclk_mhz": None, "power_w": None} for x in shards]
+    if dist is not None:                                # every rank's clock and power, gathered on rank 0 (a 2-float all-gather, outside the timed regions)
+        mine = torch.tensor([rank_sensors[0]["sclk_mhz"] or -1.0, rank_sensors[0]["power_w"] or -1.0], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_sensors = [{"sclk_mhz": (float(a[0]) if float(a[0]) >= 0 else None), "power_w": (float(a[1]) if float(a[1]) >= 0 else None)} for a in allr]
+    steps_taken = sh.i
     tm = eng.timing()
     front_bytes, path = tm["front_bytes"], tm.get("path", 0)
     sentences_ok = eng.sentences_ok()
@@ -398,14 +487,16 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     valu = w["D"] == 4                                      # configs[2]: the FIR chain's multiply-adds bind, not HBM
     tflops = value / world * 1e6 * flops_per_sample(w) / 1e12
     res = {
-        "prewarm_steps": P,
+        "prewarm_steps": P, "cold": cold,
+        "per_rank": [dict(rank=i, **x) for i, x in enumerate(rank_sensors)],
         "value": round(value, 1), "ms_per_step": round(dt / K * 1e3, 4), "steps": K, "S": S, "C": C, "ring_chunks": ring_chunks, "w": w,
         "timed_region_ms": round(dt * 1e3, 2),
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_front_ms, 5),
                      "n_samples": len(front_ms), "min_launch_ms": round(float(np.min(front_ms)), 5), "max_launch_ms": round(float(np.max(front_ms)), 5),
-                     "sampling": "HIP events on the engine's queue around every 3rd launch of the timed region",
+                     "n_samples_in_timed_region": n_region, "cold_avg_launch_ms": round(float(np.mean(cold_kernel_ms)), 5) if cold_kernel_ms else None,
+                     "sampling": "HIP events on the engine's queue (riding on the dispatch packet) around every 3rd launch of the sustained timed region, topped up to >= 32 launches by a sampling pass of the same loop right behind it",
                      "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 4)},
         "pipeline": {"bytes_per_sample": round(bytes_per_sample(w["D"]), 3),
                      "hbm_frac_end_to_end": round(value / world * 1e6 * bytes_per_sample(w["D"]) / 1e9 / HBM_PEAK_GBS, 4),
@@ -449,7 +540,7 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
                            "frac_of_measured_copy_peak": round(iso_bw / HBM_COPY_GBS, 4),
                            "note": "stage 1 alone: synchronous calls (nothing else on the GPU), 24 launches after the timed region"}
     res["box"] = box_identity(torch, dev)
-    chunks = [i % ring_chunks for i in range(Wt + K)]           # what the engine consumed: pre-warm + warm-up + timed steps (the self-check follows all of it)
+    chunks = [i % ring_chunks for i in range(steps_taken)]     # what the engine consumed: both regions, the pre-warm pass, the sampling pass (the self-check follows all of it)
     chunks_cpu = [i % ring_chunks for i in range(W + K)]       # the CPU baseline's bounded sample of the same workload
     if cpu_leg == "full":
         nproc = os.cpu_count() or 1
@@ -461,7 +552,7 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
         res["cpu_baseline"] = {"value": round(v, 1), "unit": "MS/s", "cores": min(c, physical_cores() or c), "threads": c, "nproc": nproc,
                                "physical_cores": physical_cores(), "kind": "port", "sample": sample,
                                "threads_calibration_MSps": calib}
-        res["cpu_baseline"].update(oracle_sample_check(w, eng, ring, chunks, C, list(range(min(S, 16)))))
+        res["cpu_baseline"].update(oracle_sample_check(w, eng, ring, chunks, C, list(range(S))))      # every stream of the shard
     elif cpu_leg == "check":
         # no CPU timing asked for: the line still says whether what it timed decodes what the oracle decodes (a far-off-tune stream among them)
         res["cpu_baseline"] = {"value": None, "kind": "port", "note": "self-check only (--no-cpu-baseline / secondary workload): the oracle was not timed"}
@@ -484,11 +575,43 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the secondary line for BASELINE configs[2] (/4)")
     ap.add_argument("--sync", action="store_true", help="deliver each step's text before the next step starts (no pipelining of calls)")
     ap.add_argument("--threads", action="store_true", help="with --gpus N and no torchrun: ONE process, an engine + a host thread per device (no RCCL anywhere)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: only the launch plumbing (ranks, gloo barrier, MAX over ranks, rank 0's line) -- CPU tests")
     args = ap.parse_args()
+
+    # --gpus N > 1 started as a plain command: this process becomes the launcher -- BEFORE torch is imported or HIP touched -- of N ranks of itself
+    # (torch.distributed.run, one per GPU), relays what they print and exits with their code.  (such a command used to run on one GPU.)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.threads:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               str(Path(__file__).resolve())] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not args.threads and world != max(1, args.gpus):
+        raise SystemExit(f"bench.py --gpus {args.gpus} inside a job of {world} rank(s): the line would report another number of GPUs than asked for")
+    if args.dry_run:
+        # the launch plumbing alone, on CPU (tests/test_sharding_gloo.py): process group, barrier, MAX of the timed region, one line from rank 0
+        import torch
+        import torch.distributed as dist
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        dt = job_time(dist if world > 1 else None, 1e-3 * (rank + 1))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            w = WORKLOADS[args.workload]; S = args.streams or w["S"]; K = args.steps or 1
+            print(json.dumps({"metric": "IQ Msamples/s (batched 2.048 MS/s streams)", "value": round(world * S * w["C"] * K / dt / 1e6, 1), "unit": "MS/s", "n_gpus": world,
+                              "steps": K, "warmup": args.warmup, "dry_run": True, "slowest_rank_ms": round(dt * 1e3, 3),
+                              "shards": [[shard(r, world, S)[0], shard(r, world, S)[-1] + 1] for r in range(world)]}), flush=True)
+        return
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path to time (the oracle is only the baseline leg)")
@@ -502,6 +625,8 @@ def main():
         threads = max(1, args.gpus)
         if torch.cuda.device_count() < threads and not os.environ.get("HD_BENCH_SAME_DEVICE"):
             raise SystemExit(f"bench.py --threads --gpus {threads}: only {torch.cuda.device_count()} device(s) visible")
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -530,8 +655,10 @@ def main():
         "config": {"workload": f"{args.workload}: {w['desc']}", "streams_per_gpu": r["S"], "chunk_samples": r["C"], "ring_chunks": r["ring_chunks"],
                    "sharding": f"{r['S']} independent streams per GPU, no data-path collective"},
         "timed_region_ms": r["timed_region_ms"],
+        "cold": r["cold"],
         "prewarm_steps": r["prewarm_steps"],
-        "prewarm_note": "untimed steps of the same loop in front of the --warmup steps (whole passes over the ring, at least 120 steps): the loop's first ~150 launches run 10 % below the rate it sustains (DESIGN.md section 6); --prewarm 0 times that ramp instead",
+        "prewarm_note": "`value` / `ms_per_step` are the K steps timed behind the pre-warm pass (untimed steps of the same loop: whole passes over the ring, at least 120) and --warmup more steps: the sustained regime, at the board's 1400 W cap; `cold` is the same K steps timed right behind --warmup alone, before that pass (the protocol of rounds 1-3: the loop's first ~150 launches, DESIGN.md section 6)",
+        "per_rank": r["per_rank"],
         "roofline": r["roofline"], "pipeline": r["pipeline"], "box": r.get("box"),
     }
     if threads:

@@ -93,6 +93,7 @@ HOST_API = {
     "hd_host_lowpass_design": (_sz, [_f, _f, _sz, _sz, _int, _f32p, _sz]),
     "hd_host_rtty_new": (_vp, [_sz, _f]),
     "hd_host_rtty_free": (None, [_vp]),
+    "hd_host_rtty_pending": (_sz, [_vp]),
     "hd_host_rtty_push_run": (_sz, [_vp, _u8p, _sz, C.c_char_p, _sz]),
     "hd_host_crc16": (None, [C.c_char_p, _sz, C.c_char_p]),
     "hd_host_extract_sentence": (_int, [C.c_char_p, _sz, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, _sz]),

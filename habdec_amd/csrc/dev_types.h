@@ -71,7 +71,13 @@ struct BitsHeader {
     // demod_ck[0] = sum bits(d[i]), demod_ck[1] = sum (i + 1) * bits(d[i]) (mod 2^32) over the demod_n = fir_m samples of the call.
     uint32_t demod_ck[2];
     uint32_t demod_n;       // 0xFFFFFFFF when the kernel that wrote the slot does not compute it
+    // The call's tag (engine: call number + 1), stored LAST -- behind a wait for every other store of the wave that wrote the slot (header, bits, and in the
+    // stream tail the spectrum statistics).  Result slots live in mapped host memory and the engine's completion events carry no system-scope fence (they
+    // cost 3 % of a step): the host takes a slot as delivered when it reads the tag it expects, not because an event said so (collect(), engine.cpp).
+    uint32_t seq;
+    uint32_t _pad[3];
 };
+static_assert(sizeof(BitsHeader) == 48, "result slot header");
 
 struct SpectrumStatsDev {   // must match hd::SpectrumStats (host/afc_tracker.hpp)
     int32_t valid;

@@ -10,6 +10,7 @@
 #include <rocfft/rocfft.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -119,32 +120,26 @@ struct hd_engine {
     bool one_stream = false;
     bool no_fuse = false;      // HD_NO_FUSE: never use the fused back end (kernels/backend.hip); A/B measurements
     bool no_tail = false;      // HD_NO_TAIL: never use the one-wave stream tail (kernels/tail_body.h); A/B measurements
-    int tail_lanes = 0;        // HD_TAIL_LANES: 64 / 256 lanes per stream in the tail kernel (0 = by batch size)
     uint32_t tail_max_n2 = 2048;   // HD_TAIL_MAX_N2: most decimated samples per call for which the stream tail is used
     int last_fuse = -1;
     // Step mode (batch decoding, kernels/decimate.hip k_step): the stream tails of call k ride in the stage-1 launch of call k+1.
     struct PendingTail { bool valid = false; hd::TailArgs ta{}; int slot = 0; bool any_fft = false; int r2 = 0, t2 = 0; } pend;
-    bool no_step = false;      // HD_NO_STEP: keep stage 1 and the tails in separate launches
     bool own_fft = false;      // HD_OWN_FFT: the spectrum as one launch of single-wave workgroups instead of rocFFT + commit where no tail does it (measured: no faster)
     bool tail_fft = true;      // a stream tail transforms its stream's completed spectrum buffer itself (kernels/spectrum_wave.h); HD_ROCFFT=1: separate launches
     DevBuf<float2> fft_tw;     // (cos, -sin)(2 pi m / 4096), rounded once from double
-    bool claim_alone = false;  // HD_CLAIM_ALONE: stage 1 as a launch of its own draws its tiles too (measured slower: off)
     bool no_claim = false;     // HD_NO_CLAIM: step launches with fixed shares of tiles (A/B measurements)
     uint32_t step_run = 0;     // HD_STEP_RUN: tiles per drawn run (default 4, minimum 2)
     bool no_cu_step = false;   // HD_NO_CU_STEP: step launches as single-wave workgroups (k_step) instead of one workgroup per CU (k_step_cu)
     uint32_t ring_run = 0;     // HD_RING_RUN: tiles per drawn run of the per-CU ring kernels (default: pick_ring_run)
-    uint32_t s1_loaders = 2;   // HD_S1_LOADERS: ... when stage 1 is a launch of its own.  Two since round 4: with the nt policy on the body rows one loader's 3 tiles in
-                               // flight (its 6-bit vmcnt holds 57 DMA instructions) are what bounds the launch -- 102.7 us with one loader, 94.7 with two (one box, alternating)
-    uint32_t s1_waves = 8;     // HD_S1_WAVES: waves per workgroup of k_stage1_cu (8 .. 16)
-    uint32_t s1_slots = 4;     // HD_S1_SLOTS: tile slots of k_stage1_cu in batch mode on the separate-kernels path: four leave half of a CU's LDS to the back-half
-                               // workgroups of the previous call on the other queue (/16: 0.334-0.343 ms per step against 0.342-0.351 with eight, one box, alternating)
+    static constexpr uint32_t kS1Loaders = 2;   // LDS-DMA loader waves of k_stage1_cu at /8 and /4 (round 4: with the nt policy on the body rows one loader's three
+                                                // tiles in flight bound the launch -- 102.7 us with one loader, 94.7 with two, one box, alternating)
+    static constexpr uint32_t kS1Slots = 4;     // tile slots of k_stage1_cu in batch mode on the separate-kernels path: four leave half of a CU's LDS to the back-half
+                                                // workgroups of the previous call on the other queue (/16: 0.334-0.343 ms per step against 0.342-0.351 with eight)
     PinBuf<unsigned int> ring_gave_up;     // mapped host word a wave of k_step_cu / k_stage1_cu sets when a bounded wait runs out (never in a correct run)
     bool device_failed = false;            // ... after which the engine stays failed: the launch that gave up left stage-1 output incomplete, and up to
                                            // three calls are undelivered by the time a collect() sees the word -- which of them it was cannot be told
     uint64_t step_launches = 0;
     DevBuf<unsigned int> step_ctr;         // two sets of per-XCD run counters ([2][16][32] u32), alternating per step launch
-    uint32_t qa_cus = 0;       // HD_CU_SPLIT experiment: CUs the stage-1 queue may use (0 = all)
-    uint32_t step_wgs = 0;     // HD_STEP_WGS: stage-1 workgroups of a step launch (default 8 per CU)
     uint32_t pend_max_taps = 0;
     uint32_t n_cus = 0, dec_wgs_per_cu = 0;   // stage-1 linear split: workgroups per CU (0 = classic grid), see kernels/decimate.hip        // path of the previous call (the two paths use the stage-2 buffers on different queues)
     hipStream_t qa = nullptr, qb = nullptr, qc = nullptr;   // front (decimation, spectrum) and back (FIR, symbols, results) HIP streams
@@ -183,6 +178,7 @@ struct hd_engine {
         bool timed = false, timed_step = false;   // this call carries the timing events (a step call: only the two around its one launch)
         hipEvent_t ev_front = nullptr, ev_done = nullptr, ev_params = nullptr, t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr;
         bool busy = false;
+        uint32_t seq = 0;                         // this call's tag: what every result slot's BitsHeader::seq must read before the slot is taken as delivered
         uint64_t total_in = 0;
         uint32_t r1 = 1;
         ~CallSlot() { for (hipEvent_t ev : {ev_front, ev_done, ev_params, t0, t1, t2, t3}) if (ev) (void)hipEventDestroy(ev); }
@@ -299,39 +295,16 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device || cfg->device < 0)
         return fail(HD_ERR_DEVICE, "no HIP device " + std::to_string(cfg->device) + " (this library has no CPU path)");
     HD_HIP(hipSetDevice(cfg->device));
-    {   // HD_QA_PRIORITY=1: the stage-1 queue gets the device's highest priority, so that when stage 1 of call k+1 and the back half
-        // of call k become runnable together, stage 1's workgroups are placed first (evenly, k per CU) and the back half fills in
-        int lo = 0, hi = 0;
-        const char* pv = getenv("HD_QA_PRIORITY");
-        if (pv && atoi(pv) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
-            HD_HIP(hipStreamCreateWithPriority(&e->qa, hipStreamNonBlocking, atoi(pv) > 0 ? hi : lo));
-        else if (getenv("HD_CU_SPLIT")) {
-            // experiment: stage 1 on the first a of every XCD's 32 CUs, the back half on the rest (mask bits [8j, 8j+8) select CU j of each XCD)
-            const int a = atoi(getenv("HD_CU_SPLIT"));
-            uint32_t ma[8] = {0}, mb[8] = {0};
-            for (int j = 0; j < 32; ++j) (j < a ? ma : mb)[j / 4] |= 0xffu << (8 * (j % 4));
-            HD_HIP(hipExtStreamCreateWithCUMask(&e->qa, 8, ma));
-            HD_HIP(hipExtStreamCreateWithCUMask(&e->qb, 8, mb));
-            e->qa_cus = 8u * (uint32_t)a;
-        } else
-            HD_HIP(hipStreamCreateWithFlags(&e->qa, hipStreamNonBlocking));
-    }
+    HD_HIP(hipStreamCreateWithFlags(&e->qa, hipStreamNonBlocking));
     // Synchronous delivery (pipeline = 0) has nothing to overlap between calls: one queue, no cross-queue event between the front and the back half
-    // (0.283 -> 0.268 ms per step at 1024 streams, 12 us of it the hop from one queue to the other).  HD_TWO_QUEUES=1 keeps the two for comparisons.
-    e->one_stream = getenv("HD_ONE_STREAM") != nullptr || (cfg->pipeline == 0 && !e->qb && !getenv("HD_TWO_QUEUES"));
+    // (0.283 -> 0.268 ms per step at 1024 streams, 12 us of it the hop from one queue to the other).
+    e->one_stream = cfg->pipeline == 0;
     e->no_fuse = getenv("HD_NO_FUSE") != nullptr;
     e->no_tail = getenv("HD_NO_TAIL") != nullptr;
-    e->no_step = getenv("HD_NO_STEP") != nullptr;
     e->no_claim = getenv("HD_NO_CLAIM") != nullptr;
-    e->claim_alone = getenv("HD_CLAIM_ALONE") != nullptr;
     if (const char* v = getenv("HD_STEP_RUN")) e->step_run = (uint32_t)atoi(v);
     e->no_cu_step = getenv("HD_NO_CU_STEP") != nullptr;
     if (const char* v = getenv("HD_RING_RUN")) e->ring_run = (uint32_t)atoi(v);
-    if (const char* v = getenv("HD_S1_LOADERS")) e->s1_loaders = atoi(v) == 1 ? 1u : 2u;
-    if (const char* v = getenv("HD_S1_WAVES")) e->s1_waves = (uint32_t)atoi(v);
-    if (const char* v = getenv("HD_S1_SLOTS")) e->s1_slots = (uint32_t)atoi(v);
-    if (const char* v = getenv("HD_STEP_WGS")) e->step_wgs = (uint32_t)atoi(v);
-    if (const char* v = getenv("HD_TAIL_LANES")) e->tail_lanes = atoi(v);
     if (const char* v = getenv("HD_TAIL_MAX_N2")) e->tail_max_n2 = (uint32_t)strtoul(v, nullptr, 0);
     {
         hipDeviceProp_t prop;
@@ -351,13 +324,17 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         HD_HIP(hipStreamCreateWithFlags(&e->qc, hipStreamNonBlocking));   // parameter fetches: tiny kernels that need not queue behind stage 1
     }
     for (auto& sl : e->slot) {
-        // No system-scope fence at these events (hipEventDisableSystemFence): what the host reads after ev_done -- result slots, spectrum statistics -- lives in
-        // coherent mapped host memory and is written straight over PCIe, and what queues hand each other on this device needs agent scope only.  With the
-        // default flags every record wrote back and invalidated the L2s: ~5 us of queue time per event between two step launches (kernel trace, round 4:
-        // gaps of 6 us behind one record, 11 behind two), i.e. 3-6 % of a step.
-        static const unsigned ev_flags = getenv("HD_EVENT_SYSTEM_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence;
+        // No system-scope fence at these events (hipEventDisableSystemFence): what queues hand each other on this device needs agent scope only, and with the
+        // default flags every record wrote back and invalidated the L2s -- ~5 us of queue time per event between two step launches (kernel trace, round 4),
+        // and a system-scope release on the dispatch that carries ev_done costs 2.8 % of a step (round 5, one box, alternating: 0.1316-0.1323 against
+        // 0.1283-0.1285 ms).  What the HOST reads behind ev_done -- result slots, spectrum statistics, the give-up word -- lives in coherent mapped host memory and
+        // is written straight over PCIe; HIP does not promise that an event without the fence orders those stores before the host's reads, so
+        // collect() does not rely on it: every result slot carries the call's tag, stored last behind a wait for the writing wave's other stores
+        // (BitsHeader::seq), and a slot counts as delivered when the host reads that tag.
+        static const unsigned ev_flags = (unsigned)hipEventDisableSystemFence;
+        static const unsigned done_flags = ev_flags;
         HD_HIP(hipEventCreateWithFlags(&sl.ev_front, hipEventDisableTiming | ev_flags));
-        HD_HIP(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming | ev_flags));
+        HD_HIP(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming | done_flags));
         HD_HIP(hipEventCreateWithFlags(&sl.ev_params, hipEventDisableTiming | ev_flags));
         for (hipEvent_t* ev : {&sl.t0, &sl.t1, &sl.t2, &sl.t3}) HD_HIP(hipEventCreateWithFlags(ev, ev_flags));
     }
@@ -499,7 +476,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
                              e->carry[1].p, sl.d_call.p, e->fir_hist_cap, e->tail.p, e->tail_cap, e->d_symstate.p, e->fbuf[1].p,
                              e->fir_head.p, e->fir_head_n.p, e->fir_head.p + (size_t)S * e->head_cap, e->fir_head_n.p + S, e->head_cap);
         hd::launch_symbols(q, S, 1, 1, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p, sl.d_call.p,
-                           sl.h_slots.dev, e->slot_words, nullptr, 0, e->min_R);
+                           sl.h_slots.dev, e->slot_words, nullptr, 0, e->min_R, 0u);
         HD_HIP(hipStreamSynchronize(q));
         HD_HIP(hipGetLastError());        // a kernel this shape cannot launch (LDS, grid) fails the creation, not every later call
         // the all-idle call moved nothing, but the history / carry ping-pong "out" buffers were written: restore zeros
@@ -653,13 +630,13 @@ int run_pending_tail(hd_engine* e)
     hd_engine::CallSlot& ps = e->slot[e->pend.slot];
     e->pend.valid = false;
     hd::TailArgs ta = e->pend.ta;
-    const int lanes = e->tail_lanes ? e->tail_lanes : (e->S >= 2 * e->n_cus ? 64 : 256);
+    const int lanes = (e->S >= 2 * e->n_cus ? 64 : 256);
     hd::TailArgs lay = ta;
     if (lanes != 64) {      // the pending arguments carry the 64-lane carve of the step launch; a 256-lane kernel needs its own
         // (same buffers, other LDS offsets)
         if (!hd::tail_layout(lay, lanes, e->pend.r2, e->pend.t2, e->pend_max_taps, e->max_R, e->min_R, e->tail_cap, e->pend.ta.pend_max, 64 * 1024)) return fail(HD_ERR_INVALID, "stream tail layout");
     }
-    const bool own_spectrum = (!ta.fft_tw && e->cfg.enable_spectrum && e->pend.any_fft) || getenv("HD_STEP_PACKET_EVENTS");       // a transform launch follows the tails: the event goes behind that one
+    const bool own_spectrum = !ta.fft_tw && e->cfg.enable_spectrum && e->pend.any_fft;       // a transform launch follows the tails: the event goes behind that one
     if (!hd::launch_tail(e->qa, lanes, e->pend.r2, e->pend.t2, e->S, lay, own_spectrum ? nullptr : ps.ev_done)) return fail(HD_ERR_INVALID, "stream tail refused a shape it was selected for");
     if (own_spectrum) { if (!ta.fft_tw) { if (const int r = run_spectrum(e, e->qa, ps, e->pend.any_fft)) return r; } HD_HIP(hipEventRecord(ps.ev_done, e->qa)); }
     HD_HIP(hipGetLastError());
@@ -687,10 +664,31 @@ int collect(hd_engine* e, hd_engine::CallSlot& sl)
         ++e->last_timing.timed_calls;
     }
     int rc = HD_OK;
+    {   // every stream's slot must carry this call's tag (the kernels store it last); in practice it is there when the event has fired -- if not, wait for it
+        const auto t_lim = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
+        for (uint32_t s = 0; s < e->S && !e->device_failed; ++s) {
+            const volatile uint32_t* tag = &reinterpret_cast<const volatile hd::BitsHeader*>(sl.h_slots.p + (size_t)s * e->slot_words)->seq;
+            while (*tag != sl.seq) {
+                if (std::chrono::steady_clock::now() > t_lim) {
+                    e->device_failed = true;
+                    rc = fail(HD_ERR_DEVICE, "result slot of stream " + std::to_string(s) + " does not carry its call's tag 200 ms after the completion event: the results of this engine are unreliable -- destroy the engine");
+                    break;
+                }
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
     if (e->ring_gave_up.p && e->ring_gave_up.p[0]) e->device_failed = true;
-    if (e->device_failed)
-        rc = fail(HD_ERR_DEVICE, "k_step_cu / k_stage1_cu: a bounded wait ran out inside a launch (word " + std::to_string(e->ring_gave_up.p ? e->ring_gave_up.p[0] : 0u) +
+    if (e->device_failed && rc == HD_OK)
+        rc = fail(HD_ERR_DEVICE, "k_stage1_cu (loader / consumer waves): a bounded wait ran out inside a launch (word " + std::to_string(e->ring_gave_up.p ? e->ring_gave_up.p[0] : 0u) +
                                  "): the results of this and of every later call of this engine are unreliable -- destroy the engine");
+    if (e->device_failed) {
+        // Nothing of this slot is delivered: the launch that gave up left stage-1 output incomplete, so the characters -- possibly CRC-passing
+        // sentences -- framed from it would be handed to the callbacks as if they were results.  No AFC step, no framer push, no callbacks, no counters.
+        e->last_timing.host_wait_us = std::chrono::duration<double, std::micro>(w1 - w0).count();
+        e->last_timing.host_text_us = 0;
+        return rc;
+    }
     for (uint32_t s = 0; s < e->S; ++s) {
         StreamHost& st = e->st[s];
         const hd::StreamCall& c = sl.h_call.p[s];
@@ -709,7 +707,7 @@ int collect(hd_engine* e, hd_engine::CallSlot& sl)
         st.last_nbits = hdr->nbits; st.last_nflips = hdr->nflips;
         st.bits_total += hdr->nbits;
         st.demod_ck[0] = hdr->demod_ck[0]; st.demod_ck[1] = hdr->demod_ck[1]; st.demod_ck_n = hdr->demod_n; st.demod_ck_call = e->delivered;
-        if ((hdr->overflow & 1u) && rc != HD_ERR_DEVICE) rc = fail(HD_ERR_CAPACITY, "symbol result slot overflow on stream " + std::to_string(s));
+        if (hdr->overflow & 1u) rc = fail(HD_ERR_CAPACITY, "symbol result slot overflow on stream " + std::to_string(s));
         if (hdr->overflow & 2u) ++st.flip_list_full;     // (the search stopped at the flip-list bound and resumes next call: bits arrive a call later)
         const uint32_t* words = slot + sizeof(hd::BitsHeader) / 4;
         st.last_words.assign(words, words + (hdr->nbits + 31) / 32);
@@ -853,18 +851,15 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     }
     sl.total_in = total_in;
     sl.r1 = R1;
-    const auto h1 = std::chrono::steady_clock::now();
+    sl.seq = (uint32_t)(e->calls + 1u);           // (never the tag this slot carried four calls ago)
     // ---- uploads: per-call parameters, changed low-pass designs, changed symbol parameters
     hipStream_t qa = e->qa, qb = e->qb;
-    double tp[12]; int ntp = 0;
-    auto mark = [&] { if (ntp < 12) tp[ntp++] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count(); };
-    mark();
     // Two-stage plans at batch-decoding sizes: stage 2, low-pass, discriminator and slide run as ONE kernel per call on qb
     // (kernels/backend.hip) when a stream's call fits in LDS and no DC blocker sits in between.
     // The stream tail (kernels/tail_body.h) goes further: stage 2 through the symbol extractor as one wave per stream that walks the
     // call in pieces, so neither the call size nor the tap count has to fit an LDS image.
     hd::TailArgs ta{};
-    const int tail_lanes = e->tail_lanes ? e->tail_lanes : (S >= 2 * e->n_cus ? 64 : 256);
+    const int tail_lanes = (S >= 2 * e->n_cus ? 64 : 256);
     // One wave per stream is the right shape while a call is short: its time grows with the decimated samples per call, and beyond
     // ~2048 of them (e.g. /16 with 65536-sample pushes: 4096) the many-workgroup kernels finish a batch sooner (measured: 156 vs 173 GS/s).
     const bool tail = nst == 2 && !any_dc && !e->no_tail && max_n2 <= e->tail_max_n2 &&
@@ -874,7 +869,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     // Step mode: batch decoding of equally sized pushes through a single-wave first stage -- ONE launch per call, on one queue: this
     // call's stage 1 with the previous call's stream tails in front (kernels/decimate.hip k_step).
     hd::TailArgs ta_step{};
-    const bool step = tail && e->cfg.pipeline && !e->no_step && !e->one_stream && min_in == max_in && max_in && (R1 == 32 || R1 == 64) &&
+    const bool step = tail && e->cfg.pipeline && !e->one_stream && min_in == max_in && max_in && (R1 == 32 || R1 == 64) &&
                       hd::step_lds_bytes((int)R1, (int)T1) &&
                       hd::tail_layout(ta_step, 64, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, hd::step_lds_bytes((int)R1, (int)T1));
     const int path = step ? 3 : tail ? 2 : fuse ? 1 : 0;
@@ -897,8 +892,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     if (sl.timed && !step) HD_HIP(hipEventRecord(sl.t0, qa));
     // One queue and the stream tails behind stage 1 (synchronous delivery): both kernels read the call's parameters from the mapped host block -- one
     // round trip over PCIe at the start of a workgroup instead of a copy kernel in front of stage 1.  (Not where a spectrum launch reads the device copy.)
-    static const bool fetch_env = getenv("HD_FETCH_PARAMS") != nullptr;
-    const bool host_params = tail && !step && e->one_stream && !fetch_env && (!e->cfg.enable_spectrum || (e->tail_fft && !any_dc));
+    const bool host_params = tail && !step && e->one_stream && (!e->cfg.enable_spectrum || (e->tail_fft && !any_dc));
     if (lean) {
         if (e->sym_dirty && e->calls > e->delivered) { if (int rc = flush_locked(e)) return rc; }   // symbol parameters are uploaded below: nothing may still read them
     } else if (!host_params) {
@@ -926,7 +920,6 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         for (uint32_t s = 0; s < S; ++s)       // a reset flag is consumed by exactly one call: upload again without it next time
             if (e->st[s].sym_reset) { e->st[s].sym_reset = false; e->sym_dirty = true; }
     }
-    mark();
     // ---- front half on qa: decimation, DC blocker, spectrum
     const float2* iq = static_cast<const float2*>(d_iq);
     float2* fcur = e->fbuf[e->cur].p;
@@ -945,7 +938,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         t.call = dcall; t.fft_in = feed; t.head_buf = e->fir_head.p; t.head_cnt = e->fir_head_n.p; t.head_cap = e->head_cap;
         t.head_par = (uint32_t)cin; t.n_streams = S;
         t.ring = e->tail.p; t.ring_cap = e->tail_cap; t.sym = e->d_symstate.p; t.flipmask = e->flipmask.p; t.wsum = e->weight.p;
-        t.sp = e->d_sym.p; t.slots = sl.h_slots.dev; t.slot_words = e->slot_words;
+        t.sp = e->d_sym.p; t.slots = sl.h_slots.dev; t.slot_words = e->slot_words; t.seq = sl.seq;
         t.flips_dbg = e->flips_cap ? e->flips_dbg.p : nullptr; t.flips_cap = e->flips_cap;
         const bool in_tail = e->tail_fft && e->cfg.enable_spectrum && feed;  // the tail transforms a completed buffer itself
         t.fft_tw = in_tail ? e->fft_tw.p : nullptr; t.spec = e->spec.p; t.power = e->power.p; t.stats = sl.h_stats.dev; t.rate = e->fsd; t.bins_sep = e->bins_sep;
@@ -960,7 +953,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         const uint64_t runs = (uint64_t)S * ntiles / run_len;
         const bool shape_ok = run_len_cu ? (hd::stage1_cu_supported((int)R1, (int)T1) && max_in % 2048u == 0) : ((R1 == 32 || R1 == 64) && max_n1 % 64 == 0);
         if (!e->no_claim && (nst == 2 || (run_len_cu && nst == 1)) && shape_ok && min_in == max_in && max_in && !any_zero1 && n_xcd && e->n_cus % 32u == 0 && n_xcd <= 16 &&
-            ntiles && ntiles % run_len == 0 && runs % n_xcd == 0 && !e->qa_cus && (uint64_t)S * ntiles < (1ull << 32) && (uint64_t)ntiles * S >= 4ull * lin_wgs) {   // (the two counter sets alternate: a launch that takes one must really run that way)
+            ntiles && ntiles % run_len == 0 && runs % n_xcd == 0 && (uint64_t)S * ntiles < (1ull << 32) && (uint64_t)ntiles * S >= 4ull * lin_wgs) {   // (the two counter sets alternate: a launch that takes one must really run that way)
             claim.ctr = e->step_ctr.p + (size_t)(e->step_launches & 1u) * 16 * 32;
             claim.ctr_next = e->step_ctr.p + (size_t)((e->step_launches & 1u) ^ 1u) * 16 * 32;
             claim.n_xcd = n_xcd; claim.runs_per_xcd = (uint32_t)(runs / n_xcd); claim.run_len = run_len;
@@ -989,8 +982,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         // worker slots leave of the CU's 160 KB (23 KB: larger caches for the search phase than the 20 KB slot of the single-wave fallback) -- now; the
         // launch that runs them decides.
         const bool cu_shape = !e->no_cu_step && !e->no_claim && !any_zero1 && max_in % 2048u == 0 && hd::step_cu_supported((int)R1, (int)T1, (int)R2, (int)T2);
-        uint32_t cu_tail = cu_shape ? hd::step_cu_tail_lds((int)R1, (int)T1) : 0u;
-        if (const char* v = getenv("HD_CU_TAIL_LDS")) cu_tail = std::min<uint32_t>(cu_tail, (uint32_t)atoi(v));      // (A/B: the tails' LDS carve inside the per-CU step kernel)
+        const uint32_t cu_tail = cu_shape ? hd::step_cu_tail_lds((int)R1, (int)T1) : 0u;
         if (cu_tail) {
             hd::TailArgs tacu{};
             if (hd::tail_layout(tacu, 64, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, cu_tail)) ta_step = tacu;
@@ -1000,15 +992,15 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         hd_engine::CallSlot* ps = prev.valid ? &e->slot[prev.slot] : nullptr;
         // Events of a k_step_cu launch ride on its dispatch packet (launch_step_cu): an event recorded behind it is a barrier packet of its own and
         // costs the queue ~5 us before the next launch starts.  (Not where the spectra are a launch of their own: ev_done follows that one.)
-        static const bool ext_events = !getenv("HD_STEP_PACKET_EVENTS");
+        const bool ext_events = true;
         bool ev_on_dispatch = false;
-        uint32_t wgs = e->step_wgs ? e->step_wgs : 32u * e->n_cus;   // short runs of tiles: the dispatcher evens out the tail of the launch
+        uint32_t wgs = 32u * e->n_cus;                          // short runs of tiles: the dispatcher evens out the tail of the launch
         // One workgroup per CU (four stage-1 worker waves, the tails in the other four) where the plan and the sizes allow it
         const uint32_t ring_run = pick_ring_run(hd::ring_tiles((int)R1, (int)T1, max_in));
         static const int cu_exp0 = getenv("HD_CU_EXP") ? atoi(getenv("HD_CU_EXP")) : 0;   // timing experiments only (results wrong): 1 = no tails, 2 = no stage 1
         const bool want_cu = cu_tail && ((cu_exp0 & 1) || (ta_step.lds_bytes <= cu_tail && (!prev.valid || prev.ta.lds_bytes <= cu_tail)));
         const hd::StepClaim claim = make_claim(0, want_cu ? ring_run : 0u);
-        if (claim.ctr && !e->step_wgs) wgs = 8u * e->n_cus;
+        if (claim.ctr) wgs = 8u * e->n_cus;
         bool launched = false;
         e->last_timing.step_variant = 0;
         if (want_cu && claim.ctr) {
@@ -1029,7 +1021,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             hd::StepClaim fb = claim;
             if (want_cu && claim.ctr) {                        // (runs cut for the ring kernel's tiles are not k_step's: fixed shares, and the counter set was not drawn from)
                 --e->step_launches; fb = hd::StepClaim{};
-                if (!e->step_wgs) wgs = 32u * e->n_cus;
+                wgs = 32u * e->n_cus;
             }
             if (!hd::launch_step(qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, max_n1, iq, stride, e->hist1[hin].p,
                                  e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, wgs, prev.ta, prev.valid ? S : 0u,
@@ -1074,9 +1066,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         // measured at 10 MS/s, /256: 1.73 against 1.84 ms per step)
         static const bool wgs_env = getenv("HD_DEC_WGS_PER_CU") != nullptr;
         const uint32_t wgs_cu = (R1 == 64 && !wgs_env && e->dec_wgs_per_cu > 4u) ? 4u : e->dec_wgs_per_cu;
-        const uint32_t lin1 = (min_in == max_in && max_in) ? wgs_cu * (e->qa_cus ? e->qa_cus : e->n_cus) : 0u;
-        // (Stage 1 alone is HBM-bound: drawing runs costs it ~3 % -- more halo re-reads, 588 vs 576 MB per launch -- where the step launch gains
-        // 4 %; measured on one box, alternating.  HD_CLAIM_ALONE=1 turns it on for experiments.)
+        const uint32_t lin1 = (min_in == max_in && max_in) ? wgs_cu * e->n_cus : 0u;
         // A /32 first stage over equally sized pushes: one workgroup per CU, LDS-DMA loader waves + computing waves (k_stage1_cu, stage1_ring.h)
         bool s1_cu = false;
         if ((single ? R1 == 4 : R1 != 4) && min_in == max_in && max_in && !e->no_cu_step && !any_zero1 && max_in % 2048u == 0 && hd::stage1_cu_supported((int)R1, (int)T1)) {
@@ -1084,13 +1074,13 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             if (cl.ctr) {
                 if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
                 s1_cu = hd::launch_stage1_cu(qa, (int)R1, (int)T1, e->n_cus, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
-                                             max_in, cl, e->ring_gave_up.dev, e->s1_loaders, e->s1_waves, (e->cfg.pipeline && !fuse && !single) ? e->s1_slots : 8u,   // (/4 as the only stage is bound by the vector pipes: eight slots, 0.838 against 0.904 ms per step with four)
+                                             max_in, cl, e->ring_gave_up.dev, hd_engine::kS1Loaders, 16u, (e->cfg.pipeline && !fuse && !single) ? hd_engine::kS1Slots : 8u,   // (/4 as the only stage is bound by the vector pipes: eight slots, 0.838 against 0.904 ms per step with four)
                                              single ? (lean ? sl.h_call.dev : dcall) : nullptr, e->fir_hist_cap, single ? feed : nullptr);
                 if (!s1_cu) --e->step_launches;                // (the counter sets alternate per launch that really draws: this one did not)
             }
         }
         e->last_timing.step_variant = s1_cu ? 1u : 0u;
-        const hd::StepClaim claim1 = (s1_cu || single || !lin1 || !e->claim_alone) ? hd::StepClaim{} : make_claim(lin1);
+        const hd::StepClaim claim1{};                      // (stage 1 alone is HBM-bound: drawing runs there cost 3 % -- more halo re-reads -- where the step launch gains 4 %: fixed shares)
         if (sl.timed && !s1_cu) HD_HIP(hipEventRecord(sl.t1, qa));
         if (!s1_cu)
         if (!hd::launch_decimate(qa, R1, T1, S, max_n1, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
@@ -1107,7 +1097,6 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
                 return fail(HD_ERR_INVALID, "no kernel for this decimation stage");
         }
     }
-    mark();
     auto spectrum = [&](hipStream_t q) -> int {
         if (!(e->cfg.enable_spectrum && max_n2)) return HD_OK;
         if (!fuse && (any_dc || nst == 0)) hd::launch_fft_feed(q, S, fcur, e->fbuf_stride, e->fft_in.p, dcall, e->fir_hist_cap);
@@ -1120,17 +1109,13 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         if (any_dc) hd::launch_dc_remove(qa, S, fcur, e->fbuf_stride, dcall, e->fir_hist_cap);
         if (const int r = spectrum(qa)) return r;
     }
-    mark();
     if (!e->one_stream) HD_HIP(hipEventRecord(sl.ev_front, qa));
-    const auto h2 = std::chrono::steady_clock::now();
     // ---- back half on qb: [stage 2 +] low-pass + discriminator + buffer slide, [spectrum,] symbol extractor, results.  It may
     // still be running when the NEXT call's front half starts on qa: the two halves touch disjoint buffers (DESIGN.md
     // "two-stream pipeline").
     if (!e->one_stream) HD_HIP(hipStreamWaitEvent(qb, sl.ev_front, 0));
-    mark();
     bool done_on_dispatch = false;
-    static const bool dispatch_events = !getenv("HD_STEP_PACKET_EVENTS");
-    const bool ev_ride = dispatch_events && !sl.timed && e->one_stream;   // (two queues: the event is not on the step's critical path, and /16 measured no better with it on the dispatch)
+    const bool ev_ride = !sl.timed && e->one_stream;   // (two queues: the event is not on the step's critical path, and /16 measured no better with it on the dispatch)
     if (tail) {
         if (lean) hd::launch_fetch_params(qb, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
         fill_tail(ta);
@@ -1152,16 +1137,12 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
                              e->tail.p, e->tail_cap, e->d_symstate.p, fnext, e->fir_head.p + (size_t)cin * S * e->head_cap, e->fir_head_n.p + (size_t)cin * S,
                              e->fir_head.p + (size_t)cout * S * e->head_cap, e->fir_head_n.p + (size_t)cout * S, e->head_cap);
     }
-    mark();
-    mark();
     if (!tail)
     hd::launch_symbols(qb, S, max_m, max_new, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p,
-                       dcall, sl.h_slots.dev, e->slot_words, e->flips_cap ? e->flips_dbg.p : nullptr, e->flips_cap, e->min_R, ev_ride ? sl.ev_done : nullptr);
+                       dcall, sl.h_slots.dev, e->slot_words, e->flips_cap ? e->flips_dbg.p : nullptr, e->flips_cap, e->min_R, sl.seq, ev_ride ? sl.ev_done : nullptr);
     if (!tail && ev_ride) done_on_dispatch = true;
-    mark();
     if (sl.timed) HD_HIP(hipEventRecord(sl.t3, qb));
     if (!done_on_dispatch) HD_HIP(hipEventRecord(sl.ev_done, qb));
-    mark();
     HD_HIP(hipGetLastError());
     sl.busy = true;
     e->cur ^= 1;
@@ -1169,15 +1150,6 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     if (max_in && nst) e->hist_cur ^= 1;
     ++e->calls;
     e->last_timing.host_enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
-    if (getenv("HD_TRACE") && e->last_timing.host_enqueue_us > 400) {
-        fprintf(stderr, "[hd] slow call %llu:", (unsigned long long)e->calls);
-        for (int i = 0; i < ntp; ++i) fprintf(stderr, " %.0f", tp[i]);
-        fprintf(stderr, "\n");
-    }
-    if (getenv("HD_TRACE") && (e->calls % 64) == 0)
-        fprintf(stderr, "[hd] call %llu: mirror %.1f us, front enqueue %.1f us, back enqueue %.1f us\n", (unsigned long long)e->calls,
-                std::chrono::duration<double, std::micro>(h1 - h0).count(), std::chrono::duration<double, std::micro>(h2 - h1).count(),
-                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h2).count());
     if (!e->cfg.pipeline) { ++e->delivered; return collect(e, sl); }
     // pipelined: keep up to two calls in flight; deliver the oldest one's results now (its host stage overlaps the GPU work
     // of the newer calls, and the GPU always has the next call queued)

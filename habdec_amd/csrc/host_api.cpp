@@ -56,6 +56,7 @@ size_t hd_host_lowpass_design(float cutoff_rel, float transition, size_t batch, 
 
 hd_host_rtty* hd_host_rtty_new(size_t nbits, float nstops) { auto* r = new hd_host_rtty; r->f.nbits = nbits; r->f.nstops = nstops; return r; }
 void hd_host_rtty_free(hd_host_rtty* r) { delete r; }
+size_t hd_host_rtty_pending(const hd_host_rtty* r) { return r ? r->f.pending() : 0; }
 size_t hd_host_rtty_push_run(hd_host_rtty* r, const uint8_t* bits, size_t n, char* out, size_t cap)
 {
     r->f.push_bits(bits, n);

@@ -28,13 +28,7 @@
 #include "tail_body.h"
 #include "stage1_ring.h"
 
-#ifndef HD_DEC_LA
-#define HD_DEC_LA 4        // products this many taps ahead of the sum in the single-wave first stages
-#endif
-
-#ifndef HD_DEC_MAXW
 #define HD_DEC_MAXW 4     // most waves per SIMD the 256-lane stages are compiled for (their registers and LDS decide what they get: 3-4)
-#endif
 
 namespace hd {
 
@@ -69,25 +63,6 @@ constexpr int dec_tile_f4()                        // float4 slots of a workgrou
     constexpr int OPL = dec_opl<D>(), TOUT = TO * OPL, RD = OPL * D, JS = (T - 1) & 1;
     constexpr int NJJ = (TOUT - 1) * D + T + JS, NL = NJJ + 2 * (NJJ / RD) + 4;
     return (NL + 1) / 2 + TOUT / 2 + 1;
-}
-
-// Taps [J0, J1) of a 16-slot chunk for ONE accumulator (a lane's only output), products LA taps ahead of the sum: the T-term sum is a
-// serial chain of adds by definition (ascending tap order, one accumulator), but the products are independent -- written as
-// "acc = acc + x * k" the compiler multiplies into one temporary right in front of each add and the wave waits out the multiplier
-// AND the adder on every tap.  With the products a few taps ahead, an independent multiply sits between consecutive adds.
-template <int J0, int J1, int LA>
-__device__ __forceinline__ void dec_chunk_mac(f32x2& acc, const f32x4 (&x)[8], const float (&k)[16])
-{
-    auto smp = [&](int j) -> f32x2 { return (j & 1) ? x[j >> 1].zw : x[j >> 1].xy; };
-    f32x2 pr[LA];
-#pragma unroll
-    for (int j = J0; j < J0 + LA; ++j)
-        if (j < J1) pr[(j - J0) % LA] = smp(j) * k[j];
-#pragma unroll
-    for (int j = J0; j < J1; ++j) {
-        acc = acc + pr[(j - J0) % LA];
-        if (j + LA < J1) pr[(j - J0) % LA] = smp(j + LA) * k[j + LA];
-    }
 }
 
 #ifdef HD_STAMP_TAIL  // diagnostic build only: the phase clocks of the tails that ran inside step launches (this translation unit's copy)
@@ -205,7 +180,6 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
         };
         const long xe = (long)tile_i * TOUT * D - (T - 1) - JS;    // stream sample of LDS slot 0; even
         const float4* src = reinterpret_cast<const float4*>(in_s + xe);
-#ifndef HD_DEC_NO_FASTLOAD
         // A tile that lies wholly inside this call's input -- all but a stream's first and (sometimes) last: one scalar test, then ITER
         // plain loads off one scalar base with immediate offsets.  (Tested per sweep, the compiler kept the bounds in vector registers
         // and put ten instructions between consecutive loads.)
@@ -218,7 +192,6 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
             for (int it = 0; it < ITER; ++it) r[it] = *reinterpret_cast<const float4*>(base + (lane_off + (uint32_t)it * (TO * 16u)));
             return;
         }
-#endif
         // Per sweep of TO pairs: plain aligned 16-byte loads when the whole sweep lies inside this call's input (wave-uniform
         // test); only the sweeps that touch the history in front of the stream (first tile: the first ceil((T-1)/2/TO) sweeps)
         // or the end of the input take the address-selecting path.
@@ -241,13 +214,6 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
         }
     };
 
-#ifdef HD_DEC_STAGGER   // experiment: start a CU's eight waves an eighth of a tile period apart (HW_ID: wave slot [3:0], SIMD [5:4])
-    {
-        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
-        const unsigned slot8 = ((hw >> 4) & 3u) * 2u + (hw & 1u);
-        for (unsigned i = 0; i < slot8; ++i) __builtin_amdgcn_s_sleep(HD_DEC_STAGGER);
-    }
-#endif
     DSTAMP_DECL;
     load_tile(first, false);                                // (a workgroup's first tile: once, through the general path only)
     const float2* p = tile + threadIdx.x * (RD + 2);
@@ -324,7 +290,6 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
         // together, then 2*B packed multiply/add) inside a rolled loop: that keeps ~B taps live in SGPRs instead
         // of all T (which spilled SGPRs through v_writelane) and puts B/2 LDS reads in flight per wave.
         float2 yq[OPL];
-#ifndef HD_DEC_OLDLOOP
         if constexpr (OPL == 1 && D >= 32 && (D % 16) == 0) {
             // Single-wave first stages (/32, /64): 16-slot chunks (never across a row pad), the next chunk's LDS reads and taps requested
             // before the current chunk is summed (two register images, rolled loop over chunk pairs), products ahead of the adds.
@@ -380,15 +345,10 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
             }
             yq[0] = make_float2(acc.x, acc.y);
         } else
-#endif
         if constexpr (OPL == 1) {
             float ar = 0.f, ai = 0.f;
             auto mac = [&](float xr, float xi, float k) { ar = ar + xr * k; ai = ai + xi * k; };
-    #ifdef HD_DEC_B16   // 181 instead of 207 VGPRs for D = 32; +1 % in batch mode, -3 % alone (measured) -- not the default
-            constexpr int B = 16;
-    #else
             constexpr int B = D >= 32 ? 32 : 16;               // slots per block; pad inside a block is compile-time
-    #endif
             constexpr int NS = T + JS;                          // slots [JS, NS) carry taps [0, T)
             constexpr int NFULL = NS / B;                       // full blocks; block 0 is peeled when JS (slot 0 unused)
             // block 0 (peeled): slots [0, B) or the whole filter when it is shorter than a block
@@ -403,11 +363,7 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
                     }
                 }
             }
-    #ifdef HD_EXP_NOCOMPUTE
-            if (false) {
-    #else
             if (NFULL > 1) {
-    #endif
     #pragma unroll 1
                 for (int b = 1; b < NFULL; ++b) {
                     const int j0 = b * B;
@@ -565,16 +521,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(D == 64 ? 1 
     if (blockIdx.x < n_tail) {
         // the tails are latency chains with nobody to hide behind; the stage-1 waves beside them are waiting for HBM most of the
         // time and lose nothing when the arbiter prefers the tail
-#ifndef HD_STEP_PRIO
 #define HD_STEP_PRIO 3
-#endif
         __builtin_amdgcn_s_setprio(HD_STEP_PRIO);
         tail_body<64, 4, D2, T2>(ta, blockIdx.x, reinterpret_cast<unsigned char*>(tile4));
         return;
     }
-#ifdef HD_STEP_S1_PRIO
-    __builtin_amdgcn_s_setprio(HD_STEP_S1_PRIO);
-#endif
     decimate_body<D, T, 64>(in, in_stride, hist_in, hist_out, taps, out, out_stride, call, 0, 0, 0u, 0u, nullptr, n_streams, lin_ntiles, call_copy,
                             blockIdx.x - n_tail, 0u, gridDim.x - n_tail, tile4, uniform_n, claim);
 }
@@ -749,13 +700,8 @@ static void launch_one(hipStream_t st, uint32_t n_streams, uint32_t max_out, con
     // 256 CUs x ~4 resident workgroups; keep >= ~2048 workgroups when the batch allows it.
     uint32_t per = 1;
     while (per < 16 && (uint64_t)((ntiles + 2 * per - 1) / (2 * per)) * n_streams >= 2048) per *= 2;
-    static const uint32_t per_env = getenv("HD_DEC_PER") ? (uint32_t)atoi(getenv("HD_DEC_PER")) : 0u;    // (experiments: tiles per workgroup of the classic grid)
-    if (per_env) per = per_env;
     dim3 grid((ntiles + per - 1) / per, n_streams);
-    // (extra dynamic LDS lowers how many of these workgroups a CU takes -- room for the other queue's kernels; HD_DEC_LDS_PAD, first stages only)
-    static const uint32_t pad_env = getenv("HD_DEC_LDS_PAD") ? (uint32_t)atoi(getenv("HD_DEC_LDS_PAD")) : 0u;
-    const uint32_t pad = (stage == 0 && !final_stage) ? pad_env : 0u;
-    hipLaunchKernelGGL((k_decimate<D, T, TO>), grid, dim3(TO), pad, st, in, in_stride, hist_in, hist_out, taps, out, out_stride, call,
+    hipLaunchKernelGGL((k_decimate<D, T, TO>), grid, dim3(TO), 0, st, in, in_stride, hist_in, hist_out, taps, out, out_stride, call,
                        stage, final_stage, fir_hist_cap, per, fft_in, n_streams, 0u, (StreamCall*)nullptr, 0u, StepClaim{});
 }
 
@@ -870,8 +816,7 @@ bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, cons
     if (n_loaders != 1u) n_loaders = 2u;
     if (ratio <= 4) {            // 278 flop per input sample (/4): the vector pipes bind, not HBM -- one loader is plenty, and every other wave slot computes
         n_loaders = 1u;
-        static const uint32_t w4 = getenv("HD_S1_WAVES4") ? (uint32_t)atoi(getenv("HD_S1_WAVES4")) : 16u;
-        n_waves = (w4 >= 8u && w4 <= 16u) ? w4 : 16u;
+        n_waves = 16u;
     }
     if (n_slots < 2u * n_loaders || n_slots > 8u) n_slots = 8u;
     if (n_waves < 8u || n_waves > 16u) n_waves = 8u;

@@ -69,6 +69,7 @@ void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t
                     uint32_t ring_cap, SymState* sym, unsigned long long* flipmask, float* weight, const SymbolParams* sp,
                     const StreamCall* call, uint32_t* slots, uint32_t slot_words, uint32_t* flips_dbg, uint32_t flips_cap,
                     uint32_t min_R /* smallest averaging half-window over the streams: bounds the flips one call can find */,
+                    uint32_t seq /* the call's tag, stored last into every result slot (BitsHeader::seq) */,
                     hipEvent_t ev_stop = nullptr /* signalled by the dispatch itself, as in launch_step_cu */);
 
 // ---- the fused stream tail (tail_body.h / tail.hip): stage 2 + low-pass + discriminator + symbol extractor, one wave per stream
@@ -85,6 +86,7 @@ struct TailArgs {
     // symbol extractor (same rings and state as launch_symbols)
     float* ring; uint32_t ring_cap; SymState* sym; unsigned long long* flipmask; float* wsum; const SymbolParams* sp;
     uint32_t* slots; uint32_t slot_words; uint32_t* flips_dbg; uint32_t flips_cap;
+    uint32_t seq;                                   // the call's tag, stored last into the result slot (BitsHeader::seq)
     // spectrum of a stream whose 4096-sample buffer completes in this call, done by the tail itself when fft_tw != nullptr (spectrum_wave.h)
     const float2* fft_tw; float2* spec; float* power; SpectrumStatsDev* stats; double rate; int bins_sep;
     // LDS carve in bytes from the base of the workgroup's scratch (tail_layout)

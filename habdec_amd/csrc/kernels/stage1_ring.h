@@ -172,12 +172,8 @@ __device__ __forceinline__ void glds16_x17(const void* base, const uint32_t (&of
 // 156.2 us, stage 1 alone 115.6 -> 111.2; MI355X_MICROARCH.md rows ldsdma-fill / nt-weights) -- EXCEPT the last two of the seventeen instructions:
 // they carry the tile's rows 56.5 .. 63, whose last seven are the NEXT tile's halo; left on the default policy they stay in this XCD's L2 for that
 // re-read (with nt on all seventeen the PMC traffic of a step launch rose from 630.6 to 647.6 MB: the halo reads went to HBM).  The halo rows
-// themselves are default-policy loads.  -DHD_GLDS_DEFAULT_POLICY: the A/B build without nt.
-#ifndef HD_GLDS_DEFAULT_POLICY
+// themselves are default-policy loads.
 #define HD_GLDS_BODY_POLICY " nt"
-#else
-#define HD_GLDS_BODY_POLICY ""
-#endif
 #define HD_G1(n) "global_load_lds_dwordx4 %" #n ", %19" HD_GLDS_BODY_POLICY "\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
 #define HD_G1D(n) "global_load_lds_dwordx4 %" #n ", %19\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
     asm volatile("s_cselect_b32 %1, 1, 0\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %20\n\ts_nop 0\n\t"
@@ -350,16 +346,6 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
 }
 
 // -------------------------------------------------------------------------------------------------------------- a consumer wave
-template <int J0, int J1>
-__device__ __forceinline__ void ring_mac16(r_f32x2& acc, const r_f32x4 (&x)[8], const float (&k)[16])
-{
-#pragma unroll
-    for (int j = J0; j < J1; ++j) {
-        const r_f32x2 smp = (j & 1) ? x[j >> 1].zw : x[j >> 1].xy;
-        acc = acc + smp * k[j];
-    }
-}
-
 // Sixteen taps of ONE sum, scheduled by hand: the sum is a serial chain of adds by definition (ascending tap order, one accumulator), the
 // products are not -- but written as "acc = acc + x * k" the compiler multiplies into a temporary right in front of each add, and a lone wave
 // then waits out the multiplier's latency sixteen times per chunk (tools/micro/valu_rate.hip: 6.4 cycles per instruction against 5.2 for

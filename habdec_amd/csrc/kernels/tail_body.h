@@ -100,8 +100,7 @@ __device__ __forceinline__ void tb_sync()
 
 // NT lanes, OP stage-2 outputs per lane and piece, stage-2 design (D2, T2).
 template <int NT, int OP, int D2, int T2>
-__device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, unsigned char* __restrict__ lds,
-                                          const uint32_t prio_phase = 2u /* 0 / 1: one of two tails sharing a SIMD inside a step launch -- see HD_TAIL_PRIO_ALT below; 2: leave the priority alone */)
+__device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, unsigned char* __restrict__ lds)
 {
     constexpr int P = NT * OP;                      // stage-2 outputs per piece
     constexpr int XCH = P * D2;                     // stage-1 samples a piece consumes
@@ -312,12 +311,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
             const bool any = KP * tid < cnt;
             float wp[KP];
             if (any) {
-#if defined(HD_TB_EXP) && (HD_TB_EXP & 16)   // ablation: what the window sums cost (results wrong)
-#pragma unroll
-                for (int j = 0; j < (int)KP; ++j) wp[j] = V[off + KP * tid + j];
-#else
                 window_sums8(V + off + KP * tid, R, wp);
-#endif
                 TSTAMP(19);
 #pragma unroll
                 for (int j = 0; j < (int)KP; ++j) WS[off + R + KP * tid + j] = wp[j];
@@ -390,16 +384,6 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     // change: the whole backlog is due), then the pieces of the call -- so that the window-sum code exists once.
     uint32_t old_left = old_cnt - take0;
     for (uint32_t pc = 0;;) {
-#ifndef HD_TAIL_PRIO_EQUAL
-        // Two tails share a SIMD inside a step launch, and at equal priority the issue arbiter prefers the OLDER wave every time both are ready:
-        // the younger tail finishes ~20 us after its neighbour (in-kernel clocks, round 4), and the launch's second half -- the slots across PAIRS of
-        // finished tails -- waits for the later one.  Taking turns at the higher priority, piece by piece, lets the two progress alike: launch 152.5 ->
-        // 149.4 us, 0.1576-0.1587 -> 0.1543-0.1560 ms per step (one box, alternating builds; the younger one always on top: 150.5 us).
-#ifndef HD_TAIL_PRIO_LOW
-#define HD_TAIL_PRIO_LOW 2
-#endif
-        if (prio_phase < 2u) { if ((pc + prio_phase) & 1u) __builtin_amdgcn_s_setprio(HD_TAIL_PRIO_LOW); else __builtin_amdgcn_s_setprio(3); }
-#endif
         if (do_sums) {
             tb_sync<NT>();
             sym_feed();
@@ -584,14 +568,10 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
                             float pr = qv.x, pi = qv.y;
                             if (i == 0 && !kin.primed) { pr = c0.x; pi = c0.y; }   // very first sample: arg(y0*conj(y0)) (FSK2_Demod.h:35)
                             float d[4];
-#if defined(HD_TB_EXP) && (HD_TB_EXP & 4)
-                            d[0] = c0.x * pr; d[1] = c1.x * pi; d[2] = c2.x; d[3] = c3.y;
-#else
                             d[0] = discriminate(c0.x, c0.y, pr, pi);
                             d[1] = discriminate(c1.x, c1.y, c0.x, c0.y);
                             d[2] = discriminate(c2.x, c2.y, c1.x, c1.y);
                             d[3] = discriminate(c3.x, c3.y, c2.x, c2.y);
-#endif
                             const f32x2 av[4] = {c0, c1, c2, c3};
 #pragma unroll
                             for (int u = 0; u < 4; ++u)
@@ -830,9 +810,6 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     constexpr int NX = kTailStrip / 64;
     auto chain = [&](float acc, uint32_t a0, uint32_t b) -> float {     // acc + v[a0] + ... + v[b-1] (backlog indices)
         if (a0 >= b) return acc;
-#if defined(HD_TB_EXP) && (HD_TB_EXP & 8)   // ablation: what the run sums cost (results wrong)
-        return acc + (float)(b - a0);
-#endif
         if (a0 >= carried_to && b - carried_to <= vc_n) {               // the samples are in LDS already (wave-uniform addresses: broadcast reads)
             const float* v0 = vc + (a0 - carried_to);
             uint32_t n = b - a0, i = 0;
@@ -958,14 +935,15 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     // ---- the stream's spectrum, when its 4096-sample buffer completed in this call (Decoder.h:475-489): transform, half swap, power and
     // AFC statistics by this same wave (spectrum_wave.h) -- no launches of their own, no fft_raw round trip.  The buffer's last samples
     // were stored by this workgroup a moment ago.
-#ifndef HD_TB_NO_SPECTRUM     // (register-budget experiments: the tail without the in-wave transform)
     if (a.fft_tw && c.fft_run) {
         __threadfence_block();
         tb_sync<NT>();                                                  // every wave is done with the LDS images
         if (wave == 0)
             spectrum_wave_body(a.fft_in, a.fft_tw, a.spec, a.power, a.stats, s, a.rate, a.bins_sep, reinterpret_cast<float*>(lds + kTailHdrBytes));
     }
-#endif
+    // the call's tag, LAST: every store this wave has issued -- header, bits, spectrum statistics, all by wave 0 -- has been acknowledged before it goes out
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) __hip_atomic_store(&hdr->seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     TSTAMP_WRITE();
 }
 

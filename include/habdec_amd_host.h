@@ -30,6 +30,7 @@ typedef struct hd_host_rtty hd_host_rtty;
 hd_host_rtty* hd_host_rtty_new(size_t nbits, float nstops);
 void hd_host_rtty_free(hd_host_rtty*);
 size_t hd_host_rtty_push_run(hd_host_rtty*, const uint8_t* bits, size_t n, char* out, size_t cap);
+size_t hd_host_rtty_pending(const hd_host_rtty*);   /* unframed bits the framer still holds (bounded: 2^18 + what can still frame) */
 
 /* CRC (CRC.cpp:21-47) and extractSentence (sentence_extract.cpp:58-98) */
 void hd_host_crc16(const char* s, size_t n, char out4[5]);

@@ -118,18 +118,14 @@ def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, s
     eng.close()
 
 
-@pytest.mark.parametrize("kernel", ["per_cu", "single_wave_drawn", "single_wave"])
+@pytest.mark.parametrize("kernel", ["per_cu", "single_wave"])
 def test_stage1_alone_at_full_size(monkeypatch, headline_ring, kernel):
-    """Synchronous calls (what the Decoder facade makes): stage 1 as a launch of its own, then the stream tails.  "per_cu": one workgroup per CU
-    with two LDS-DMA loader waves, eight tile slots and six computing waves (k_stage1_cu, the default for a /32 first stage; one loader and twelve waves: the second variant); "single_wave_drawn":
-    k_decimate drawing runs from the per-XCD counters (HD_CLAIM_ALONE=1: measured slower than fixed shares, off by default; the path stays
-    covered); "single_wave": k_decimate with fixed shares."""
+    """Synchronous calls (what the Decoder facade makes): stage 1 as a launch of its own, then the stream tails.  "per_cu": one workgroup per CU of eight
+    worker waves, each loading its own tiles with LDS-DMA (k_stage1_cu, the default for a /32 first stage); "single_wave": k_decimate with fixed shares."""
     import habdec_amd
     from oracle import pyoracle
     if not kernel.startswith("per_cu"):
         monkeypatch.setenv("HD_NO_CU_STEP", "1")
-    if kernel == "single_wave_drawn":
-        monkeypatch.setenv("HD_CLAIM_ALONE", "1")
     w, ring, ring_chunks = headline_ring
     S, fs = w["S"], w["fs"]
     check = [0, 127, 128, 511, 512, 775, 1023]

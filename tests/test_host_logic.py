@@ -108,6 +108,37 @@ def test_rtty_framer_forgets_what_can_never_frame(L, O, nbits, nstops):
     L.hd_host_rtty_free(h)
 
 
+def test_rtty_framer_at_its_bound_of_kept_bits(L, O):
+    """The one place the framer departs from the reference: beyond 2^18 unframed bits it forgets the oldest ones that can no longer
+    frame in the current format.  At, just below and far beyond the bound the BYTES stay the reference's (the oracle keeps every bit and scans them all),
+    and what is held stays bounded."""
+    KEEP = 1 << 18
+    nbits, nstops = 7, 2.0
+    chars = synth.rtty_bits("$$EDGE,9,9*0A0B\n", nbits, 2, 0, 0)
+    r = np.random.default_rng(18)
+    broken = np.tile(np.concatenate([[0], r.integers(0, 2, nbits), [0, 0]]).astype(np.uint8), 3000)        # 30 000 bits of start bits whose stop bits never come
+    pieces = [np.ones(KEEP - 7, np.uint8), chars,                   # idle up to just below the bound, then characters
+              np.ones(12, np.uint8), chars,                         # ... across it
+              np.zeros(KEEP + 4321, np.uint8), chars,               # a stuck-at-zero stretch longer than the bound (every bit a start bit without stop bits)
+              broken, np.ones(KEEP, np.uint8), broken, chars[:-1],  # unframeable structure, idle, more of it, and a character that is one bit short
+              np.ones(1, np.uint8), chars]
+    ro = O.rtty(nbits, nstops)
+    h = L.hd_host_rtty_new(nbits, nstops)
+    got_all, held = b"", []
+    for piece in pieces:
+        ro.push(piece)
+        want = ro.run()
+        buf = C.create_string_buffer(1 << 12)
+        n = L.hd_host_rtty_push_run(h, np.ascontiguousarray(piece), len(piece), buf, len(buf))
+        assert buf.raw[:n] == want
+        got_all += buf.raw[:n]
+        held.append(L.hd_host_rtty_pending(h))
+    assert got_all.count(b"EDGE") == 5
+    assert max(held) <= KEEP + len(chars) + 16, held                # bounded: the kept bits + what can still frame
+    assert sum(len(x) for x in pieces) > 3 * KEEP
+    L.hd_host_rtty_free(h)
+
+
 def _extract(L, s):
     b = s.encode("latin-1")
     cap = len(b) + 1

@@ -68,3 +68,34 @@ def test_algorithmic_bytes_model():
     import bench
     assert bench.bytes_per_sample(64) == pytest.approx(8.1875) and bench.bytes_per_sample(4) == 11.0
     assert set(bench.WORKLOADS) == {"cfg1", "cfg2", "cfg3", "cfg4", "cfg5"}
+
+
+def _bench(*args, env=None):
+    import json
+    import subprocess
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True, timeout=300, env=e)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
+
+
+def test_bench_gpus_n_as_a_plain_command_starts_n_ranks():
+    """`python bench.py --gpus 8` without torchrun ran on ONE GPU and said n_gpus: 1.  The plain command now starts the ranks itself (the parent
+    never imports torch), relays rank 0's line and fails when the ranks fail; a world size that differs from --gpus is an error.  --dry-run: the launch
+    plumbing alone (gloo), no GPU."""
+    rc, line, err = _bench("--gpus", "2", "--dry-run", "--steps", "3")
+    assert rc == 0 and line is not None, err[-2000:]
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["steps"] == 3
+    assert line["shards"] == [[0, 1024], [1024, 2048]]
+    assert line["slowest_rank_ms"] == pytest.approx(2.0)            # the MAX over ranks (rank r reports r + 1 ms)
+    rc1, line1, _ = _bench("--dry-run")
+    assert rc1 == 0 and line1["n_gpus"] == 1
+    # asked for two, started inside a one-rank job: refused, not a silently smaller run
+    rc2, line2, err2 = _bench("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc2 != 0 and line2 is None and "--gpus 2" in err2
+    # without GPUs the real run fails in every rank -- and so does the launcher
+    rc3, line3, _ = _bench("--gpus", "2", "--steps", "1")
+    assert rc3 != 0 and line3 is None

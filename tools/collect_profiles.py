@@ -33,16 +33,25 @@ def main():
     tag, rnd, workload = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "cfg4")
     src = ROOT / "gpurun_out" / f"prof_{tag}"
     dst = ROOT / "profiles"
-    # 1. kernel stats summary
+    # 1. kernel stats summaries: rocprofv3's own (every launch, the loop's ramp included) and the steady-state one (tools/steady_stats.py on the GPU box:
+    # launches behind the first 150 of the dominant kernel), which is what bench.py's roofline.frac_rocprof refers to
     rows = []
-    with open(next((src / "stats").glob("*kernel_stats.csv")), newline="") as f:
+    with open(next(p for p in (src / "stats").glob("*kernel_stats.csv") if "steady" not in p.name), newline="") as f:
         rd = csv.DictReader(f)
         for r in rd:
             k = short(r["Name"])
             if k: rows.append([k, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
-    out = dst / f"{rnd}_kernel_stats.csv"
+    out = dst / f"{rnd}_kernel_stats_all_launches.csv"
     with open(out, "w", newline="") as f:
         w = csv.writer(f); w.writerow(["Kernel", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"]); w.writerows(rows)
+    steady = src / "stats" / "steady_kernel_stats.csv"
+    out = dst / f"{rnd}_kernel_stats.csv"
+    if steady.exists():
+        out.write_text(steady.read_text())
+        with open(steady, newline="") as f:
+            rows = [[r["Kernel"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]] for r in csv.DictReader(f)]
+    else:
+        out.write_text((dst / f"{rnd}_kernel_stats_all_launches.csv").read_text())
     # 2. PMC traffic per launch (steady-state launches: drop the warm-up launches with tiny grids by taking the median)
     fetch = pmc(next((src / "fetch").glob("*counter_collection.csv")), "FETCH_SIZE")
     write = pmc(next((src / "write").glob("*counter_collection.csv")), "WRITE_SIZE")
