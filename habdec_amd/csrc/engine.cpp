@@ -133,7 +133,10 @@ struct hd_engine {
     uint32_t ring_run = 0;     // HD_RING_RUN: tiles per drawn run of the per-CU ring kernels (default: pick_ring_run)
     static constexpr uint32_t kS1Loaders = 2;   // LDS-DMA loader waves of k_stage1_cu at /8 and /4 (round 4: with the nt policy on the body rows one loader's three
                                                 // tiles in flight bound the launch -- 102.7 us with one loader, 94.7 with two, one box, alternating)
-    static constexpr uint32_t kS1Slots = 4;     // tile slots of k_stage1_cu in batch mode on the separate-kernels path: four leave half of a CU's LDS to the back-half
+#ifndef HD_S1_SLOTS_BATCH
+#define HD_S1_SLOTS_BATCH 4
+#endif
+    static constexpr uint32_t kS1Slots = HD_S1_SLOTS_BATCH;     // tile slots of k_stage1_cu in batch mode on the separate-kernels path: four leave half of a CU's LDS to the back-half
                                                 // workgroups of the previous call on the other queue (/16: 0.334-0.343 ms per step against 0.342-0.351 with eight)
     PinBuf<unsigned int> ring_gave_up;     // mapped host word a wave of k_step_cu / k_stage1_cu sets when a bounded wait runs out (never in a correct run)
     bool device_failed = false;            // ... after which the engine stays failed: the launch that gave up left stage-1 output incomplete, and up to
@@ -666,7 +669,8 @@ int collect(hd_engine* e, hd_engine::CallSlot& sl)
     int rc = HD_OK;
     {   // every stream's slot must carry this call's tag (the kernels store it last); in practice it is there when the event has fired -- if not, wait for it
         const auto t_lim = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
-        for (uint32_t s = 0; s < e->S && !e->device_failed; ++s) {
+        static const bool timing_experiment = getenv("HD_CU_EXP") != nullptr;      // (step launches without their tails or without stage 1: nothing writes the slots)
+        for (uint32_t s = 0; s < e->S && !e->device_failed && !timing_experiment; ++s) {
             const volatile uint32_t* tag = &reinterpret_cast<const volatile hd::BitsHeader*>(sl.h_slots.p + (size_t)s * e->slot_words)->seq;
             while (*tag != sl.seq) {
                 if (std::chrono::steady_clock::now() > t_lim) {
@@ -953,7 +957,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         const uint64_t runs = (uint64_t)S * ntiles / run_len;
         const bool shape_ok = run_len_cu ? (hd::stage1_cu_supported((int)R1, (int)T1) && max_in % 2048u == 0) : ((R1 == 32 || R1 == 64) && max_n1 % 64 == 0);
         if (!e->no_claim && (nst == 2 || (run_len_cu && nst == 1)) && shape_ok && min_in == max_in && max_in && !any_zero1 && n_xcd && e->n_cus % 32u == 0 && n_xcd <= 16 &&
-            ntiles && ntiles % run_len == 0 && runs % n_xcd == 0 && (uint64_t)S * ntiles < (1ull << 32) && (uint64_t)ntiles * S >= 4ull * lin_wgs) {   // (the two counter sets alternate: a launch that takes one must really run that way)
+            ntiles && (ntiles % run_len == 0 || (run_len_cu && R1 >= 32 && ((uint64_t)S * ntiles) % run_len == 0)) && runs % n_xcd == 0 && (uint64_t)S * ntiles < (1ull << 32) && (uint64_t)ntiles * S >= 4ull * lin_wgs) {   // (the two counter sets alternate: a launch that takes one must really run that way)
             claim.ctr = e->step_ctr.p + (size_t)(e->step_launches & 1u) * 16 * 32;
             claim.ctr_next = e->step_ctr.p + (size_t)((e->step_launches & 1u) ^ 1u) * 16 * 32;
             claim.n_xcd = n_xcd; claim.runs_per_xcd = (uint32_t)(runs / n_xcd); claim.run_len = run_len;
@@ -966,8 +970,9 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     // last runs of a launch are its ragged end: four measured best among 3 / 4 / 6 / 9 / 12 (0.1360-0.1368 ms per step against 0.1386 with nine, one box,
     // alternating); the loader / consumer kernels of the smaller ratios keep eight (round 4).  The nearest usable length, the longer one first.
     auto pick_ring_run = [&](const uint32_t ntiles) -> uint32_t {
-        const uint32_t n_xcd = e->n_cus / 32u ? e->n_cus / 32u : 1u, want = R1 == 32 ? 4u : 8u;
-        auto ok = [&](uint32_t r) { return r >= 2u && r <= ntiles && ntiles % r == 0 && ((uint64_t)S * ntiles / r) % n_xcd == 0; };
+        const uint32_t n_xcd = e->n_cus / 32u ? e->n_cus / 32u : 1u, want = R1 >= 32 ? 4u : 8u;
+        // (the worker waves of the /32 and /64 stages walk a run on into the next stream: it need not divide a stream's tiles, only the slab's)
+        auto ok = [&](uint32_t r) { return r >= 2u && r <= ntiles && (R1 >= 32 ? ((uint64_t)S * ntiles) % r == 0 : ntiles % r == 0) && ((uint64_t)S * ntiles / r) % n_xcd == 0; };
         if (e->ring_run >= 2 && ok(e->ring_run)) return e->ring_run;
         for (uint32_t d = 0; d <= 8u; ++d) {
             if (ok(want + d)) return want + d;

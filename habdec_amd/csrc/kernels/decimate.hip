@@ -592,15 +592,16 @@ __global__ __launch_bounds__(512) void k_step_cu(const RingArgs ra, const Stream
 }
 
 // Stage 1 ALONE in the same shape (synchronous delivery, the first half of a call whose tails run as a launch of their own): one workgroup per CU.
-// D = 32: eight worker waves, each with its own slot (ring_worker).  D = 8 (the /8 first stage of /16 plans, four outputs per lane row) and D = 4 (the
+// D = 32: eight worker waves, each with its own slot (ring_worker); D = 64 (the /64 first stage of /256 plans: rows of 64 samples, 33 KB slots): four, or
+// three where the previous call's 4097-tap low-pass on the other queue needs its 45 KB of the CU's LDS.  D = 8 (the /8 first stage of /16 plans, four outputs per lane row) and D = 4 (the
 // only stage of a /4 plan, eight outputs per lane): a lane's window spans several rows there and the slot stays busy while it is summed, so these keep
 // the loader / consumer arrangement -- one or two LDS-DMA loader waves with up to eight tile slots between them, computing waves in all the others.
 template <int T, int D>
-__global__ __launch_bounds__(D == 4 ? 1024 : 512) void k_stage1_cu(const RingArgs ra, const uint32_t n_loaders, const uint32_t n_slots /* 2 .. 8 */)
+__global__ __launch_bounds__(D == 4 ? 1024 : D == 64 ? 256 : 512) void k_stage1_cu(const RingArgs ra, const uint32_t n_loaders, const uint32_t n_slots /* 2 .. 8 */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char cu_lds[];
-    if constexpr (D == 32) {
-        ring_worker<T>(ra, cu_lds + (threadIdx.x >> 6) * (uint32_t)kWorkSlotBytes, threadIdx.x >> 6);
+    if constexpr (D == 32 || D == 64) {
+        ring_worker<T, D>(ra, cu_lds + (threadIdx.x >> 6) * (uint32_t)work_slot_bytes<D>(), threadIdx.x >> 6);
     } else {
     unsigned char* ring = cu_lds;
     RingCtl* ctl = reinterpret_cast<RingCtl*>(cu_lds + n_slots * ring_slot_bytes<T>());
@@ -748,15 +749,16 @@ bool launch_step(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2, u
 // (stage1_ring.h: ring_adv); the smaller ratios keep tiles of 64 rows + halo, 2048 input samples each.
 uint32_t ring_tiles(int ratio, int ntaps, uint32_t n)
 {
-    if (ratio != 32) return n / 2048u;
-    const uint32_t adv = 64u - (uint32_t)((ntaps - 1 + 31) / 32);
-    return n / 32u >= 64u ? ring_sys_tiles(n, adv) : 0u;
+    if (ratio != 32 && ratio != 64) return n / 2048u;
+    const uint32_t adv = 64u - (uint32_t)((ntaps - 1 + ratio - 1) / ratio), rows = n / (uint32_t)ratio;
+    return rows >= 64u ? (rows + adv - 1u) / adv : 0u;
 }
 
 // what a publication word of the ring protocol can name (stage1_ring.h, RingCtl::pub): 24 bits of sequence number, 20 of stream, 12 of tile
-static bool ring_limits_ok(uint32_t ntiles, const StepClaim& claim)
+static bool ring_limits_ok(uint32_t ntiles, const StepClaim& claim, bool workers = false /* worker waves: a run may run on into the next stream */)
 {
     const uint64_t total = (uint64_t)claim.runs_per_xcd * claim.n_xcd * claim.run_len;
+    if (workers) return ntiles && claim.run_len >= 2u && total % ntiles == 0 && total < (1ull << 32);
     return ntiles && ntiles <= 4096u && claim.run_len && ntiles % claim.run_len == 0 && total < (1ull << 24) && total / ntiles <= (1ull << 20);
 }
 
@@ -773,7 +775,7 @@ bool launch_step_cu(hipStream_t st, int ratio, int ntaps, int ratio2, int ntaps2
 {
     if (ratio != 32 || !claim.ctr || !uniform_n || uniform_n % 2048u) return false;
     const uint32_t ntiles = ring_tiles(ratio, ntaps, uniform_n);
-    if (!ring_limits_ok(ntiles, claim)) return false;
+    if (!ring_limits_ok(ntiles, claim, true)) return false;
     if (tail_bytes < (uint32_t)kWorkSlotBytes) tail_bytes = (uint32_t)kWorkSlotBytes;       // (a finished tail's slice is its wave's tile slot)
     tail_bytes = (tail_bytes + 15u) & ~15u;
     RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, ntiles, claim, nullptr, nullptr, 0u, nullptr};
@@ -806,7 +808,7 @@ bool step_cu_supported(int ratio, int ntaps, int ratio2, int ntaps2)
 
 bool stage1_cu_supported(int ratio, int ntaps)
 {
-    return (ratio == 32 && (ntaps == 212 || ntaps == 174)) || (ratio == 8 && ntaps == 54) || (ratio == 4 && ntaps == 139);   // (/4: as a final stage)
+    return (ratio == 32 && (ntaps == 212 || ntaps == 174)) || (ratio == 64 && ntaps == 348) || (ratio == 8 && ntaps == 54) || (ratio == 4 && ntaps == 139);   // (/4: as a final stage)
 }
 
 bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, const float2* in, size_t in_stride, const float2* hist_in, float2* hist_out,
@@ -822,13 +824,14 @@ bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, cons
     if (n_waves < 8u || n_waves > 16u) n_waves = 8u;
     if (!claim.ctr || !uniform_n || uniform_n % 2048u) return false;
     const uint32_t ntiles = ring_tiles(ratio, ntaps, uniform_n);
-    if (!ring_limits_ok(ntiles, claim)) return false;
+    if (!ring_limits_ok(ntiles, claim, ratio >= 32)) return false;
     if ((ratio <= 4) != (final_call != nullptr)) return false;               // /4 exists as a FINAL stage only (the only stage of a plan), the others as first stages only
     RingArgs ra{in, in_stride, hist_in, hist_out, taps, out, out_stride, uniform_n, ntiles, claim, gave_up, final_call, fir_hist_cap, fft_in};
 #define HD_S1_CASE(D, T)                                                                                                              \
     if (ratio == D && ntaps == T) {                                                                                                   \
-        static_assert(D == 32 || (uint32_t)ring_bytes<T, kRingNSLAlone>() <= 163840u, "eight tile slots must fit a CU's LDS");       \
-        const uint32_t lds = D == 32 ? 8u * (uint32_t)kWorkSlotBytes : n_slots * (uint32_t)ring_slot_bytes<T>() + (uint32_t)kRingCtlBytes; \
+        static_assert(D >= 32 || (uint32_t)ring_bytes<T, kRingNSLAlone>() <= 163840u, "eight tile slots must fit a CU's LDS");       \
+        const uint32_t workers = D == 32 ? 8u : n_slots <= 4u ? 3u : 4u;            /* (/64: 33 KB slots; three leave room for the other queue's FIR tile) */ \
+        const uint32_t lds = D >= 32 ? workers * (uint32_t)work_slot_bytes<(D >= 32 ? D : 32)>() : n_slots * (uint32_t)ring_slot_bytes<T>() + (uint32_t)kRingCtlBytes; \
         static bool attr_set[64] = {};                                                                                                \
         int dev_ = 0;                                                                                                                 \
         if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return false;                                                \
@@ -836,10 +839,10 @@ bool launch_stage1_cu(hipStream_t st, int ratio, int ntaps, uint32_t n_cus, cons
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_stage1_cu<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) return false; \
             attr_set[dev_] = true;                                                                                                    \
         }                                                                                                                             \
-        hipLaunchKernelGGL((k_stage1_cu<T, D>), dim3(n_cus), dim3(64u * (D == 4 ? n_waves : 8u)), lds, st, ra, n_loaders, n_slots);   \
+        hipLaunchKernelGGL((k_stage1_cu<T, D>), dim3(n_cus), dim3(64u * (D == 4 ? n_waves : D >= 32 ? workers : 8u)), lds, st, ra, n_loaders, n_slots);   \
         return true;                                                                                                                  \
     }
-    HD_S1_CASE(32, 212) HD_S1_CASE(32, 174) HD_S1_CASE(8, 54) HD_S1_CASE(4, 139)
+    HD_S1_CASE(32, 212) HD_S1_CASE(32, 174) HD_S1_CASE(64, 348) HD_S1_CASE(8, 54) HD_S1_CASE(4, 139)
 #undef HD_S1_CASE
     return false;
 }

@@ -665,47 +665,89 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
 // fall on that lane's row, and is handed to lane o + 1 (one DPP rotate per component) for the next row.  Every sum still receives its T products in
 // ascending tap order, separately rounded: bit-identical to the lane-owns-the-window loop by construction.  After HR hand-overs lane l >= HR holds
 // output origin + l - HR; the sums that wrapped past lane 63 are the next tile's (ring_adv).
-template <int T>
+// (Row length D: the stage's ratio -- 32 samples at /32, 64 at /64 -- so that output o's window starts in row o.  A row is D / 2 sixteen-byte chunks plus one pad
+// chunk; 64 rows are D / 2 + 1 DMA instructions.)
+template <int D> constexpr int work_row_bytes() { return D * 8 + 16; }
+template <int D> constexpr int work_slot_bytes() { return 64 * work_row_bytes<D>(); }
+template <int T, int D> constexpr int work_halo_rows() { return (T - 1 + D - 1) / D; }
+static_assert(work_slot_bytes<32>() == kWorkSlotBytes && work_row_bytes<32>() == kRingRowBytes, "the /32 worker slot");
+
+// Eleven LDS-DMA instructions back to back with M0 stepped by 1 KiB in between (a /64 tile's 64 rows are three such blocks); NT = how many of them, from the
+// first on, carry the nt policy (the rows the NEXT tile shares stay on the default policy: glds16_x17).
+template <int NT>
+__device__ __forceinline__ void glds16_x11(const void* base, const uint32_t* off, uint32_t lds_dst)
+{
+    unsigned keep, scc_keep;
+#define HD_GN(n) "global_load_lds_dwordx4 %" #n ", %13 nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+#define HD_GD(n) "global_load_lds_dwordx4 %" #n ", %13\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+#define HD_G11_OPS : "=&s"(keep), "=&s"(scc_keep) : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]), "v"(off[8]), "v"(off[9]), "v"(off[10]), "s"(base), "s"(lds_dst) : "memory"
+#define HD_G11_HEAD "s_cselect_b32 %1, 1, 0\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %14\n\ts_nop 0\n\t"
+#define HD_G11_TAIL "s_mov_b32 m0, %0\n\ts_cmp_lg_u32 %1, 0"
+    if constexpr (NT >= 11)
+        asm volatile(HD_G11_HEAD HD_GN(2) HD_GN(3) HD_GN(4) HD_GN(5) HD_GN(6) HD_GN(7) HD_GN(8) HD_GN(9) HD_GN(10) HD_GN(11) HD_GN(12) HD_G11_TAIL HD_G11_OPS);
+    else
+        asm volatile(HD_G11_HEAD HD_GN(2) HD_GN(3) HD_GN(4) HD_GN(5) HD_GN(6) HD_GN(7) HD_GN(8) HD_GD(9) HD_GD(10) HD_GD(11) HD_GD(12) HD_G11_TAIL HD_G11_OPS);
+#undef HD_GN
+#undef HD_GD
+#undef HD_G11_OPS
+#undef HD_G11_HEAD
+#undef HD_G11_TAIL
+}
+
+template <int T, int D = 32>
 __device__ __forceinline__ void ring_worker(const RingArgs& a, unsigned char* __restrict__ slot, const uint32_t role /* diagnostic builds: the wave's row in the stamp table */)
 {
-    constexpr int HR = ring_halo_rows<T>();
-    constexpr uint32_t ADV = (uint32_t)ring_adv<T>();
-    constexpr int JS = HR * 32 - (T - 1);           // slot of tap 0, counted from column 0 of the lane's first row
+    static_assert(D == 32 || D == 64, "a row is one output's stride");
+    constexpr int HR = work_halo_rows<T, D>();
+    constexpr uint32_t ADV = 64u - (uint32_t)HR;    // outputs per tile
+    constexpr int JS = HR * D - (T - 1);            // slot of tap 0, counted from column 0 of the lane's first row
     constexpr int NS = JS + T;                      // taps sit on slots [JS, NS)
-    constexpr int NB0 = ((int)ADV * 17 + 63) / 64;  // DMA instructions for the ADV input rows of a stream's first tile
+    constexpr int CPR = D / 2 + 1;                  // sixteen-byte chunks per padded row = DMA instructions per 64 rows
+    constexpr int ROWB = work_row_bytes<D>();
+    constexpr int NX = D / 2;                       // a lane's row: NX 16-byte reads
+    constexpr int UPS = D / 32;                     // units of 32 slots (two 16-tap chunks) per step
+    constexpr int NU = (HR + 1) * UPS;              // units in all; the sum moves on to the next lane behind every UPS-th
+    constexpr int NB0 = ((int)ADV * CPR + 63) / 64; // DMA instructions for the ADV input rows of a stream's first tile
+    constexpr int HQ = D / 32;                      // dword-wide DMA instructions per history row
+    static_assert(NS == HR * D + 1, "the window ends with slot 0 of row HR");
     const uint32_t lane = threadIdx.x & 63u;
     typedef const float __attribute__((address_space(4)))* ctaps_t;
     const ctaps_t taps = (ctaps_t)(uintptr_t)a.taps - JS;                                   // taps[slot]
     const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr_of(slot));      // (wave-uniform: M0 takes it)
-    const unsigned char* p = slot + lane * (uint32_t)kRingRowBytes;
-    const uint32_t rows = a.n / 32u;
+    const unsigned char* p = slot + lane * (uint32_t)ROWB;
+    const uint32_t rows = a.n / (uint32_t)D;
     RSTAMP_DECL;
     uint32_t n_done = 0; (void)n_done;
 
-    // per-lane source offsets of the seventeen DMA instructions of 64 rows (chunk P = 64 i + lane of the slot = column P % 17 of row P / 17; column 16,
+    // per-lane source offsets of the CPR DMA instructions of 64 rows (chunk P = 64 i + lane of the slot = column P % CPR of row P / CPR; the last column,
     // the pad, loads the row's last chunk again) and of the HR history rows of a stream's first tile (dword-wide: the history sits at odd 8-byte offsets)
-    uint32_t boff[17], hist_off[HR];
+    uint32_t boff[CPR], hist_off[HR * HQ];
 #pragma unroll
-    for (int i = 0; i < 17; ++i) { const uint32_t P = 64u * i + lane, row = P / 17u, col = P - row * 17u; boff[i] = row * 256u + (col < 16u ? col : 15u) * 16u; }
+    for (int i = 0; i < CPR; ++i) { const uint32_t P = 64u * i + lane, row = P / (uint32_t)CPR, col = P - row * (uint32_t)CPR; boff[i] = row * (uint32_t)(D * 8) + (col < (uint32_t)(CPR - 1) ? col : (uint32_t)(CPR - 2)) * 16u; }
 #pragma unroll
-    for (int r = 0; r < HR; ++r) {
-        const int h = (r - HR) * 32 + (int)(lane >> 1) + (T - 1);                          // index into the T-1 history samples (< 0: in front of them, never read)
+    for (int r = 0; r < HR * HQ; ++r) {             // instruction r: dwords [64 (r % HQ), +64) of history row r / HQ
+        const int h = (r / HQ - HR) * D + (r % HQ) * 32 + (int)(lane >> 1) + (T - 1);      // index into the T-1 history samples (< 0: in front of them, never read)
         hist_off[r] = (uint32_t)(h < 0 ? 0 : h) * 8u + (lane & 1u) * 4u;
     }
     auto issue = [&](const uint32_t s, const uint32_t tile) {
         const unsigned char* in_s = reinterpret_cast<const unsigned char*>(a.in + (size_t)s * a.in_stride);
         if (tile == 0) {                            // rows 0 .. HR-1: the stage history; rows HR .. 63: the call's first ADV rows
-            glds4_rows<HR>(reinterpret_cast<const unsigned char*>(a.hist_in + (size_t)s * (T - 1)), hist_off, dst);
+            const unsigned char* hb = reinterpret_cast<const unsigned char*>(a.hist_in + (size_t)s * (T - 1));
+#pragma unroll
+            for (int r = 0; r < HR * HQ; ++r) glds4(hb, hist_off[r], dst + (uint32_t)((r / HQ) * ROWB + (r % HQ) * 256));
 #pragma unroll
             for (int i = 0; i < NB0; ++i)
-                if (64 * (i + 1) <= (int)ADV * 17 || lane < (uint32_t)((int)ADV * 17 - 64 * i)) glds16(in_s, boff[i], dst + (uint32_t)(HR * kRingRowBytes) + 1024u * i);
+                if (64 * (i + 1) <= (int)ADV * CPR || lane < (uint32_t)((int)ADV * CPR - 64 * i)) glds16(in_s, boff[i], dst + (uint32_t)(HR * ROWB) + 1024u * i);
         } else {
             const uint32_t origin = tile * ADV < rows - ADV ? tile * ADV : rows - ADV;
-            glds16_x17(in_s + (size_t)(origin - (uint32_t)HR) * 256u, boff, dst);
+            const unsigned char* src = in_s + (size_t)(origin - (uint32_t)HR) * (uint32_t)(D * 8);
+            if constexpr (D == 32) glds16_x17(src, boff, dst);
+            else { glds16_x11<11>(src, boff, dst); glds16_x11<11>(src, boff + 11, dst + 11u * 1024u); glds16_x11<7>(src, boff + 22, dst + 22u * 1024u); }
         }
     };
 
-    // runs of tiles from this XCD's counter (launch.h: StepClaim; the first ticket past the end resets the counter of the other set for the next launch)
+    // runs of tiles from this XCD's counter (launch.h: StepClaim; the first ticket past the end resets the counter of the other set for the next launch).
+    // A run is run_len consecutive tiles of the slab -- of one stream where run_len divides its tile count, on into the next stream where it does not.
     const uint32_t xcd0 = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // XCC_ID
     const uint32_t xcd = xcd0 < a.claim.n_xcd ? xcd0 : a.claim.n_xcd - 1;
     unsigned int* my_ctr = a.claim.ctr + (size_t)xcd * 32;
@@ -721,11 +763,12 @@ __device__ __forceinline__ void ring_worker(const RingArgs& a, unsigned char* __
         s = g0 / a.ntiles; tile = g0 - s * a.ntiles; left = run_len;
         return true;
     };
+    auto advance = [&]() { ++tile; --left; if (tile == a.ntiles) { tile = 0; ++s; } };
 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (a former tail wave: every LDS access of the tail has completed before DMA lands in its slice)
     if (!take_run(draw())) { RSTAMP_WRITE(role, 0); return; }
     uint32_t cs = s, ct = tile;                     // the tile in (or on its way into) my slot
-    issue(cs, ct); ++tile; --left;
+    issue(cs, ct); advance();
     unsigned int ticket = 0;                        // the draw in flight (lane 0's register) once the run's last tile has been issued
     if (!left) ticket = draw();
 
@@ -745,32 +788,33 @@ __device__ __forceinline__ void ring_worker(const RingArgs& a, unsigned char* __
         asm volatile("" : "+v"(ticket));            // (the compiler's scoreboard learns here, where it costs nothing, that the draw has returned -- or it waits for it
                                                     // where the register is written next: behind the DMA of a run's last tile)
         RSTAMP(0);
-        r_f32x2 kk[2][2][8];                        // [step parity][half row][pair]
-        r_f32x4 x[16];
+        r_f32x2 kk[2][2][8];                        // [unit parity][chunk of the unit][pair]
+        r_f32x4 x[NX];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) x[q] = *reinterpret_cast<const r_f32x4*>(p + 16 * q);
-        ldk(kk[0][0], std::integral_constant<int, 0>{}); ldk(kk[0][1], std::integral_constant<int, 1>{});   // (step 0's taps travel with the row)
+        for (int q = 0; q < NX; ++q) x[q] = *reinterpret_cast<const r_f32x4*>(p + 16 * q);
+        ldk(kk[0][0], std::integral_constant<int, 0>{}); ldk(kk[0][1], std::integral_constant<int, 1>{});   // (unit 0's taps travel with the row)
         __builtin_amdgcn_sched_barrier(0);
         // the rows are in registers: the slot can take the next tile at once -- its DMA flies while this tile is summed
-        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
-                          "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) :: "memory");
+#pragma unroll
+        for (int q = 0; q < NX; q += 8)
+            asm volatile("" : "+v"(x[q]), "+v"(x[q + 1]), "+v"(x[q + 2]), "+v"(x[q + 3]), "+v"(x[q + 4]), "+v"(x[q + 5]), "+v"(x[q + 6]), "+v"(x[q + 7]) :: "memory");
         RSTAMP(3);
         bool more = true;
         if (!left) more = take_run(ticket);         // (drawn behind the DMA of the run's last tile: it arrived with that tile)
         uint32_t ns = 0, nt = 0;
         if (more) {
             ns = s; nt = tile;
-            issue(ns, nt); ++tile; --left;
+            issue(ns, nt); advance();
             if (!left) ticket = draw();
         }
         RSTAMP(4);
 
         const uint32_t origin = ct * ADV < rows - ADV ? ct * ADV : rows - ADV;
         r_f32x2 acc = {0.f, 0.f};
-        // chunk c of the slot sequence = half h = c & 1 of the row of step c >> 1: all sixteen taps (the hand-scheduled form), or the few that exist
+        // chunk c of the slot sequence = chunk c % (D / 16) of the row of step c / (D / 16): all sixteen taps (the hand-scheduled form), or the few that exist
         auto mac_chunk = [&](const r_f32x2 (&k)[8], auto cc) {
             constexpr int c = decltype(cc)::value, j0 = JS > 16 * c ? JS - 16 * c : 0, j1 = NS < 16 * c + 16 ? NS - 16 * c : 16;
-            const r_f32x4 (&xh)[8] = reinterpret_cast<const r_f32x4 (&)[8]>(x[8 * (c & 1)]);
+            const r_f32x4 (&xh)[8] = reinterpret_cast<const r_f32x4 (&)[8]>(x[8 * (c % (D / 16))]);
             if constexpr (j0 == 0 && j1 == 16) ring_mac16_asm(acc, xh, k);
             else {
 #pragma unroll
@@ -786,25 +830,25 @@ __device__ __forceinline__ void ring_worker(const RingArgs& a, unsigned char* __
             acc.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, re), 0x13C, 0xF, 0xF, false));
             acc.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, im), 0x13C, 0xF, 0xF, false));
         };
-        // A step's taps are requested a step ahead through the scalar cache.  Scalar loads return out of order, so waiting for any of them waits for all
-        // that are outstanding: the wait for step r's taps (forced by `arrived`) therefore sits IN FRONT of the request for step r + 1's, which then has
-        // the whole of step r's arithmetic to come back; the scheduling barrier keeps the compiler from sinking the request to its use.
+        // A unit's taps (32 slots) are requested a unit ahead through the scalar cache.  Scalar loads return out of order, so waiting for any of them waits for
+        // all that are outstanding: the wait for unit u's taps (forced by `arrived`) therefore sits IN FRONT of the request for unit u + 1's, which then has
+        // the whole of unit u's arithmetic to come back; the scheduling barrier keeps the compiler from sinking the request to its use.
         auto arrived = [&](const r_f32x2 (&k)[2][8]) {
             asm volatile("" :: "s"(k[0][0]), "s"(k[0][1]), "s"(k[0][2]), "s"(k[0][3]), "s"(k[0][4]), "s"(k[0][5]), "s"(k[0][6]), "s"(k[0][7]),
                                "s"(k[1][0]), "s"(k[1][1]), "s"(k[1][2]), "s"(k[1][3]), "s"(k[1][4]), "s"(k[1][5]), "s"(k[1][6]), "s"(k[1][7]));
         };
-        ring_for_each_index([&](auto ri) {
-            constexpr int r = decltype(ri)::value;      // step r: the row's slots [32 r, 32 r + 32) of the slot sequence
-            arrived(kk[r & 1]);
-            if constexpr (r < HR) {
-                ldk(kk[(r + 1) & 1][0], std::integral_constant<int, 2 * r + 2>{});
-                ldk(kk[(r + 1) & 1][1], std::integral_constant<int, 2 * r + 3>{});
+        ring_for_each_index([&](auto ui) {
+            constexpr int u = decltype(ui)::value;      // unit u: slots [32 u, 32 u + 32) of the slot sequence = part u % UPS of the row of step u / UPS
+            arrived(kk[u & 1]);
+            if constexpr (u + 1 < NU) {
+                ldk(kk[(u + 1) & 1][0], std::integral_constant<int, 2 * u + 2>{});
+                ldk(kk[(u + 1) & 1][1], std::integral_constant<int, 2 * u + 3>{});
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (JS < 32 * r + 16) mac_chunk(kk[r & 1][0], std::integral_constant<int, 2 * r>{});
-            if constexpr (32 * r + 16 < NS && JS < 32 * r + 32) mac_chunk(kk[r & 1][1], std::integral_constant<int, 2 * r + 1>{});
-            if constexpr (r < HR) rot();
-        }, std::make_integer_sequence<int, HR + 1>{});
+            if constexpr (JS < 32 * u + 16 && 32 * u < NS) mac_chunk(kk[u & 1][0], std::integral_constant<int, 2 * u>{});
+            if constexpr (32 * u + 16 < NS && JS < 32 * u + 32) mac_chunk(kk[u & 1][1], std::integral_constant<int, 2 * u + 1>{});
+            if constexpr ((u + 1) % UPS == 0 && u + 1 < NU) rot();
+        }, std::make_integer_sequence<int, NU>{});
 #ifdef HD_STAMP_RING
         asm volatile("" : "+v"(acc));
         ++n_done;

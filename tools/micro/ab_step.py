@@ -29,6 +29,7 @@ def load(label):
     L = C.CDLL(str(path))
     for table in (capi.ENGINE_API, capi.HOST_API):
         for name, (res, args) in table.items():
+            if not hasattr(L, name): continue               # (an older build of the library: the entry points the loop uses are all there)
             f = getattr(L, name); f.restype, f.argtypes = res, args
     return L
 

@@ -1,15 +1,12 @@
 #!/bin/bash
-# Run ON the GPU box: the full GPU suite, the driver's command, the profile passes of the headline shape.
+# Run ON the GPU box: the bench lines that go to profiles/ and the profile passes of the other shapes.
 cd $GRAFT_REPO_ROOT
-o=gpurun_out/r5n; mkdir -p $o
-timeout 700 python -m pytest tests -m gpu -q 2>&1 | tail -12 > $o/pytest.txt
-timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 2>$o/driver.err | tail -1 > $o/driver_bench_line.json
-bash tools/gpu_profile.sh step > $o/profile_step.log 2>&1
-cat $o/pytest.txt
-python3 - <<P
-import json
-d = json.load(open("$o/driver_bench_line.json")); r = d["roofline"]
-print("driver", d["value"], d["ms_per_step"], "cold", d["cold"]["value"], d["cold"]["ms_per_step"], r["kernel"], r["avg_launch_ms"], r["n_samples"], r.get("frac"), "e2e", d["pipeline"]["hbm_frac_end_to_end"], "also", (d.get("also") or {}).get("value"), "per_rank", d["per_rank"])
-print("cpu", {k: d["cpu_baseline"].get(k) for k in ("value", "threads", "gpu_matches_oracle_on_sample", "streams_in_sample", "bits_in_sample", "check_seconds", "mismatches")})
-P
-tail -3 $o/driver.err; tail -5 $o/profile_step.log; cat gpurun_out/prof_step/stats/steady_kernel_stats.csv | head -8
+o=gpurun_out/r5o; mkdir -p $o
+bash tools/final_lines.sh > $o/final_lines.log 2>&1
+cp gpurun_out/lines/* $o/ 2>/dev/null
+timeout 300 python3 tools/single_stream.py > $o/single_stream.jsonl 2>$o/single.err
+bash tools/gpu_profile.sh sync --sync > $o/profile_sync.log 2>&1
+bash tools/gpu_profile.sh cfg2 --workload cfg2 > $o/profile_cfg2.log 2>&1
+bash tools/gpu_profile.sh cfg3 --workload cfg3 > $o/profile_cfg3.log 2>&1
+bash tools/gpu_profile.sh cfg5 --workload cfg5 > $o/profile_cfg5.log 2>&1
+tail -12 $o/final_lines.log
