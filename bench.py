@@ -266,8 +266,8 @@ def physical_cores():
 
 STAGE1 = {64: "k_decimate<32,212,64>", 16: "k_decimate<8,54,256>", 4: "k_decimate<4,139,256>", 256: "k_decimate<64,348,64>"}
 STEP = {64: "k_step<32,212,2,69>", 256: "k_step<64,348,4,139>"}
-STEP_CU = {64: "k_step_cu<212,2,69>", 128: "k_step_cu<174,4,139>"}     # one workgroup per CU: loader + computing waves for stage 1, the tails in the others
-STAGE1_CU = {64: "k_stage1_cu<212,32>", 128: "k_stage1_cu<174,32>", 16: "k_stage1_cu<54,8>", 4: "k_stage1_cu<139,4>"}   # stage 1 alone in that shape (eight tile slots, computing waves beside the loader)
+STEP_CU = {64: "k_step_cu<212,2,69>", 128: "k_step_cu<174,4,139>"}     # one workgroup per CU: a stage-1 worker wave and a stream tail per SIMD
+STAGE1_CU = {64: "k_stage1_cu<212,32>", 128: "k_stage1_cu<174,32>", 256: "k_stage1_cu<348,64>", 16: "k_stage1_cu<54,8>", 4: "k_stage1_cu<139,4>"}   # stage 1 alone, one workgroup per CU (worker waves at /32 and /64, loader + computing waves at /8 and /4)
 PATHS = {0: "separate kernels", 1: "fused back end", 2: "stream tail kernel", 3: "step kernel (stage 1 + previous call's stream tails)"}
 
 

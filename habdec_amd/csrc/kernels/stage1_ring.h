@@ -165,6 +165,7 @@ __device__ __forceinline__ void glds4(const void* base, uint32_t off, uint32_t l
 
 // Seventeen of them back to back -- a tile's 64 rows -- with M0 stepped by 1 KiB in between: one scalar instruction per DMA instruction
 // instead of five (the loader's issue time per tile is what bounds a CU's stream when nothing else does).
+template <bool HEAD_KEPT = false /* the tile's first rows are another tile's last ones and that tile has not come yet (a run's first tile): default policy there too */>
 __device__ __forceinline__ void glds16_x17(const void* base, const uint32_t (&off)[17], uint32_t lds_dst)
 {
     unsigned keep, scc_keep;                      // (s_add_u32 writes SCC, which compiler code around the statement may hold live: saved and restored)
@@ -176,13 +177,22 @@ __device__ __forceinline__ void glds16_x17(const void* base, const uint32_t (&of
 #define HD_GLDS_BODY_POLICY " nt"
 #define HD_G1(n) "global_load_lds_dwordx4 %" #n ", %19" HD_GLDS_BODY_POLICY "\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
 #define HD_G1D(n) "global_load_lds_dwordx4 %" #n ", %19\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-    asm volatile("s_cselect_b32 %1, 1, 0\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %20\n\ts_nop 0\n\t"
-                 HD_G1(2) HD_G1(3) HD_G1(4) HD_G1(5) HD_G1(6) HD_G1(7) HD_G1(8) HD_G1(9) HD_G1(10) HD_G1(11) HD_G1(12) HD_G1(13) HD_G1(14) HD_G1(15) HD_G1(16) HD_G1D(17)
-                 "global_load_lds_dwordx4 %18, %19\n\ts_mov_b32 m0, %0\n\ts_cmp_lg_u32 %1, 0"
-                 : "=&s"(keep), "=&s"(scc_keep)
-                 : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]), "v"(off[8]), "v"(off[9]),
-                   "v"(off[10]), "v"(off[11]), "v"(off[12]), "v"(off[13]), "v"(off[14]), "v"(off[15]), "v"(off[16]), "s"(base), "s"(lds_dst)
-                 : "memory");
+#define HD_G17_OPS : "=&s"(keep), "=&s"(scc_keep)                                                                                                                   \
+                   : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]), "v"(off[8]), "v"(off[9]),              \
+                     "v"(off[10]), "v"(off[11]), "v"(off[12]), "v"(off[13]), "v"(off[14]), "v"(off[15]), "v"(off[16]), "s"(base), "s"(lds_dst)                      \
+                   : "memory"
+    // (Round 5: the worker waves of an XCD walk neighbouring runs at the same time, so the rows a run's FIRST tile shares with the previous run's last tile are
+    // loaded long before that last tile comes -- with nt they were gone by then: 16 MB per step launch fetched twice at runs of four.  Such a tile keeps its
+    // first two instructions -- rows 0 .. 7.5 -- on the default policy as well.)
+    if constexpr (HEAD_KEPT)
+        asm volatile("s_cselect_b32 %1, 1, 0\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %20\n\ts_nop 0\n\t"
+                     HD_G1D(2) HD_G1D(3) HD_G1(4) HD_G1(5) HD_G1(6) HD_G1(7) HD_G1(8) HD_G1(9) HD_G1(10) HD_G1(11) HD_G1(12) HD_G1(13) HD_G1(14) HD_G1(15) HD_G1(16) HD_G1D(17)
+                     "global_load_lds_dwordx4 %18, %19\n\ts_mov_b32 m0, %0\n\ts_cmp_lg_u32 %1, 0" HD_G17_OPS);
+    else
+        asm volatile("s_cselect_b32 %1, 1, 0\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %20\n\ts_nop 0\n\t"
+                     HD_G1(2) HD_G1(3) HD_G1(4) HD_G1(5) HD_G1(6) HD_G1(7) HD_G1(8) HD_G1(9) HD_G1(10) HD_G1(11) HD_G1(12) HD_G1(13) HD_G1(14) HD_G1(15) HD_G1(16) HD_G1D(17)
+                     "global_load_lds_dwordx4 %18, %19\n\ts_mov_b32 m0, %0\n\ts_cmp_lg_u32 %1, 0" HD_G17_OPS);
+#undef HD_G17_OPS
 #undef HD_G1D
 #undef HD_G1
 }
@@ -729,7 +739,7 @@ __device__ __forceinline__ void ring_worker(const RingArgs& a, unsigned char* __
         const int h = (r / HQ - HR) * D + (r % HQ) * 32 + (int)(lane >> 1) + (T - 1);      // index into the T-1 history samples (< 0: in front of them, never read)
         hist_off[r] = (uint32_t)(h < 0 ? 0 : h) * 8u + (lane & 1u) * 4u;
     }
-    auto issue = [&](const uint32_t s, const uint32_t tile) {
+    auto issue = [&](const uint32_t s, const uint32_t tile, const bool run_start) {
         const unsigned char* in_s = reinterpret_cast<const unsigned char*>(a.in + (size_t)s * a.in_stride);
         if (tile == 0) {                            // rows 0 .. HR-1: the stage history; rows HR .. 63: the call's first ADV rows
             const unsigned char* hb = reinterpret_cast<const unsigned char*>(a.hist_in + (size_t)s * (T - 1));
@@ -741,7 +751,7 @@ __device__ __forceinline__ void ring_worker(const RingArgs& a, unsigned char* __
         } else {
             const uint32_t origin = tile * ADV < rows - ADV ? tile * ADV : rows - ADV;
             const unsigned char* src = in_s + (size_t)(origin - (uint32_t)HR) * (uint32_t)(D * 8);
-            if constexpr (D == 32) glds16_x17(src, boff, dst);
+            if constexpr (D == 32) { if (run_start) glds16_x17<true>(src, boff, dst); else glds16_x17<false>(src, boff, dst); }
             else { glds16_x11<11>(src, boff, dst); glds16_x11<11>(src, boff + 11, dst + 11u * 1024u); glds16_x11<7>(src, boff + 22, dst + 22u * 1024u); }
         }
     };
@@ -768,7 +778,7 @@ __device__ __forceinline__ void ring_worker(const RingArgs& a, unsigned char* __
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (a former tail wave: every LDS access of the tail has completed before DMA lands in its slice)
     if (!take_run(draw())) { RSTAMP_WRITE(role, 0); return; }
     uint32_t cs = s, ct = tile;                     // the tile in (or on its way into) my slot
-    issue(cs, ct); advance();
+    issue(cs, ct, true); advance();
     unsigned int ticket = 0;                        // the draw in flight (lane 0's register) once the run's last tile has been issued
     if (!left) ticket = draw();
 
@@ -804,7 +814,7 @@ __device__ __forceinline__ void ring_worker(const RingArgs& a, unsigned char* __
         uint32_t ns = 0, nt = 0;
         if (more) {
             ns = s; nt = tile;
-            issue(ns, nt); advance();
+            issue(ns, nt, left == run_len); advance();
             if (!left) ticket = draw();
         }
         RSTAMP(4);
