@@ -144,6 +144,8 @@ struct hd_engine {
     uint64_t step_launches = 0;
     DevBuf<unsigned int> step_ctr;         // two sets of per-XCD run counters ([2][16][32] u32), alternating per step launch
     uint32_t pend_max_taps = 0;
+    bool dec_wgs_forced = false;   // HD_DEC_WGS_PER_CU was given (tests of the linear split)
+    int cu_exp = 0;                // HD_CU_EXP: timing experiments only, results wrong -- 1: step launches without their tails, 2: without stage 1 (tools/micro/joules.py)
     uint32_t n_cus = 0, dec_wgs_per_cu = 0;   // stage-1 linear split: workgroups per CU (0 = classic grid), see kernels/decimate.hip        // path of the previous call (the two paths use the stage-2 buffers on different queues)
     hipStream_t qa = nullptr, qb = nullptr, qc = nullptr;   // front (decimation, spectrum) and back (FIR, symbols, results) HIP streams
     // hd_process_host: copies run on their own stream into two alternating slabs; a call returns once ITS copy has landed, so the
@@ -318,7 +320,8 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         // 135, 141, 135, 132 us).  Batch mode when the step kernel does not apply: six, so that the previous call's back half, on the
         // second queue, finds room underneath.
         e->dec_wgs_per_cu = cfg->pipeline ? 6u : 8u;
-        if (const char* v = getenv("HD_DEC_WGS_PER_CU")) e->dec_wgs_per_cu = (uint32_t)atoi(v);
+        if (const char* v = getenv("HD_DEC_WGS_PER_CU")) { e->dec_wgs_per_cu = (uint32_t)atoi(v); e->dec_wgs_forced = true; }
+        if (const char* v = getenv("HD_CU_EXP")) e->cu_exp = atoi(v);
     }
     for (hipEvent_t* ev : {&e->ev_copy[0], &e->ev_copy[1], &e->ev_staging_free[0], &e->ev_staging_free[1]}) HD_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     if (e->one_stream) e->qb = e->qc = e->qa;
@@ -669,7 +672,7 @@ int collect(hd_engine* e, hd_engine::CallSlot& sl)
     int rc = HD_OK;
     {   // every stream's slot must carry this call's tag (the kernels store it last); in practice it is there when the event has fired -- if not, wait for it
         const auto t_lim = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
-        static const bool timing_experiment = getenv("HD_CU_EXP") != nullptr;      // (step launches without their tails or without stage 1: nothing writes the slots)
+        const bool timing_experiment = e->cu_exp != 0;      // (HD_CU_EXP: step launches without their tails or without stage 1 -- nothing writes the slots)
         for (uint32_t s = 0; s < e->S && !e->device_failed && !timing_experiment; ++s) {
             const volatile uint32_t* tag = &reinterpret_cast<const volatile hd::BitsHeader*>(sl.h_slots.p + (size_t)s * e->slot_words)->seq;
             while (*tag != sl.seq) {
@@ -1002,7 +1005,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         uint32_t wgs = 32u * e->n_cus;                          // short runs of tiles: the dispatcher evens out the tail of the launch
         // One workgroup per CU (four stage-1 worker waves, the tails in the other four) where the plan and the sizes allow it
         const uint32_t ring_run = pick_ring_run(hd::ring_tiles((int)R1, (int)T1, max_in));
-        static const int cu_exp0 = getenv("HD_CU_EXP") ? atoi(getenv("HD_CU_EXP")) : 0;   // timing experiments only (results wrong): 1 = no tails, 2 = no stage 1
+        const int cu_exp0 = e->cu_exp;             // timing experiments only (results wrong): 1 = no tails, 2 = no stage 1
         const bool want_cu = cu_tail && ((cu_exp0 & 1) || (ta_step.lds_bytes <= cu_tail && (!prev.valid || prev.ta.lds_bytes <= cu_tail)));
         const hd::StepClaim claim = make_claim(0, want_cu ? ring_run : 0u);
         if (claim.ctr) wgs = 8u * e->n_cus;
@@ -1069,8 +1072,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         const size_t out1_stride = single ? e->fbuf_stride : e->n1_cap;
         // (a /64 workgroup holds 36.7 KB of LDS and ~400 VGPRs: four fit a CU, and six per CU would be a launch of one round and a half --
         // measured at 10 MS/s, /256: 1.73 against 1.84 ms per step)
-        static const bool wgs_env = getenv("HD_DEC_WGS_PER_CU") != nullptr;
-        const uint32_t wgs_cu = (R1 == 64 && !wgs_env && e->dec_wgs_per_cu > 4u) ? 4u : e->dec_wgs_per_cu;
+        const uint32_t wgs_cu = (R1 == 64 && !e->dec_wgs_forced && e->dec_wgs_per_cu > 4u) ? 4u : e->dec_wgs_per_cu;
         const uint32_t lin1 = (min_in == max_in && max_in) ? wgs_cu * e->n_cus : 0u;
         // A /32 first stage over equally sized pushes: one workgroup per CU, LDS-DMA loader waves + computing waves (k_stage1_cu, stage1_ring.h)
         bool s1_cu = false;
