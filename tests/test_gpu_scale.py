@@ -223,11 +223,13 @@ def test_first_stages_of_the_small_ratios_at_1024_streams(monkeypatch, factor, f
     eng.close()
 
 
-@pytest.mark.parametrize("factor,fs,S,CH,lowpass", [(16, 2.5e6, 8, 16384, 3000.0), (16, 2.5e6, 24, 4096, 3000.0), (64, 2.048e6, 8, 16384, None), (64, 2.048e6, 40, 4096, None), (64, 2.048e6, 3, 4096, None)])
+@pytest.mark.parametrize("factor,fs,S,CH,lowpass", [(16, 2.5e6, 8, 16384, 3000.0), (16, 2.5e6, 24, 4096, 3000.0), (64, 2.048e6, 8, 16384, None), (64, 2.048e6, 40, 4096, None), (64, 2.048e6, 3, 4096, None),
+                                                     (256, 10e6, 8, 16384, None), (256, 10e6, 16, 24576, None), (128, 4.096e6, 16, 8192, None)])
 def test_per_cu_first_stage_with_few_tiles(factor, fs, S, CH, lowpass):
-    """k_stage1_cu with far fewer tiles than the chip has waves: a handful of streams and short pushes (8, 2 or 1 tile of 2048 samples per stream
-    and call, runs of 8, 2 or -- where even that does not divide among the XCDs -- the fall-back to the classic grid), most CUs finding no run at
-    all.  Synchronous calls, EVERY stream compared with the oracle after every call."""
+    """k_stage1_cu with far fewer tiles than the chip has waves: a handful of streams and short pushes -- nine, five, three tiles per stream and call for the
+    worker waves of the /32 and /64 stages (57- and 58-output tiles; a run may run on into the next stream), eight or two for the loader / consumer
+    kernel of /8 -- most CUs finding no run at all, and the fall-back to the classic grid where no run length divides among the XCDs.  Synchronous
+    calls, EVERY stream compared with the oracle after every call."""
     torch = pytest.importorskip("torch")
     import habdec_amd
     from oracle import pyoracle
@@ -253,11 +255,18 @@ def test_per_cu_first_stage_with_few_tiles(factor, fs, S, CH, lowpass):
             assert same_bits(eng.demodulated(s), o.array("last_demod")), (k, s)
             assert np.array_equal(eng.bits(s), o.bits()), (k, s)
     # the first call of a stream restarts its history (classic grid); after that the per-CU kernel serves every call whose tiles can be cut into
-    # runs of 8, 4 or 2 that divide evenly among the 8 XCDs (engine.cpp: make_claim) -- otherwise the classic grid stays
-    ntiles, run = CH // 2048, 8
-    while run > 2 and (ntiles % run or (S * ntiles // run) % 8):
-        run //= 2
-    per_cu = ntiles % run == 0 and (S * ntiles // run) % 8 == 0
+    # runs that divide evenly among the 8 XCDs (engine.cpp: pick_ring_run, make_claim) -- otherwise the classic grid stays
+    r1, t1 = {16: (8, 54), 64: (32, 212), 128: (32, 174), 256: (64, 348)}[factor]
+    worker = r1 >= 32
+    if worker:
+        adv = 64 - (t1 - 1 + r1 - 1) // r1
+        ntiles = -(-(CH // r1) // adv)
+    else:
+        ntiles = CH // 2048
+    total = S * ntiles
+    ok = lambda r: 2 <= r <= ntiles and (total % r == 0 if worker else ntiles % r == 0) and (total // r) % 8 == 0
+    want = 4 if worker else 8
+    per_cu = any(ok(want + d) or (0 < d < want and ok(want - d)) for d in range(9))
     assert variants[0] == 0 and all(v == (1 if per_cu else 0) for v in variants[1:]), (variants, per_cu)
     eng.close()
 

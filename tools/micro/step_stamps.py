@@ -2,7 +2,6 @@
 early in the launch (beside the stream tails) and late (alone)."""
 import sys, ctypes, os, numpy as np
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
-os.environ.setdefault("HD_STEP_WGS", "4096")
 import torch, bench, habdec_amd
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
 import _variant

@@ -6,7 +6,7 @@
 //   MODE 1: taps from an LDS table with broadcast ds_read_b128 (in-order returns: counted waits), same chunking
 //   MODE 2: MODE 1 on two tiles at once (two independent sums per lane, 2 x 18 KB of LDS)
 //   MODE 3: MODE 0 with the sixteen-tap chunk scheduled by hand (ring_mac16_asm of stage1_ring.h): products three taps ahead of the adds
-//   MODE 4: the SYSTOLIC loop (round 4's candidate for round 5): a lane reads only ITS row (16 x 16 bytes instead of 106), the accumulators travel -- output o
+//   MODE 4: the SYSTOLIC loop (built into stage1_ring.h's ring_worker in round 5): a lane reads only ITS row (16 x 16 bytes instead of 106), the accumulators travel -- output o
 //           starts in lane o and after the taps that fall on row o + r moves to the next lane with one DPP rotate per component; same products in the same
 //           order.  (Timing only here: the wrap at lane 63 is not handled -- a real version computes 57 outputs per 64 rows.)
 #include <hip/hip_runtime.h>
@@ -142,8 +142,11 @@ __global__ __launch_bounds__(64) void k(unsigned long long* out, float2* res, co
                 for (int j = 0; j < 8; ++j) { kk[j].x = taps[c * 16 + 2 * j]; kk[j].y = taps[c * 16 + 2 * j + 1]; }
             };
             auto rot = [&]() {                                      // lane l takes lane l-1's accumulator (wave_ror:1)
-                acc.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc.x), 0x13C, 0xF, 0xF, false));
-                acc.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc.y), 0x13C, 0xF, 0xF, false));
+                // (through scalars: __builtin_bit_cast of an ext-vector ELEMENT reads the vector's first element whichever was named -- round 4's version
+                // of this loop rotated the real part twice; the timing is the same)
+                const float re = acc.x, im = acc.y;
+                acc.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, re), 0x13C, 0xF, 0xF, false));
+                acc.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, im), 0x13C, 0xF, 0xF, false));
             };
             ld(ka, 0); ld(kb, 1);
             acc = acc + xa[6].zw * ka[6].y; acc = acc + xa[7].xy * ka[7].x; acc = acc + xa[7].zw * ka[7].y;      // step 0: slots 13..15 of chunk 0
