@@ -14,6 +14,14 @@ __global__ __launch_bounds__(NT) void k_tail(const TailArgs a)
     tail_body<NT, OP, D2, T2>(a, blockIdx.x, tail_lds);
 }
 
+#ifdef HD_RING_FAULT   // the tails of THIS translation unit (k_tail: synchronous delivery, the drain at hd_flush)
+extern "C" void hd_debug_tail_fault_arm_no_tag()
+{
+    const unsigned int one = 1, zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tail_fault_armed), &one, sizeof one);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tail_fault_fired), &zero, sizeof zero);
+}
+#endif
 #ifdef HD_STAMP_TAIL
 extern "C" void hd_debug_tail_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tail_stamps), n * 8); }
 #endif

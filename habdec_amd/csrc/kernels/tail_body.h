@@ -46,6 +46,9 @@ __device__ __forceinline__ cfloat_ptr as_const(const float* p) { return (cfloat_
         a0 = a0 + p0_; a1 = a1 + p1_; a2 = a2 + p2_; a3 = a3 + p3_;                           \
     }
 
+#ifdef HD_RING_FAULT   // fault-injection build (libhabdec_amd_fault.so): ONE stream tail of the process leaves its result slot without the call's tag
+__device__ unsigned int g_tail_fault_armed, g_tail_fault_fired;
+#endif
 #ifdef HD_STAMP_TAIL   // diagnostic build only (tools/micro/tail_stamps.py): cycles per phase of the tail, per stream
 __device__ unsigned long long g_tail_stamps[8192 * 24];
 #define TSTAMP_DECL unsigned long long ts_t = __builtin_amdgcn_s_memtime(), ts_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long ts_r0 = __builtin_amdgcn_s_memrealtime()
@@ -943,6 +946,9 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     }
     // the call's tag, LAST: every store this wave has issued -- header, bits, spectrum statistics, all by wave 0 -- has been acknowledged before it goes out
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef HD_RING_FAULT
+    if (tid == 0 && g_tail_fault_armed && atomicCAS(&g_tail_fault_fired, 0u, 1u) == 0u) return;     // (the host's wait for the tag runs out: tests/test_gpu_fault.py)
+#endif
     if (tid == 0) __hip_atomic_store(&hdr->seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     TSTAMP_WRITE();
 }

@@ -71,5 +71,6 @@ def test_fault_injection_library_loads_and_binds():
             getattr(L, name)
     getattr(L, "hd_debug_ring_fault_arm")
     getattr(L, "hd_debug_ring_fault_arm_starve")
+    getattr(L, "hd_debug_tail_fault_arm_no_tag")
     prod = ctypes.CDLL(str(capi.LIB_PATH))
     assert not hasattr(prod, "hd_debug_ring_fault_arm")      # the hook is compiled out of the product

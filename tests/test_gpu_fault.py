@@ -96,3 +96,28 @@ def test_starved_loaders_report_instead_of_waiting_forever(pipeline):
     L.hd_engine_destroy(h)
     del iq
     torch.cuda.empty_cache()
+
+
+def test_a_result_slot_without_its_tag_fails_the_engine_instead_of_delivering_stale_results():
+    """Round 5: the engine's completion events carry no system-scope fence, so the host takes a result slot as delivered when it reads the call's tag in
+    the slot's header (BitsHeader::seq, stored last by the wave that wrote the slot) -- not because the event fired.  The fault build makes ONE stream tail
+    return without storing its tag: collect() must wait for it, give up after 200 ms, fail the call with HD_ERR_DEVICE, deliver nothing and stay failed."""
+    torch = pytest.importorskip("torch")
+    from habdec_amd import capi
+    L = load_fault_lib()
+    if not hasattr(L, "hd_debug_tail_fault_arm_no_tag"):
+        pytest.skip("fault-injection library without the missing-tag mode (rebuild it)")
+    S, CH, fs = 64, 16384, 2.048e6
+    cfg = capi.hd_engine_config()
+    L.hd_engine_config_default(C.byref(cfg))
+    cfg.n_streams, cfg.max_chunk, cfg.sampling_rate, cfg.decimation, cfg.pipeline = S, CH, fs, 64, 0
+    h = C.c_void_p()
+    assert L.hd_engine_create(C.byref(cfg), C.byref(h)) == 0, L.hd_last_error()
+    iq = torch.randn((S, CH, 2), device="cuda", dtype=torch.float32) * 0.1
+    assert L.hd_process_device(h, iq.data_ptr(), CH, None, CH) == 0          # a healthy call first
+    L.hd_debug_tail_fault_arm_no_tag()
+    codes = [L.hd_process_device(h, iq.data_ptr(), CH, None, CH) for _ in range(3)]
+    assert codes[0] == HD_ERR_DEVICE and all(c == HD_ERR_DEVICE for c in codes), codes
+    assert b"tag" in L.hd_last_error() or b"failed state" in L.hd_last_error(), L.hd_last_error()
+    assert L.hd_flush(h) == HD_ERR_DEVICE
+    L.hd_engine_destroy(h)
