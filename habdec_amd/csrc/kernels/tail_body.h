@@ -663,22 +663,29 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     const uint32_t lmw = (nw + 1u) & ~1u;
     const uint32_t dyn_floats = hunt ? (((a.lds_bytes - a.dyn_off) - lmw * 8u) >> 2) & ~3u : 0u;
     const uint32_t vc_want = (hunt && limit > carried_to) ? limit - carried_to : 0u;
-    const uint32_t vc_cap = min((vc_want + 3u) & ~3u, (dyn_floats * 5u / 8u) & ~3u);
+    // Both caches are images of RING-ALIGNED quads (round 5): their first element is the ring position rounded down to a multiple of four, so that every
+    // load is an aligned 16-byte one that cannot straddle the ring's end -- a dozen load instructions where there were thirty-odd 4-byte ones (inside a step
+    // launch every global-memory instruction of this wave queues behind the stage-1 workers' tile loads).  woff / voff: where backlog position 0 /
+    // sample carried_to sits in its image.
+    const uint32_t woff = st.base & 3u, voff = (st.base + carried_to) & 3u;
+    const uint32_t vc_cap = min((vc_want + voff + 7u) & ~3u, (dyn_floats * 5u / 8u) & ~3u);
     const uint32_t wc_cap = dyn_floats - vc_cap;
-    const uint32_t wc_n = hunt ? min(limit, wc_cap) : 0u;              // window sums [0, wc_n) of the backlog
+    const uint32_t wc_n = hunt ? min(limit, wc_cap > woff + 4u ? wc_cap - woff - 4u : 0u) : 0u;   // window sums [0, wc_n) of the backlog
     // the run sums add up the backlog samples [carried_to, frontier) (frontier <= limit), in pieces
-    const uint32_t vc_n = min(vc_want, vc_cap);                        // samples [carried_to, carried_to + vc_n)
-    constexpr int MB = 512 / NT, CB = 1024 / NT, SB = 1024 / NT;
+    const uint32_t vc_n = min(vc_want, vc_cap > voff + 4u ? vc_cap - voff - 4u : 0u);             // samples [carried_to, carried_to + vc_n)
+    const uint32_t wq_n = wc_n ? (wc_n + woff + 3u) >> 2 : 0u, vq_n = vc_n ? (vc_n + voff + 3u) >> 2 : 0u;   // quads of each image
+    const uint32_t wpos4 = st.base & ~3u, vpos4 = (st.base + carried_to) & ~3u;                     // ring positions of the images' first elements
+    constexpr int MB = 512 / NT, CB = 1024 / NT / 4 > 0 ? 1024 / NT / 4 : 1, SB = CB;      // first batches: 512 mask words, 1024 window sums, 1024 samples
     unsigned long long tm0[MB];
-    float tc0[CB], ts0[SB];
+    float4 tc0[CB], ts0[SB];
     if (hunt) {
         __threadfence_block();                                          // this call's own ring stores first
 #pragma unroll
         for (int u = 0; u < MB; ++u) { const uint32_t i = tid + u * NT; tm0[u] = i < nw ? gmask[((wr0 + 64u * i) & rmask) >> 6] : 0ull; }
 #pragma unroll
-        for (int u = 0; u < CB; ++u) { const uint32_t k = tid + u * NT; tc0[u] = k < wc_n ? gw[(st.base + k) & rmask] : 0.f; }
+        for (int u = 0; u < CB; ++u) { const uint32_t qd = tid + u * NT; tc0[u] = qd < wq_n ? *reinterpret_cast<const float4*>(gw + ((wpos4 + 4u * qd) & rmask)) : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
-        for (int u = 0; u < SB; ++u) { const uint32_t k = tid + u * NT; ts0[u] = k < vc_n ? vring[(st.base + carried_to + k) & rmask] : 0.f; }
+        for (int u = 0; u < SB; ++u) { const uint32_t qd = tid + u * NT; ts0[u] = qd < vq_n ? *reinterpret_cast<const float4*>(vring + ((vpos4 + 4u * qd) & rmask)) : make_float4(0.f, 0.f, 0.f, 0.f); }
     }
 
     // ---- what the next call finds: stage-2 history of an idle stream, [history | leftover pending] at the front of the other
@@ -727,35 +734,37 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     uint32_t* flips = reinterpret_cast<uint32_t*>(lds + a.flips_off);
     uint32_t* runinfo = flips + a.fl_cap;
     float* strips = reinterpret_cast<float*>(lds + a.strips_off);
-    float* vc = reinterpret_cast<float*>(lds + a.dyn_off + lmw * 8u);  // vc[k] = backlog sample carried_to + k
-    float* wc = vc + vc_cap;                                            // wc[k] = window sum of backlog position k
+    float* vc4 = reinterpret_cast<float*>(lds + a.dyn_off + lmw * 8u); // the sample image (ring-aligned quads) ...
+    float* wc4 = vc4 + vc_cap;                                          // ... and the window-sum image
+    const float* vc = vc4 + voff;                                       // vc[k] = backlog sample carried_to + k
+    const float* wc = wc4 + woff;                                       // wc[k] = window sum of backlog position k
     const uint32_t fl_cap = a.fl_cap;
     tb_sync<NT>();                                                      // the slide above read the stream windows these images overwrite
     {
 #pragma unroll
         for (int u = 0; u < MB; ++u) { const uint32_t i = tid + u * NT; if (i < nw) lmask[i] = tm0[u]; }
 #pragma unroll
-        for (int u = 0; u < CB; ++u) { const uint32_t k = tid + u * NT; if (k < wc_n) wc[k] = tc0[u]; }
+        for (int u = 0; u < CB; ++u) { const uint32_t qd = tid + u * NT; if (qd < wq_n) reinterpret_cast<float4*>(wc4)[qd] = tc0[u]; }
 #pragma unroll
-        for (int u = 0; u < SB; ++u) { const uint32_t k = tid + u * NT; if (k < vc_n) vc[k] = ts0[u]; }
+        for (int u = 0; u < SB; ++u) { const uint32_t qd = tid + u * NT; if (qd < vq_n) reinterpret_cast<float4*>(vc4)[qd] = ts0[u]; }
         // longer backlogs than the first batches cover (idle or freshly re-parameterised streams): plain loops
         for (uint32_t i = tid + MB * NT; i < nw; i += NT) lmask[i] = gmask[((wr0 + 64u * i) & rmask) >> 6];
-        constexpr int RB = 8;                                           // (eight loads per lane in flight per trip: a loop of single loads is a round trip per element)
+        constexpr int RB = 4;                                           // (four 16-byte loads per lane in flight per trip: a loop of single loads is a round trip per element)
 #pragma unroll 1
-        for (uint32_t k0 = tid + CB * NT; k0 < wc_n; k0 += RB * NT) {
-            float t[RB];
+        for (uint32_t q0 = tid + CB * NT; q0 < wq_n; q0 += RB * NT) {
+            float4 t[RB];
 #pragma unroll
-            for (int u = 0; u < RB; ++u) { const uint32_t k = k0 + u * NT; t[u] = k < wc_n ? gw[(st.base + k) & rmask] : 0.f; }
+            for (int u = 0; u < RB; ++u) { const uint32_t qd = q0 + u * NT; t[u] = qd < wq_n ? *reinterpret_cast<const float4*>(gw + ((wpos4 + 4u * qd) & rmask)) : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
-            for (int u = 0; u < RB; ++u) { const uint32_t k = k0 + u * NT; if (k < wc_n) wc[k] = t[u]; }
+            for (int u = 0; u < RB; ++u) { const uint32_t qd = q0 + u * NT; if (qd < wq_n) reinterpret_cast<float4*>(wc4)[qd] = t[u]; }
         }
 #pragma unroll 1
-        for (uint32_t k0 = tid + SB * NT; k0 < vc_n; k0 += RB * NT) {
-            float t[RB];
+        for (uint32_t q0 = tid + SB * NT; q0 < vq_n; q0 += RB * NT) {
+            float4 t[RB];
 #pragma unroll
-            for (int u = 0; u < RB; ++u) { const uint32_t k = k0 + u * NT; t[u] = k < vc_n ? vring[(st.base + carried_to + k) & rmask] : 0.f; }
+            for (int u = 0; u < RB; ++u) { const uint32_t qd = q0 + u * NT; t[u] = qd < vq_n ? *reinterpret_cast<const float4*>(vring + ((vpos4 + 4u * qd) & rmask)) : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
-            for (int u = 0; u < RB; ++u) { const uint32_t k = k0 + u * NT; if (k < vc_n) vc[k] = t[u]; }
+            for (int u = 0; u < RB; ++u) { const uint32_t qd = q0 + u * NT; if (qd < vq_n) reinterpret_cast<float4*>(vc4)[qd] = t[u]; }
         }
     }
     tb_sync<NT>();
@@ -816,7 +825,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         if (a0 >= carried_to && b - carried_to <= vc_n) {               // the samples are in LDS already (wave-uniform addresses: broadcast reads)
             const float* v0 = vc + (a0 - carried_to);
             uint32_t n = b - a0, i = 0;
-            for (; i < n && ((a0 - carried_to + i) & 3u); ++i) acc = acc + v0[i];
+            for (; i < n && ((a0 - carried_to + voff + i) & 3u); ++i) acc = acc + v0[i];
             const float4* v4 = reinterpret_cast<const float4*>(v0 + i);
             const uint32_t nq = (n - i) >> 2;
             uint32_t q = 0;
