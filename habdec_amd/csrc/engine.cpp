@@ -161,7 +161,7 @@ struct hd_engine {
     rocfft_execution_info fft_info = nullptr;
     DevBuf<char> fft_work;
 
-    DevBuf<float2> staging, dec1, dec1b, dec1c, hist1[2], hist2[2], fbuf[2], fft_in, fft_raw, spec, filtered;   // dec1/b/c: stage-1 output, rotating per call
+    DevBuf<float2> staging, dec1, dec1b, dec1c, hist1[2], hist2[2], fbuf[3], fft_in, fft_raw, spec, filtered;   // dec1/b/c: stage-1 output, rotating per call
     DevBuf<float> stage_taps[2], lp_taps, power, demod, tail, weight;
     DevBuf<unsigned long long> flipmask;
     DevBuf<uint32_t> flips_dbg;
@@ -190,7 +190,7 @@ struct hd_engine {
     } slot[kSlots];
     uint64_t calls = 0;
     uint64_t delivered = 0;   // calls whose results have been delivered; calls - delivered <= 2 (pipelined mode)
-    int cur = 0;          // which fbuf receives this call's chunk
+    int cur = 0;          // which fbuf receives this call's chunk (three take turns: the one a call writes was last read by the back half of call k-3, which the host has collected)
     int hist_cur = 0;     // which stage-history buffers are read this call (the others are written)
     int carry_cur = 0;
     bool sym_dirty = true;
@@ -893,14 +893,19 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     // half rides in front of the back end on qb.  The unfused path keeps the fetch queue and the ordering behind call k-2 (its
     // front half writes the low-pass buffer the back half of call k-2 may still be reading).
     const bool lean = fuse && !e->one_stream;
-    if (!lean && e->calls >= 2 && !e->one_stream) HD_HIP(hipStreamWaitEvent(qa, e->slot[(e->calls - 2) % hd_engine::kSlots].ev_done, 0));
+    // Round 5: the unfused TWO-stage plans (calls too large for an LDS image or a one-wave tail: /16 and /256 at 4096 decimated samples per call) do not wait
+    // either.  What the wait protected was the low-pass buffer -- with three of them taking turns, the one this call's second stage writes was last read by
+    // the back half of call k-3, which the host has collected before it submits call k -- and the parameter copy rides on qa behind stage 1, which reads the
+    // mapped host block.  (Kernel trace before: 15-22 us of barrier packets in front of every stage 1, on the queue a step waits for.)
+    const bool free_front = !fuse && nst == 2 && !e->one_stream;
+    if (!lean && !free_front && e->calls >= 2 && !e->one_stream) HD_HIP(hipStreamWaitEvent(qa, e->slot[(e->calls - 2) % hd_engine::kSlots].ev_done, 0));
     sl.timed = e->timing_every && (e->calls % e->timing_every) == 0;
     sl.timed_step = sl.timed && step;                       // a step call is ONE launch: two event records (each a barrier packet), not four
     if (sl.timed && !step) HD_HIP(hipEventRecord(sl.t0, qa));
     // One queue and the stream tails behind stage 1 (synchronous delivery): both kernels read the call's parameters from the mapped host block -- one
     // round trip over PCIe at the start of a workgroup instead of a copy kernel in front of stage 1.  (Not where a spectrum launch reads the device copy.)
     const bool host_params = tail && !step && e->one_stream && (!e->cfg.enable_spectrum || (e->tail_fft && !any_dc));
-    if (lean) {
+    if (lean || free_front) {
         if (e->sym_dirty && e->calls > e->delivered) { if (int rc = flush_locked(e)) return rc; }   // symbol parameters are uploaded below: nothing may still read them
     } else if (!host_params) {
         // the parameter block is pulled on its own queue, so it does not wait for the previous call's stage 1 to drain
@@ -930,7 +935,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     // ---- front half on qa: decimation, DC blocker, spectrum
     const float2* iq = static_cast<const float2*>(d_iq);
     float2* fcur = e->fbuf[e->cur].p;
-    float2* fnext = e->fbuf[e->cur ^ 1].p;
+    float2* fnext = e->fbuf[(e->cur + 1) % 3].p;
     const hd::StreamCall* dcall = host_params ? sl.h_call.dev : sl.d_call.p;
     float2* d1 = (e->calls % 3 == 0) ? e->dec1.p : (e->calls % 3 == 1) ? e->dec1b.p : e->dec1c.p;   // never a buffer a call in flight still reads
     const int hin = e->hist_cur, hout = e->hist_cur ^ 1;
@@ -1045,7 +1050,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         e->pend.r2 = (int)R2; e->pend.t2 = (int)T2; e->pend_max_taps = max_taps;
         HD_HIP(hipGetLastError());
         sl.busy = true;
-        e->cur ^= 1;
+        e->cur = (e->cur + 1) % 3;
         e->carry_cur ^= 1;
         e->hist_cur ^= 1;
         ++e->calls;
@@ -1091,10 +1096,11 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         if (sl.timed && !s1_cu) HD_HIP(hipEventRecord(sl.t1, qa));
         if (!s1_cu)
         if (!hd::launch_decimate(qa, R1, T1, S, max_n1, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
-                                 lean ? sl.h_call.dev : dcall, 0, single ? 1 : 0, e->fir_hist_cap, single ? feed : nullptr, lin1,
+                                 (lean || free_front) ? sl.h_call.dev : dcall, 0, single ? 1 : 0, e->fir_hist_cap, single ? feed : nullptr, lin1,
                                  nullptr, claim1.ctr ? max_in : 0u, claim1))
             return fail(HD_ERR_INVALID, "no kernel for this decimation stage");
         if (sl.timed) HD_HIP(hipEventRecord(sl.t2, qa));
+        if (free_front) hd::launch_fetch_params(qa, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
         if (!single && !fuse) {
             // (Round 4 measured the second stage as a ring kernel too -- /2 with sixteen outputs per lane, /4 with eight: bit-identical, and SLOWER in the
             // pipelined step (/16: 0.338-0.342 against 0.326-0.338 ms): a ring kernel takes a CU's whole LDS, and the back half of the previous call
@@ -1152,7 +1158,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     if (!done_on_dispatch) HD_HIP(hipEventRecord(sl.ev_done, qb));
     HD_HIP(hipGetLastError());
     sl.busy = true;
-    e->cur ^= 1;
+    e->cur = (e->cur + 1) % 3;
     e->carry_cur ^= 1;
     if (max_in && nst) e->hist_cur ^= 1;
     ++e->calls;

@@ -2,11 +2,13 @@ import sys, ctypes, numpy as np, json, subprocess
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import torch, bench, habdec_amd
 import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _variant
 w = dict(bench.WORKLOADS[os.environ.get("WL", "cfg4")]); S = w["S"]; C = w["C"]
 dev = torch.device("cuda", 0)
 ring, rc, _ = bench.generate_ring(torch, dev, w, S, 0, 1234)
 eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"],
-                        lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"])
+                        lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"], pipeline=int(os.environ.get("PIPE", "0")))
 L = habdec_amd.lib(); f = L.hd_debug_sym_stamps; f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 tot_p = []; ph_mean = np.zeros(5); ph_max = np.zeros(5); n = 0; span = []
 NC = int(os.environ.get('NCALLS', '70'))
