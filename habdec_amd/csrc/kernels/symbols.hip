@@ -73,11 +73,11 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     const uint32_t cap_bits = (slot_words - sizeof(BitsHeader) / 4) * 32;
     const uint32_t m = call[s].fir_m;
     const SymState old = sym[s];
+    const SymbolParams q = sp[s];                           // (requested with the two above: one round trip, not two)
     if (!m) {                                               // symbol stage not reached this call
         if (tid == 0) { hdr->nbits = 0; hdr->held_after = old.held; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = old.base + old.held - old.cached; hdr->demod_n = 0xFFFFFFFFu; HD_SLOT_DONE(); }
         return;
     }
-    const SymbolParams q = sp[s];
     SymState st = state_after_push(old, q, m);
     const uint32_t h = st.held;
     // Too little backlog for the extractor to run (SymbolExtractor.h:134): the reference returns; here the window sums of the
@@ -144,25 +144,32 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     bool staged = true;
     uint32_t sweeps = 0, wl_c0 = st.cached;                 // wl holds W of [wl_c0 - R, wl_c0 + kAvgSpan) after the last sweep
     SWEEP_DECL;
+    float nxw[WB];                                          // the NEXT sweep's samples, requested before this sweep's window sums: their round trip runs under the adds
     for (uint32_t c0 = st.cached; (int32_t)(pend - c0) > 0; c0 += kAvgSpan) {
         SWEEP(2);
         const uint32_t wb0 = c0 & ~63u, wsh = c0 & 63u;    // sweeps start wherever the previous call stopped: words are shared
         if (!staged) {
+            // the R sums in front of this sweep are the previous sweep's last R: they are in LDS (wl[span .. span + R)), as is the mask word it ended in
+            float tl[LB];
+#pragma unroll
+            for (int u = 0; u < LB; ++u) { const uint32_t k = tid + u * kSymLanes; tl[u] = k < R ? wl[kAvgSpan + k] : 0.0f; }
             __syncthreads();                                // previous sweep's LDS consumers are done
-            for (uint32_t k0 = tid; k0 < wn; k0 += WB * kSymLanes) {
-                float tw[WB];
 #pragma unroll
-                for (int u = 0; u < WB; ++u) { const uint32_t k = k0 + u * kSymLanes; tw[u] = k < wn ? v[(c0 + k) & rmask] : 0.0f; }
+            for (int u = 0; u < WB; ++u) { const uint32_t k = tid + u * kSymLanes; if (k < wn) win[k] = nxw[u]; }
+            for (uint32_t k = tid + WB * kSymLanes; k < wn; k += kSymLanes) win[k] = v[(c0 + k) & rmask];
 #pragma unroll
-                for (int u = 0; u < WB; ++u) { const uint32_t k = k0 + u * kSymLanes; if (k < wn) win[k] = tw[u]; }
-            }
-            for (uint32_t k = tid; k < R; k += kSymLanes) wl[k] = gw[(c0 - R + k) & rmask];   // cached sums of the R positions in front
+            for (int u = 0; u < LB; ++u) { const uint32_t k = tid + u * kSymLanes; if (k < R) wl[k] = tl[u]; }
+            for (uint32_t k = tid + LB * kSymLanes; k < R; k += kSymLanes) wl[k] = gw[(c0 - R + k) & rmask];   // (windows longer than the batches cover: from the ring, as written above)
             first_word = lmask[(c0 & rmask) >> 6];          // as the previous sweep left it
         }
         staged = false;
         ++sweeps; wl_c0 = c0;
         if (tid < kAvgSpan / 64 + 1) words[tid] = 0ull;
         __syncthreads();
+        if ((int32_t)(pend - (c0 + kAvgSpan)) > 0) {        // another sweep follows: its samples
+#pragma unroll
+            for (int u = 0; u < WB; ++u) { const uint32_t k = tid + u * kSymLanes; nxw[u] = k < wn ? v[(c0 + kAvgSpan + k) & rmask] : 0.0f; }
+        }
         SWEEP(0);
         const uint32_t p0 = c0 + tid * kAvgPos;
         const bool any = (int32_t)(pend - p0) > 0;
