@@ -274,6 +274,43 @@ def test_ragged_and_idle_streams(hd):
         assert eng.take_chars(s) == orcs[s].text("chars_log")
 
 
+def test_ragged_and_idle_pushes_free_running_through_the_unfused_two_stage_path(hd):
+    """/16 with pushes of up to 65536 samples: 4096 decimated samples per call, too many for the one-wave stream tail -- the separate kernels on two queues
+    (launch path 0).  Round 5 took the event waits off its front queue (three low-pass buffers take turns, the parameter copy rides behind stage 1), so
+    calls really overlap: ragged sizes, streams that skip calls, and NO getter between the calls (a getter drains the pipeline); every call's discriminator
+    checksum is compared afterwards, then text, and the last call's buffers."""
+    import habdec_amd
+    from oracle import pyoracle
+    S, fs = 6, 2.5e6
+    iq, _ = make_streams(S, fs, 300, 8, 2, seed0=77, repeat=3)
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=16, baud=300, rtty_bits=8, rtty_stops=2, lowpass_bw_hz=3000.0, pipeline=1)
+    orcs = [pyoracle.Decoder("oracle", factor=16, baud=300, bits=8, stops=2, lowpass_bw=3000.0) for _ in range(S)]
+    pos = [0] * S
+    r = np.random.default_rng(5)
+    ncalls = 0
+    while min(pos) < iq.shape[1] and ncalls < 90:
+        n = np.array([C, 0 if ncalls % 3 == 1 else C, 32768 if ncalls >= 2 else C, 2048 * int(r.integers(1, 33)), C if ncalls % 5 else 4096, 2048 * int(r.integers(8, 33))], np.uint32)
+        n = np.minimum(n, [iq.shape[1] - p for p in pos]).astype(np.uint32)
+        buf = np.zeros((S, C), np.complex64)
+        for s in range(S):
+            buf[s, :n[s]] = iq[s, pos[s]:pos[s] + n[s]]
+        habdec_amd.capi.check(eng.L.hd_process_host(eng.h, buf.ctypes.data, C, n.ctypes.data, 0))
+        for s in range(S):
+            if n[s]: orcs[s](iq[s, pos[s]:pos[s] + n[s]], fs)
+            pos[s] += int(n[s])
+        last_n = n
+        ncalls += 1
+    eng.flush()
+    assert eng.timing()["path"] == 0
+    for s in range(S):
+        assert eng.take_chars(s) == orcs[s].text("chars_log"), s
+        assert eng.take_sentences(s) == orcs[s].sentences(), s
+        if last_n[s]:
+            assert same_bits(eng.demodulated(s), orcs[s].array("last_demod")), s
+            assert same_bits(eng.decimated(s), orcs[s].array("last_decimated")), s
+    assert sum(len(o.sentences()) for o in orcs) >= 2 and all(len(o.text("chars_log")) > 10 for o in orcs)
+
+
 def test_short_chunk_history_quirk_and_rejects(hd):
     """Q4: a chunk so short that the in-place history overlaps the outputs still matches; a chunk shorter than the
     history is undefined in the reference and is rejected."""
