@@ -41,7 +41,13 @@ bool tail_layout(TailArgs& a, int lanes, int ratio2, int ntaps2, uint32_t max_ta
     // while the low-pass runs, and the read-ahead slack behind X and F is the next region (values read there are never used).  It is what lets
     // four tails sit beside FIVE stage-1 tile slots in a CU's LDS (decimate.hip: k_step_cu).
     const bool compact = lanes == 64;
-    uint32_t off = kTailHdrBytes + (compact ? ((XN + 1) & ~1u) : ((XN + 4 + 1) & ~1u) + 2 * NT + 2) * 8;
+#ifdef HD_X_NOPAD
+    const bool xpad = false;
+#else
+    const bool xpad = compact && tail_op(lanes) == 4 && ratio2 == 2;      // the padded stage-1 image (tail_body.h: kXPad): 16 bytes behind every 8 samples
+#endif
+    const uint32_t XNP = xpad ? XN + 2u * (XN >> 3) + 2u : XN;
+    uint32_t off = kTailHdrBytes + (compact ? ((XNP + 1) & ~1u) : ((XN + 4 + 1) & ~1u) + 2 * NT + 2) * 8;
     a.f_off = off; off += ((H + B + (compact ? 0u : 16u) + 1) & ~1u) * 8;
     a.v_off = off; off += ((max_R + B + 16 + 3) & ~3u) * 4;
     a.ws_off = off; off += ((max_R + B + 8 + 3) & ~3u) * 4;

@@ -122,7 +122,19 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     // when the low-pass passes run; the carry Y[0] outlives a piece and is kept in the header (sh[8..9]) between rounds.
     constexpr bool kCompact = NT == 64;
     static_assert(!kCompact || 2 * NT + 2 <= XCH, "the exchange array must fit the dead part of the stage-1 image");
-    float2* Y = kCompact ? X + ((T2 - 1 + 1) & ~1) : X + ((XN + 4 + 1) & ~1);
+    // The PADDED stage-1 image (one wave, four outputs per lane, /2): a lane's stage-2 window starts OP * D2 = 8 samples = 64 bytes after its neighbour's, and
+    // ds_read_b128 serves sixteen lanes per cycle from sixteen 16-byte bank groups -- at a 64-byte stride every fourth lane of a group hits the same one (a
+    // four-way conflict on every read of the tap loop).  16 bytes of padding behind every 8 samples make the stride 80 bytes, an odd number of bank groups:
+    // conflict-free (sample j lives at xpos(j); the lane's k-th 16-byte chunk at chunk k + k / 4 behind its first).  tail_layout (tail.hip) sizes the image.
+#ifdef HD_X_NOPAD
+    constexpr bool kXPad = false;
+#else
+    constexpr bool kXPad = kCompact && OP == 4 && D2 == 2;
+#endif
+    auto xpos = [](uint32_t j) -> uint32_t { return kXPad ? j + 2u * (j >> 3) : j; };
+    constexpr int YOFF = kXPad ? (((T2 - 2) + 2 * ((T2 - 2) >> 3) + 1 + 1) & ~1) : ((T2 - 1 + 1) & ~1);    // behind the (padded) stage-2 history
+    static_assert(!kXPad || YOFF + 2 * NT + 2 <= XN, "the exchange array must fit the dead part of the padded stage-1 image");
+    float2* Y = kCompact ? X + YOFF : X + ((XN + 4 + 1) & ~1);
     float2* carryY = reinterpret_cast<float2*>(sh + 8);
     float2* F = reinterpret_cast<float2*>(lds + a.f_off);               // low-pass input window, F[0] = input index fbase
     float* V = reinterpret_cast<float*>(lds + a.v_off);                 // discriminator output from position c0 on
@@ -289,7 +301,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         }
         }
 #pragma unroll
-        for (int u = 0; u < HB; ++u) { const uint32_t k = tid + u * NT; if (k < (uint32_t)(T2 - 1)) X[k] = th[u]; }
+        for (int u = 0; u < HB; ++u) { const uint32_t k = tid + u * NT; if (k < (uint32_t)(T2 - 1)) X[xpos(k)] = th[u]; }
         if (tid == 0) { if (kCompact) carryY[0] = make_float2(kin.re, kin.im); else Y[0] = make_float2(kin.re, kin.im); }
     }
     vcnt = take0;
@@ -403,7 +415,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
 #pragma unroll
         for (int u = 0; u < XB; ++u) {
             const uint32_t k = tid + u * NT;
-            *reinterpret_cast<float4*>(X + (T2 - 1) + 2 * k) = tx[u];
+            *reinterpret_cast<float4*>(X + xpos((uint32_t)(T2 - 1) + 2 * k)) = tx[u];     // (T2 - 1 is even: a pair never straddles a pad)
         }
         tb_sync<NT>();
         if (pc + 1 < npieces) prefetch(pc + 1);
@@ -416,19 +428,14 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         {
             constexpr int NWIN = ((D2 * (OP - 1) + 3) >> 1) + 1;       // 16-byte pairs a block of four taps touches
             const f32x4* h2 = reinterpret_cast<const f32x4*>(H2);
-            const f32x4* px = reinterpret_cast<const f32x4*>(X + (size_t)(OP * tid) * D2);
+            const f32x4* px = reinterpret_cast<const f32x4*>(X + xpos((uint32_t)(OP * tid) * D2));
             f32x4 kc = h2[0];
             f32x2 acc[OP];
             f32x4 win[NWIN];
 #pragma unroll
             for (int q = 0; q < OP; ++q) acc[q] = (f32x2){0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < NWIN; ++j) win[j] = px[j];
             constexpr int NB4 = T2 / 4;
-#pragma unroll 2
-            for (int b = 0; b < NB4; ++b) {
-                const f32x4 n0 = px[2 * b + NWIN], n1 = px[2 * b + NWIN + 1];   // (the last block reads a few slots past its taps: in bounds, unused)
-                const f32x4 kn = h2[b + 1];
+            auto block = [&](const f32x4 n0, const f32x4 n1, const f32x4 kn) {
                 __builtin_amdgcn_sched_barrier(0);                      // keep those reads up here: one wave has nobody else to hide their latency
                 tb_s2_tap<0, OP, D2, NWIN>(acc, win, kc.x);
                 tb_s2_tap<1, OP, D2, NWIN>(acc, win, kc.y);
@@ -438,6 +445,30 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
                 for (int j = 0; j + 2 < NWIN; ++j) win[j] = win[j + 2];
                 win[NWIN - 2] = n0; win[NWIN - 1] = n1;
                 kc = kn;
+            };
+            if constexpr (kXPad) {
+                // chunk k of the lane's window sits at px[k + k / 4]; a block of four taps takes chunks 2 b + NWIN and 2 b + NWIN + 1 (NWIN = 5), so two blocks
+                // advance the chunk pointer by exactly five: immediate offsets inside the pair, one pointer bump per pair
+                static_assert(NWIN == 5, "the padded image's offsets below are those of four outputs per lane at /2");
+#pragma unroll
+                for (int j = 0; j < NWIN; ++j) win[j] = px[j + (j >> 2)];
+                const f32x4* pq = px;
+                int b = 0;
+#pragma unroll 1
+                for (; b + 2 <= NB4; b += 2, pq += 5) {
+                    { const f32x4 n0 = pq[6], n1 = pq[7]; const f32x4 kn = h2[b + 1]; block(n0, n1, kn); }
+                    { const f32x4 n0 = pq[8], n1 = pq[10]; const f32x4 kn = h2[b + 2]; block(n0, n1, kn); }
+                }
+                if (b < NB4) { const f32x4 n0 = pq[6], n1 = pq[7]; const f32x4 kn = h2[b + 1]; block(n0, n1, kn); }   // (reads a few slots past its taps: in bounds, unused)
+            } else {
+#pragma unroll
+                for (int j = 0; j < NWIN; ++j) win[j] = px[j];
+#pragma unroll 2
+                for (int b = 0; b < NB4; ++b) {
+                    const f32x4 n0 = px[2 * b + NWIN], n1 = px[2 * b + NWIN + 1];   // (the last block reads a few slots past its taps: in bounds, unused)
+                    const f32x4 kn = h2[b + 1];
+                    block(n0, n1, kn);
+                }
             }
             if constexpr (T2 % 4 >= 1) tb_s2_tap<0, OP, D2, NWIN>(acc, win, kc.x);   // the T2 % 4 taps left over
             if constexpr (T2 % 4 >= 2) tb_s2_tap<1, OP, D2, NWIN>(acc, win, kc.y);
@@ -489,7 +520,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         // the last T2-1 samples of this image are the next piece's history
         float2 xt[HB];
 #pragma unroll
-        for (int u = 0; u < HB; ++u) { const uint32_t k = tid + u * NT; xt[u] = k < (uint32_t)(T2 - 1) ? X[XCH + k] : make_float2(0.f, 0.f); }
+        for (int u = 0; u < HB; ++u) { const uint32_t k = tid + u * NT; xt[u] = k < (uint32_t)(T2 - 1) ? X[xpos((uint32_t)XCH + k)] : make_float2(0.f, 0.f); }
         if (pc + 1 == npieces && n1) {
             // stage-2 history carry for the next call (Decimator.h:140-143, with the in-place quirk Q4 of Decoder.h:443-444: history
             // positions inside the first n2 samples hold OUTPUTS -- only for inputs so short that this is the only piece)
@@ -501,7 +532,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         }
         tb_sync<NT>();
 #pragma unroll
-        for (int u = 0; u < HB; ++u) { const uint32_t k = tid + u * NT; if (k < (uint32_t)(T2 - 1)) X[k] = xt[u]; }
+        for (int u = 0; u < HB; ++u) { const uint32_t k = tid + u * NT; if (k < (uint32_t)(T2 - 1)) X[xpos(k)] = xt[u]; }
         fcount += po;
         TSTAMP(3);
 
