@@ -132,6 +132,10 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     constexpr bool kXPad = kCompact && OP == 4 && D2 == 2;
 #endif
     auto xpos = [](uint32_t j) -> uint32_t { return kXPad ? j + 2u * (j >> 3) : j; };
+    // (positions this lane stores to, once per call: sample tid + NT u sits NT + NT / 4 slots behind sample tid + NT (u - 1), and so on -- NT is a multiple of 8)
+    constexpr uint32_t kXStepH = kXPad ? NT + 2 * (NT >> 3) : NT, kXStepP = kXPad ? 2 * NT + 2 * (2 * NT >> 3) : 2 * NT, kXPiece = kXPad ? XCH + 2 * (XCH >> 3) : XCH;
+    static_assert(NT % 8 == 0 && XCH % 8 == 0, "whole pad groups per step");
+    const uint32_t xh0 = xpos(tid), xp0 = xpos((uint32_t)(T2 - 1) + 2u * tid);
     constexpr int YOFF = kXPad ? (((T2 - 2) + 2 * ((T2 - 2) >> 3) + 1 + 1) & ~1) : ((T2 - 1 + 1) & ~1);    // behind the (padded) stage-2 history
     static_assert(!kXPad || YOFF + 2 * NT + 2 <= XN, "the exchange array must fit the dead part of the padded stage-1 image");
     float2* Y = kCompact ? X + YOFF : X + ((XN + 4 + 1) & ~1);
@@ -301,7 +305,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         }
         }
 #pragma unroll
-        for (int u = 0; u < HB; ++u) { const uint32_t k = tid + u * NT; if (k < (uint32_t)(T2 - 1)) X[xpos(k)] = th[u]; }
+        for (int u = 0; u < HB; ++u) { const uint32_t k = tid + u * NT; if (k < (uint32_t)(T2 - 1)) X[xh0 + u * kXStepH] = th[u]; }
         if (tid == 0) { if (kCompact) carryY[0] = make_float2(kin.re, kin.im); else Y[0] = make_float2(kin.re, kin.im); }
     }
     vcnt = take0;
@@ -414,8 +418,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         const uint32_t o0 = pc * P, po = min((uint32_t)P, n2 - o0);
 #pragma unroll
         for (int u = 0; u < XB; ++u) {
-            const uint32_t k = tid + u * NT;
-            *reinterpret_cast<float4*>(X + xpos((uint32_t)(T2 - 1) + 2 * k)) = tx[u];     // (T2 - 1 is even: a pair never straddles a pad)
+            *reinterpret_cast<float4*>(X + xp0 + u * kXStepP) = tx[u];     // (sample T2 - 1 + 2 k; T2 - 1 is even: a pair never straddles a pad)
         }
         tb_sync<NT>();
         if (pc + 1 < npieces) prefetch(pc + 1);
@@ -520,7 +523,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         // the last T2-1 samples of this image are the next piece's history
         float2 xt[HB];
 #pragma unroll
-        for (int u = 0; u < HB; ++u) { const uint32_t k = tid + u * NT; xt[u] = k < (uint32_t)(T2 - 1) ? X[xpos((uint32_t)XCH + k)] : make_float2(0.f, 0.f); }
+        for (int u = 0; u < HB; ++u) { const uint32_t k = tid + u * NT; xt[u] = k < (uint32_t)(T2 - 1) ? X[xh0 + kXPiece + u * kXStepH] : make_float2(0.f, 0.f); }
         if (pc + 1 == npieces && n1) {
             // stage-2 history carry for the next call (Decimator.h:140-143, with the in-place quirk Q4 of Decoder.h:443-444: history
             // positions inside the first n2 samples hold OUTPUTS -- only for inputs so short that this is the only piece)
@@ -532,7 +535,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         }
         tb_sync<NT>();
 #pragma unroll
-        for (int u = 0; u < HB; ++u) { const uint32_t k = tid + u * NT; if (k < (uint32_t)(T2 - 1)) X[xpos(k)] = xt[u]; }
+        for (int u = 0; u < HB; ++u) { const uint32_t k = tid + u * NT; if (k < (uint32_t)(T2 - 1)) X[xh0 + u * kXStepH] = xt[u]; }
         fcount += po;
         TSTAMP(3);
 
