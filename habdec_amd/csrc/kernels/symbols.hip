@@ -316,72 +316,79 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     // run in progress is carried across calls (SymState::run_sum covers [base, run_pos)): every call extends it up to
     // the search frontier -- samples that can no longer become a flip point -- so when the flip finally shows up only
     // the few samples between the frontier and the flip remain.  The chain is the same left-to-right sequence of adds.
-    float* sb = strips + wave * kRunStrip;                                // wave-private strip, single buffer
-    constexpr int NX = kRunStrip / 64;                                    // loads in flight per lane: one whole strip
-    auto chain = [&](float acc, uint32_t a, uint32_t b) -> float {       // acc + v[a] + v[a+1] + ... + v[b-1] (backlog indices)
-        if (a >= b) return acc;
+    // FOUR runs per wave at a time (round 5): lanes 16 g .. 16 g + 15 work on run 4 q + g -- their own strip of the wave's LDS, their own accumulator -- in ONE
+    // instruction stream, so a call's runs cost a quarter of the vector instructions (each add used to be a wave instruction with one useful lane) and
+    // sixteen runs are in flight per workgroup instead of four.  The runs of a batch differ in length: a strip is zero-filled behind its run's end and every
+    // group adds the batch's longest length -- x + (+0.0f) is x for every x, and a sum that starts at +0 is never -0, so the extra adds change nothing.
+    constexpr int G = 4, GL = 64 / G, SL = (int)kRunStrip / 2;           // groups per wave, lanes per group, samples per strip and group
+    constexpr int NX = SL / GL;                                           // loads in flight per lane: one whole strip of its group
+    static_assert(G * SL * (kSymLanes / 64) <= 2 * (kAvgSpan + 4), "the strips overlay win / wl");
+    const uint32_t g = lane / GL, gl = lane % GL;
+    float* sbg = strips + wave * (G * SL) + g * SL;                       // my group's strip (wave-private memory)
+    const uint32_t carried_to = st.run_pos - st.base;       // run 0's sum is already known up to here
+    // Run nfl is the carry for the next call: the run now in progress starts at the last flip (or continues) and is summed up to the frontier.
+    const uint32_t frontier = s_frontier;
+    for (uint32_t rb = (uint32_t)G * wave; rb <= nfl; rb += (uint32_t)G * (kSymLanes / 64)) {
+        const uint32_t r = rb + g;
+        const bool live = r <= nfl;
+        uint32_t a = 0, b = 0;                                            // the samples run r still has to add: backlog indices [a, b)
+        float acc = 0.0f;
+        if (live) {
+            if (r < nfl) { b = flips[r]; a = r ? flips[r - 1] : min(carried_to, b); }
+            else { a = nfl ? flips[nfl - 1] : carried_to; b = max(a, frontier); }
+            if (r == 0u || (r == nfl && !nfl)) acc = st.run_sum;
+        }
+        const uint32_t len = b > a ? b - a : 0u;
+        const uint32_t maxlen = max(max((uint32_t)__builtin_amdgcn_readlane((int)len, 0), (uint32_t)__builtin_amdgcn_readlane((int)len, GL)),
+                                    max((uint32_t)__builtin_amdgcn_readlane((int)len, 2 * GL), (uint32_t)__builtin_amdgcn_readlane((int)len, 3 * GL)));
         float nx[NX];
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
-            const uint32_t k = a + 64 * j + lane;
+            const uint32_t k = a + GL * j + gl;
             nx[j] = k < b ? v[(st.base + k) & rmask] : 0.0f;
         }
-        for (uint32_t k0 = a; k0 < b; k0 += kRunStrip) {
+        for (uint32_t k0 = 0; k0 < maxlen; k0 += SL) {
             // the previous strip's LDS reads have all been consumed by its adds (data dependence), so the strip can be
             // rewritten from the prefetched registers; the next strip's loads then fly under this strip's adds
 #pragma unroll
-            for (int j = 0; j < NX; ++j) sb[64 * j + lane] = nx[j];
-            if (k0 + kRunStrip < b) {
+            for (int j = 0; j < NX; ++j) sbg[GL * j + gl] = nx[j];
+            if (k0 + SL < maxlen) {
 #pragma unroll
                 for (int j = 0; j < NX; ++j) {
-                    const uint32_t k = k0 + kRunStrip + 64 * j + lane;
+                    const uint32_t k = a + k0 + SL + GL * j + gl;
                     nx[j] = k < b ? v[(st.base + k) & rmask] : 0.0f;
                 }
             }
-            __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): this wave's strip writes have landed (wave-private strip)
+            __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): this wave's strip writes have landed (wave-private strips)
             __builtin_amdgcn_wave_barrier();
-            const uint32_t cnt = min(kRunStrip, b - k0);
-            const float4* s4 = reinterpret_cast<const float4*>(sb);
+            const uint32_t cnt = (min((uint32_t)SL, maxlen - k0) + 31u) & ~31u;   // whole blocks of 32: the strip is zero-filled behind every run's end
+            const float4* s4 = reinterpret_cast<const float4*>(sbg);
+            // 32 samples per block through group-uniform 16-byte reads (broadcast within a group), the next block in flight under this block's 32 adds; two
+            // register images take turns, so nothing is copied between blocks
+            float4 c[8], n[8];
+            auto ld = [&](float4 (&x)[8], const uint32_t at) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = s4[(at >> 2) + u];
+            };
+            auto adds = [&](const float4 (&x)[8]) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc = acc + x[u].x; acc = acc + x[u].y; acc = acc + x[u].z; acc = acc + x[u].w; }
+            };
             uint32_t i = 0;
-            if (cnt >= 32) {
-                // 32 samples per block through wave-uniform 16-byte reads (broadcast), the next block in flight under this block's 32 adds; two
-                // register images take turns, so nothing is copied between blocks (one VALU move per add otherwise: the chain itself cannot get
-                // shorter, but its instructions compete with the other workgroups' window sums for the vector pipe)
-                float4 c[8], n[8];
-                auto ld = [&](float4 (&x)[8], const uint32_t at) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) x[u] = s4[(at >> 2) + u];
-                };
-                auto adds = [&](const float4 (&x)[8]) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { acc = acc + x[u].x; acc = acc + x[u].y; acc = acc + x[u].z; acc = acc + x[u].w; }
-                };
-                ld(c, 0u);                                                  // invariant: c holds samples [i, i + 32), i + 32 <= cnt
-                for (; i + 96 <= cnt; i += 64) { ld(n, i + 32); adds(c); ld(c, i + 64); adds(n); }
-                if (i + 64 <= cnt) { ld(n, i + 32); adds(c); adds(n); i += 64; }
-                else { adds(c); i += 32; }
-            }
-            for (; i < cnt; ++i) acc = acc + sb[i];
+            ld(c, 0u);                                                      // invariant: c holds samples [i, i + 32), i + 32 <= cnt
+            for (; i + 96 <= cnt; i += 64) { ld(n, i + 32); adds(c); ld(c, i + 64); adds(n); }
+            if (i + 64 <= cnt) { ld(n, i + 32); adds(c); adds(n); }
+            else adds(c);
             __builtin_amdgcn_wave_barrier();
         }
-        return acc;
-    };
-    const uint32_t carried_to = st.run_pos - st.base;       // run 0's sum is already known up to here
-    for (uint32_t r = wave; r < nfl; r += kSymLanes / 64) {
-        const uint32_t a = r ? flips[r - 1] : 0u, b = flips[r];
-        const float acc = r ? chain(0.0f, a, b) : chain(st.run_sum, min(carried_to, b), b);
-        if (lane == 0) {
-            const float mean = acc / (float)(b - a);
-            const uint32_t cnt = (uint32_t)roundf((float)(b - a) / (float)q.spb);
-            runinfo[r] = (cnt << 1) | (mean > 0.0f ? 1u : 0u);
+        if (live && gl == 0) {
+            if (r < nfl) {
+                const uint32_t a0 = r ? flips[r - 1] : 0u;
+                const float mean = acc / (float)(b - a0);
+                const uint32_t cnt = (uint32_t)roundf((float)(b - a0) / (float)q.spb);
+                runinfo[r] = (cnt << 1) | (mean > 0.0f ? 1u : 0u);
+            } else s_carry = acc;
         }
-    }
-    // carry for the next call: the run now in progress starts at the last flip (or continues) and is summed up to the frontier
-    const uint32_t frontier = s_frontier;
-    if (wave == (nfl & 3u)) {
-        const uint32_t a = nfl ? flips[nfl - 1] : carried_to;
-        const float acc = chain(nfl ? 0.0f : st.run_sum, a, max(a, frontier));
-        if (lane == 0) s_carry = acc;
     }
     __syncthreads();
 
