@@ -1,13 +1,17 @@
 #!/bin/bash
 # Run ON the GPU box (through gpurun): everything profiles/<round>_* is made from -- the GPU suite, the bench lines, the single-stream lines, the
-# rocprofv3 kernel-stats + PMC passes of every shape, SQ counters, energy per step, the clock / power series.  Usage: tools/collect_round.sh <tag>
+# rocprofv3 kernel-stats + PMC passes of every shape, SQ counters, energy per step, the clock / power series.  Usage: tools/collect_round.sh <tag> [round, default r05]
 cd $GRAFT_REPO_ROOT
 o=gpurun_out/$1; mkdir -p $o
 timeout 700 python -m pytest tests -m gpu -q 2>&1 | tail -12 > $o/pytest.txt
+# the headline pair first, in this order: step profile -> its summary into profiles/ -> the driver's and the default command (their roofline.rocprof_avg_launch_ms
+# then is THIS session's steady-state average); tools/final_lines.sh makes the other lines (its own driver / default lines land in lines/ as a second sample)
+bash tools/profile_then_lines.sh ${2:-r05} > $o/headline.log 2>&1
+cp gpurun_out/headline/* $o/ 2>/dev/null
 bash tools/final_lines.sh > $o/final_lines.log 2>&1
-cp gpurun_out/lines/* $o/ 2>/dev/null
+mkdir -p $o/lines_second_sample; cp gpurun_out/lines/driver_bench_line.json gpurun_out/lines/default_bench_line.json $o/lines_second_sample/ 2>/dev/null
+cp gpurun_out/lines/sync_bench_line.json gpurun_out/lines/other_workloads.jsonl $o/ 2>/dev/null
 timeout 300 python3 tools/single_stream.py > $o/single_stream.jsonl 2>$o/single.err
-bash tools/gpu_profile.sh step > $o/profile_step.log 2>&1
 bash tools/gpu_profile.sh sync --sync > $o/profile_sync.log 2>&1
 bash tools/gpu_profile.sh cfg2 --workload cfg2 > $o/profile_cfg2.log 2>&1
 bash tools/gpu_profile.sh cfg3 --workload cfg3 > $o/profile_cfg3.log 2>&1
