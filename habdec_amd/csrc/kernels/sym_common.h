@@ -162,6 +162,31 @@ __device__ __forceinline__ void window_sums_wide(const float* __restrict__ w, ui
 #pragma unroll
     for (int j = 0; j < KP; ++j) acc[j] = s[j];
 }
+// flag(p) = sgn(W(p - R) / R) != sgn(W(p) / R) for a lane's KP consecutive positions, of which the first nvalid exist: bit j of the result.  The quotient's sign
+// is the sum's unless the quotient underflows to zero (|W| / R < 2^-149: only then does the division matter).  When every sum of every active lane of the WAVE
+// is beyond that -- always, on real data -- two sums differ in sign iff their sign bits differ: three instructions per position.  (Written per position as
+// `|W| > tiny ? sgn(W) : sgn(W / R)` the compiler turns the ?: into a select and evaluates BOTH IEEE divisions for every position: ~50 vector instructions
+// each, a sixth of k_symbols' vector instructions at /4 -- round 5.)
+template <int KP>
+__device__ __forceinline__ unsigned int sign_flags(const float (&wl)[KP], const float (&wr)[KP], const uint32_t nvalid, const uint32_t R)
+{
+    const float tiny = (float)R * 2.8e-45f;             // > R * 2^-149, far below any non-zero window sum of real data
+    bool plain = true;
+#pragma unroll
+    for (int j = 0; j < KP; ++j)
+        if ((uint32_t)j < nvalid) plain = plain && __builtin_fabsf(wl[j]) > tiny && __builtin_fabsf(wr[j]) > tiny;
+    unsigned int bits = 0;
+    if (__builtin_amdgcn_ballot_w64(!plain) == 0ull) {  // (wave-uniform: every active lane's sums are ordinary -- non-zero, not NaN)
+#pragma unroll
+        for (int j = 0; j < KP; ++j) bits |= ((__builtin_bit_cast(uint32_t, wl[j]) ^ __builtin_bit_cast(uint32_t, wr[j])) >> 31) << j;
+    } else {
+        auto avg_sign = [&](float wsum) { return __builtin_fabsf(wsum) > tiny ? sgnf(wsum) : sgnf(wsum / (float)R); };
+#pragma unroll
+        for (int j = 0; j < KP; ++j) if (avg_sign(wl[j]) != avg_sign(wr[j])) bits |= 1u << j;
+    }
+    return nvalid >= (uint32_t)KP ? bits : bits & ((1u << nvalid) - 1u);
+}
+
 constexpr int kWidePos = 8;
 __device__ __forceinline__ void window_sums8(const float* __restrict__ w, uint32_t R, float (&acc)[kWidePos]) { window_sums_wide<kWidePos>(w, R, acc); }
 

@@ -185,16 +185,12 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
         __syncthreads();
         SWEEP(1);
         if (any) {
-            unsigned int bits = 0;
-            // sgn(W/R) == sgn(W) unless the quotient underflows to zero: |W| / R < 2^-149 (only then pay for the division)
-            const float tiny = (float)R * 2.8e-45f;         // > R * 2^-149, far below any non-zero window sum of real data
-            auto avg_sign = [&](float wsum) { return __builtin_fabsf(wsum) > tiny ? sgnf(wsum) : sgnf(wsum / (float)R); };
+            // no clamping: p >= base + R is all the search reads, p + R <= end
+            float wlv[kAvgPos];
+            const float4* wl4 = reinterpret_cast<const float4*>(wl + tid * kAvgPos);
 #pragma unroll
-            for (int j = 0; j < kAvgPos; ++j) {
-                if ((int32_t)(pend - (p0 + j)) > 0) {        // no clamping: p >= base+R is all the search reads, p+R <= end
-                    if (avg_sign(wl[tid * kAvgPos + j]) != avg_sign(wp[j])) bits |= 1u << j;
-                }
-            }
+            for (int c4 = 0; c4 < kAvgPos / 4; ++c4) { const float4 x = wl4[c4]; wlv[4 * c4] = x.x; wlv[4 * c4 + 1] = x.y; wlv[4 * c4 + 2] = x.z; wlv[4 * c4 + 3] = x.w; }
+            const unsigned int bits = sign_flags<kAvgPos>(wlv, wp, min((uint32_t)kAvgPos, pend - p0), R);
             if (bits) {
                 const uint32_t bp = wsh + tid * kAvgPos;    // bit position of p0 relative to the sweep's first word
                 const uint32_t sh = bp & 63u;

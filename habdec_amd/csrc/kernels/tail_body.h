@@ -318,8 +318,6 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     auto sym_feed = [&]() {
         int32_t npos = (int32_t)vcnt - (int32_t)R + 1;
         uint32_t off = 0;
-        const float tiny = (float)R * 2.8e-45f;
-        auto avg_sign = [&](float wsum) { return __builtin_fabsf(wsum) > tiny ? sgnf(wsum) : sgnf(wsum / (float)R); };
         constexpr uint32_t KP = kWidePos;                               // positions per lane
         while (npos > 0) {
             const uint32_t cnt = min((uint32_t)npos, (uint32_t)(KP * NT));
@@ -346,10 +344,11 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
             TSTAMP(15);
             tb_sync<NT>();
             if (any) {
-                unsigned int bits = 0;
+                float wlv[KP];
+                const float4* wl4 = reinterpret_cast<const float4*>(WS + off + KP * tid);    // (off is a multiple of the sweep, the window 16-byte aligned)
 #pragma unroll
-                for (int j = 0; j < (int)KP; ++j)
-                    if (KP * tid + j < cnt && avg_sign(WS[off + KP * tid + j]) != avg_sign(wp[j])) bits |= 1u << j;
+                for (int c4 = 0; c4 < (int)KP / 4; ++c4) { const float4 x = wl4[c4]; wlv[4 * c4] = x.x; wlv[4 * c4 + 1] = x.y; wlv[4 * c4 + 2] = x.z; wlv[4 * c4 + 3] = x.w; }
+                const unsigned int bits = sign_flags<(int)KP>(wlv, wp, min(KP, cnt - KP * tid), R);
                 if (bits) {
                     const uint32_t bp = wsh + tid * KP, shb = bp & 63u;
                     atomicOr(&words[bp >> 6], (unsigned long long)bits << shb);
