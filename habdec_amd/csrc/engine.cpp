@@ -869,8 +869,10 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     const int tail_lanes = (S >= 2 * e->n_cus ? 64 : 256);
     // One wave per stream is the right shape while a call is short: its time grows with the decimated samples per call, and beyond
     // ~2048 of them (e.g. /16 with 65536-sample pushes: 4096) the many-workgroup kernels finish a batch sooner (measured: 156 vs 173 GS/s).
+    // (a handful of streams, long calls: the 256-lane tail in pieces of 1024 outputs where its windows fit -- one piece for a 65536-sample push at /64 --, of 256 otherwise)
     const bool tail = nst == 2 && !any_dc && !e->no_tail && max_n2 <= e->tail_max_n2 &&
-                      hd::tail_layout(ta, tail_lanes, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, 64 * 1024);
+                      ((tail_lanes == 256 && max_n2 >= 512u && hd::tail_layout(ta, tail_lanes, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, 64 * 1024, 4)) ||
+                       hd::tail_layout(ta, tail_lanes, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, 64 * 1024));
     const bool fuse = tail || (nst == 2 && !any_dc && !e->no_fuse && ((R2 == 2 && T2 == 69) || (R2 == 4 && T2 == 139)) &&
                       hd::backend_lds_bytes((int)T2, max_n1, max_n2, max_taps) <= 64 * 1024);
     // Step mode: batch decoding of equally sized pushes through a single-wave first stage -- ONE launch per call, on one queue: this

@@ -93,12 +93,14 @@ struct TailArgs {
     // (search phase, overlaying the stream windows: [header][flip list + run info][run-sum strips] at fixed offsets, then from dyn_off to lds_bytes a region
     // every stream carves for itself: the flag-mask image of its searchable backlog, a sample cache for the run sums, a window-sum cache for the edge search)
     uint32_t pend_max, f_off, v_off, ws_off, words_off, tp_off, h2_off, flips_off, fl_cap, strips_off, dyn_off, lds_bytes;
+    uint32_t op;          // stage-2 outputs per lane and piece the carve was made for (tail_layout; launch_tail picks the kernel by it)
 };
 // Fills the LDS carve for `lanes` (64 or 256) lanes per stream; returns false when (ratio2, ntaps2) has no tail instantiation or the
 // windows for max_taps / max_R do not fit into lds_limit bytes -- the caller then runs launch_backend / launch_decimate + launch_fir_demod
 // and launch_symbols instead.
 bool tail_layout(TailArgs& a, int lanes, int ratio2, int ntaps2, uint32_t max_taps, uint32_t max_R, uint32_t min_R, uint32_t ring_cap,
-                 uint32_t pend_max /* most pending samples any stream has in front of or behind this call's low-pass run */, uint32_t lds_limit);
+                 uint32_t pend_max /* most pending samples any stream has in front of or behind this call's low-pass run */, uint32_t lds_limit,
+                 int op = 0 /* stage-2 outputs per lane and piece: 0 = the default of `lanes` (4 for 64 lanes, 1 for 256); 256 lanes also take 4 */);
 bool launch_tail(hipStream_t st, int lanes, int ratio2, int ntaps2, uint32_t n_streams, const TailArgs& a, hipEvent_t ev_stop = nullptr);
 // Batch mode, two-stage plans whose first stage is a single-wave design: ONE launch per step -- the stream tails of the previous call
 // (workgroups [0, n_tail), arguments `ta`) in front of this call's stage 1 as a linear split over stage1_wgs workgroups; every stream

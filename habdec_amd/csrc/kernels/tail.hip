@@ -26,15 +26,21 @@ extern "C" void hd_debug_tail_fault_arm_no_tag()
 extern "C" void hd_debug_tail_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tail_stamps), n * 8); }
 #endif
 
-static constexpr int tail_op(int lanes) { return lanes == 64 ? 4 : 1; }
+// Stage-2 outputs per lane and piece: four for the one-wave tail; the 256-lane tail (a handful of streams) takes one -- pieces of 256 outputs, every wave busy
+// on short calls -- or four: a call of 1024 decimated samples is then ONE piece instead of four (a single stream's 65536-sample push at /64: 55.7 against
+// 69.8 us per push, round 5).  The engine picks by the call's size.
+static constexpr int tail_op_default(int lanes) { return lanes == 64 ? 4 : 1; }
 
-bool tail_layout(TailArgs& a, int lanes, int ratio2, int ntaps2, uint32_t max_taps, uint32_t max_R, uint32_t min_R, uint32_t ring_cap, uint32_t pend_max, uint32_t lds_limit)
+bool tail_layout(TailArgs& a, int lanes, int ratio2, int ntaps2, uint32_t max_taps, uint32_t max_R, uint32_t min_R, uint32_t ring_cap, uint32_t pend_max, uint32_t lds_limit, int op)
 {
+    if (!op) op = tail_op_default(lanes);
+    if (!(lanes == 64 ? op == 4 : (op == 1 || op == 4))) return false;
+    a.op = (uint32_t)op;
     if (!((ratio2 == 2 && ntaps2 == 69) || (ratio2 == 4 && ntaps2 == 139))) return false;
     if (lanes != 64 && lanes != 256) return false;
     if (pend_max > kFirBatch - 1) pend_max = kFirBatch - 1;
     a.pend_max = pend_max;
-    const uint32_t NT = (uint32_t)lanes, P = NT * (uint32_t)tail_op(lanes), B = 2 * P + pend_max;
+    const uint32_t NT = (uint32_t)lanes, P = NT * (uint32_t)op, B = 2 * P + pend_max;
     const uint32_t XN = (uint32_t)(ntaps2 - 1) + P * (uint32_t)ratio2;
     const uint32_t H = max_taps ? max_taps - 1 : 0;
     // 64 lanes: the compact carve (tail_body.h: kCompact) -- the discriminator's exchange array lives in the part of the stage-1 image that is dead
@@ -44,7 +50,7 @@ bool tail_layout(TailArgs& a, int lanes, int ratio2, int ntaps2, uint32_t max_ta
 #ifdef HD_X_NOPAD
     const bool xpad = false;
 #else
-    const bool xpad = compact && tail_op(lanes) == 4 && ratio2 == 2;      // the padded stage-1 image (tail_body.h: kXPad): 16 bytes behind every 8 samples
+    const bool xpad = compact && op == 4 && ratio2 == 2;      // the padded stage-1 image (tail_body.h: kXPad): 16 bytes behind every 8 samples
 #endif
     const uint32_t XNP = xpad ? XN + 2u * (XN >> 3) + 2u : XN;
     uint32_t off = kTailHdrBytes + (compact ? ((XNP + 1) & ~1u) : ((XN + 4 + 1) & ~1u) + 2 * NT + 2) * 8;
@@ -79,13 +85,13 @@ bool tail_layout(TailArgs& a, int lanes, int ratio2, int ntaps2, uint32_t max_ta
 
 bool launch_tail(hipStream_t st, int lanes, int ratio2, int ntaps2, uint32_t n_streams, const TailArgs& a, hipEvent_t ev_stop)
 {
-#define HD_TAIL_CASE(NT, D, T)                                                                                        \
-    if (lanes == NT && ratio2 == D && ntaps2 == T) {                                                                  \
-        if (ev_stop) hipExtLaunchKernelGGL((k_tail<NT, tail_op(NT), D, T>), dim3(n_streams), dim3(NT), a.lds_bytes, st, nullptr, ev_stop, 0u, a); \
-        else hipLaunchKernelGGL((k_tail<NT, tail_op(NT), D, T>), dim3(n_streams), dim3(NT), a.lds_bytes, st, a);      \
+#define HD_TAIL_CASE(NT, OP, D, T)                                                                                    \
+    if (lanes == NT && a.op == OP && ratio2 == D && ntaps2 == T) {                                                    \
+        if (ev_stop) hipExtLaunchKernelGGL((k_tail<NT, OP, D, T>), dim3(n_streams), dim3(NT), a.lds_bytes, st, nullptr, ev_stop, 0u, a); \
+        else hipLaunchKernelGGL((k_tail<NT, OP, D, T>), dim3(n_streams), dim3(NT), a.lds_bytes, st, a);               \
         return true;                                                                                                  \
     }
-    HD_TAIL_CASE(64, 2, 69) HD_TAIL_CASE(64, 4, 139) HD_TAIL_CASE(256, 2, 69) HD_TAIL_CASE(256, 4, 139)
+    HD_TAIL_CASE(64, 4, 2, 69) HD_TAIL_CASE(64, 4, 4, 139) HD_TAIL_CASE(256, 1, 2, 69) HD_TAIL_CASE(256, 1, 4, 139) HD_TAIL_CASE(256, 4, 2, 69) HD_TAIL_CASE(256, 4, 4, 139)
 #undef HD_TAIL_CASE
     return false;
 }
