@@ -311,6 +311,35 @@ def test_ragged_and_idle_pushes_free_running_through_the_unfused_two_stage_path(
     assert sum(len(o.sentences()) for o in orcs) >= 2 and all(len(o.text("chars_log")) > 10 for o in orcs)
 
 
+@pytest.mark.parametrize("factor,fs,lowpass", [(64, 2.048e6, None), (16, 2.5e6, 3000.0)])
+def test_silence_between_transmissions_takes_the_general_paths(hd, factor, fs, lowpass):
+    """Samples that are exactly zero (a muted receiver, a file padded with zeros): the discriminator sees arg(0 * conj(0)), the window sums are exactly 0 -- the
+    cases the wave-uniform fast paths (exact_math.h discriminate, sym_common.h sign_flags: no special operands, no sum inside the quotient's underflow) hand to
+    the general code.  Through the stream tail (/64) and through k_fir_demod + k_symbols (/16), call by call against the oracle."""
+    import habdec_amd
+    from oracle import pyoracle
+    S = 3
+    iq, _ = make_streams(S, fs, 300, 8, 2, seed0=91, repeat=2)
+    iq = iq.copy()
+    nch = iq.shape[1] // C
+    iq[1, :3 * C] = 0                                        # silence first, then the transmission
+    iq[2, 2 * C:5 * C] = 0                                   # silence in the middle of it
+    iq[2, 5 * C + 1000:5 * C + 1007] = 0                     # ... and a few zero samples inside live signal
+    kw = dict(lowpass_bw_hz=lowpass) if lowpass else {}
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=factor, baud=300, rtty_bits=8, rtty_stops=2, **kw)
+    orcs = [pyoracle.Decoder("oracle", factor=factor, baud=300, bits=8, stops=2, **({"lowpass_bw": lowpass} if lowpass else {})) for _ in range(S)]
+    for k in range(nch):
+        eng.process_host(np.ascontiguousarray(iq[:, k * C:(k + 1) * C]), C)
+        for s in range(S):
+            orcs[s](iq[s, k * C:(k + 1) * C], fs)
+            assert same_bits(eng.demodulated(s), orcs[s].array("last_demod")), (k, s)
+            assert np.array_equal(eng.bits(s), orcs[s].bits()), (k, s)
+    for s in range(S):
+        assert eng.take_chars(s) == orcs[s].text("chars_log"), s
+        assert eng.take_sentences(s) == orcs[s].sentences(), s
+    assert len(orcs[0].sentences()) >= 1
+
+
 def test_short_chunk_history_quirk_and_rejects(hd):
     """Q4: a chunk so short that the in-place history overlaps the outputs still matches; a chunk shorter than the
     history is undefined in the reference and is rejected."""
