@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // carve: [lmask: ring_cap/64 u64][flips, runinfo: fl_cap u32 each][win: span + R + 16 floats][wl: span + R floats];
-    // the run-sum strips (4 waves x kRunStrip floats) reuse win/wl, which are dead by then
+    // the run-sum strips (4 waves x 4 groups x kRunStrip / 2 floats) reuse win/wl, which are dead by then
     unsigned long long* lmask = reinterpret_cast<unsigned long long*>(smem);
     __shared__ unsigned long long words[kAvgSpan / 64 + 1];
     __shared__ uint32_t s_nfl, s_overflow, s_frontier;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     uint32_t* flips = reinterpret_cast<uint32_t*>(lmask + ring_cap / 64);
     uint32_t* runinfo = flips + fl_cap;                      // (count << 1) | bit
     float* win = reinterpret_cast<float*>(runinfo + fl_cap);
-    float* strips = win;                                    // phase C only; (kAvgSpan + R) * 2 floats >= 4 * kRunStrip
+    float* strips = win;                                    // phase C only; (kAvgSpan + R) * 2 floats >= 8 * kRunStrip (four waves x four groups x half a strip)
     const float* v = tail + (size_t)s * ring_cap;
     unsigned long long* gmask = flipmask + (size_t)s * (ring_cap / 64);
     float* gw = weight + (size_t)s * ring_cap;
