@@ -16,8 +16,8 @@
 //     adding its R samples left-to-right from LDS exactly like std::accumulate, so the floats are bit-identical),
 //     and cached as one "signs differ" bit (ballot -> 64-bit mask words) plus one weight per position;
 //   * the inherently sequential edge search runs on those mask words with one wave per stream (k_sym_scan: 4096
-//     positions per step through ballots and find-first-set); per-run sums are accumulated in element order with
-//     the wave loading 256 samples at a time and v_readlane feeding a wave-uniform accumulator; lane 0 packs bits.
+//     positions per step through ballots and find-first-set); per-run sums are accumulated in element order, four runs
+//     to a wave (16-lane groups, each adding its own run from its own LDS strip through broadcast reads); lane 0 packs bits.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <cstdlib>
