@@ -55,6 +55,7 @@ if str(ROOT) not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
 HBM_COPY_GBS = 6290.0          # measured float4 copy on gfx950 (same table)
 VALU_NONFMA_TFLOPS = 78.6      # FP32 vector peak with separately rounded multiply and add (157.3 TF with FMA)
+VALU_FMA_TFLOPS = 157.3        # ... with fused multiply-add: what the fast mode's FIR chain is priced against
 
 WORKLOADS = {
     # name: fs, decimation, baud, bits, stops, streams/GPU, chunk, lowpass_bw, lowpass_trans, ungated, carrier offsets
@@ -97,7 +98,7 @@ def job_time(dist, dt: float, device=None) -> float:
     if dist is None:
         return dt
     import torch
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    t = torch.tensor([dt], dtype=torch.float64)          # a host tensor: the process group is gloo (no RCCL on a collective-free data path)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -214,6 +215,79 @@ def oracle_sample_check(w, eng, ring, chunks, C, streams, lookup_mode=1, group=6
             "check_seconds": round(time.perf_counter() - t0, 1)}
 
 
+def normwise(a, b):
+    """max|a - b| / max|b| (how 'within 1e-5 relative' is evaluated for a buffer of floats); inf when the shapes differ."""
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        return float("inf")
+    if a.size == 0:
+        return 0.0
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-30))
+
+
+def fir_normwise(a, b, fir_input):
+    """The norm-wise difference of a FIR's OUTPUT, relative to the larger of the output's and the input's peak: a filter that rejects what it is fed (a
+    carrier outside the low-pass: every 8th stream of the headline workload) leaves an output far below its input, and the rounding of ANY float
+    summation -- the reference's own included -- scales with the terms that cancel (sum |x[t] k[t]|), not with what is left of them.  The low-pass has
+    unit gain at DC (FirFilter.h:198-208), so the input's peak is that scale."""
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        return float("inf")
+    if a.size == 0:
+        return 0.0
+    scale = max(float(np.max(np.abs(b))), float(np.max(np.abs(fir_input))) if np.size(fir_input) else 0.0, 1e-30)
+    return float(np.max(np.abs(a - b)) / scale)
+
+
+def demod_excess(gd, od, filt_ref, prev_ref, tol=1e-5, scale=None):
+    """The discriminator output of the fast mode against the oracle's: d[i] = arg(y[i] conj(y[i-1])) is the exact mode's code on inputs that differ by
+    <= tol * max|y|, so its output may differ by the propagated bound (|dy[i]| / |y[i]| + |dy[i-1]| / |y[i-1]| radians, angles compared modulo 2 pi) --
+    1e-5 of pi where the filtered samples are strong, more where y passes near zero (element-wise 1e-5 cannot hold at zero
+    crossings).  Returns (largest |difference| / allowed, largest |difference| in radians)."""
+    gd, od = np.asarray(gd, np.float64), np.asarray(od, np.float64)
+    if gd.shape != od.shape:
+        return float("inf"), float("inf")
+    if od.size == 0:
+        return 0.0, 0.0
+    y = np.abs(np.asarray(filt_ref).astype(np.complex128))
+    yp = np.concatenate([[abs(complex(prev_ref)) if prev_ref is not None else y[0]], y[:-1]])
+    peak = max(float(y.max()), float(scale or 0.0), 1e-30)        # (scale: the peak of the low-pass's input, see fir_normwise)
+    d = np.abs(np.angle(np.exp(1j * (gd - od))))
+    allowed = np.maximum(tol * math.pi, 1.5 * tol * peak * (1.0 / np.maximum(y, 1e-30) + 1.0 / np.maximum(yp, 1e-30)))
+    return float(np.max(d / allowed)), float(np.max(d))
+
+
+def float_parity_probe(w, ring, ring_chunks, S, C, device_index, steps=6, streams=None):
+    """Fast mode only: a short synchronous pass of its own (the first `steps` slabs of the ring, keep_filtered) whose decimated, filtered and discriminator
+    floats are compared with the oracle's call by call on a few streams -- norm-wise, the way north_star's 1e-5 is evaluated."""
+    import habdec_amd
+    from oracle import pyoracle
+    streams = sorted({0, min(7, S - 1), S // 2, S - 1}) if streams is None else list(streams)
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"],
+                            lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"], device=device_index, pipeline=0, keep_filtered=True, arith=1)
+    orcs = {s: pyoracle.Decoder("oracle", factor=w["D"], baud=w["baud"], bits=w["bits"], stops=w["stops"], lowpass_bw=w["lp_bw"], lowpass_trans=w["lp_trans"],
+                                ungated=w["ungated"]) for s in streams}
+    worst = {"decimated": 0.0, "filtered": 0.0, "demod_over_bound": 0.0, "demod_max_abs_rad": 0.0}
+    prev = {s: None for s in streams}
+    n = 0
+    for k in range(min(steps, ring_chunks)):
+        eng.process_device(ring[k].data_ptr(), C, C)
+        for s, o in orcs.items():
+            o(ring[k, s].cpu().numpy().view(np.complex64).reshape(-1), w["fs"])
+            worst["decimated"] = max(worst["decimated"], normwise(eng.decimated(s), o.array("last_decimated")))
+            fo, do = o.array("last_filtered"), o.array("last_decimated")
+            worst["filtered"] = max(worst["filtered"], fir_normwise(eng.filtered(s), fo, do))
+            ex, ab = demod_excess(eng.demodulated(s), o.array("last_demod"), fo, prev[s], scale=float(np.max(np.abs(do))) if do.size else None)
+            worst["demod_over_bound"] = max(worst["demod_over_bound"], ex); worst["demod_max_abs_rad"] = max(worst["demod_max_abs_rad"], ab)
+            if fo.size:
+                prev[s] = fo[-1]
+            n += int(fo.size)
+    eng.close()
+    return {"normwise_max": {k: float("%.3g" % v) for k, v in worst.items()}, "tolerance": 1e-5, "streams": streams, "calls": min(steps, ring_chunks), "filtered_samples_compared": n,
+            "within_tolerance": bool(worst["decimated"] <= 1e-5 and worst["filtered"] <= 1e-5 and worst["demod_over_bound"] <= 1.0),
+            "how": "per call: max|gpu - oracle| / max|oracle| for the decimated samples; for the filtered samples relative to the larger of their own and the low-pass input's peak (fir_normwise); the discriminator output against the bound those 1e-5 propagate to (demod_excess)"}
+
+
 def box_identity(torch, dev):
     """What this box's GPU delivers right now, so that a kernel time can be attributed (boxes of the pool differ by +-6 %): a 20 ms calibration
     pass -- a 1 GiB device-to-device copy, the access pattern of the guide's 6.29 TB/s float4 copy figure -- and the clock levels the driver
@@ -274,14 +348,14 @@ PATHS = {0: "separate kernels", 1: "fused back end", 2: "stream tail kernel", 3:
 class Shard:
     """One GPU's share of the job: its engine, its HBM-resident ring of push slabs and its step loop (streams are independent: nothing is shared)."""
 
-    def __init__(self, torch, w, S, device_index, rank, sync):
+    def __init__(self, torch, w, S, device_index, rank, sync, arith=0):
         import habdec_amd
         self.torch, self.S, self.C, self.dev = torch, S, w["C"], torch.device("cuda", device_index)
         # (the engine first -- allocations, rocFFT plan, code objects: host-side work during which the GPU idles -- then the synthetic ring, whose
         # generation keeps the GPU busy right up to the warm-up steps)
         self.eng = habdec_amd.Engine(n_streams=S, max_chunk=w["C"], sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"],
                                      rtty_stops=w["stops"], lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"],
-                                     device=device_index, pipeline=0 if sync else int(os.environ.get("HD_BENCH_PIPELINE", "2")))
+                                     device=device_index, pipeline=0 if sync else int(os.environ.get("HD_BENCH_PIPELINE", "2")), arith=arith)
         self.ring, self.ring_chunks, self.texts = generate_ring(torch, self.dev, w, S, rank, seed=1234 + rank)
         # The ring is generated on torch's stream, the engine launches on its own queues: without this wait the warm-up steps run while the last
         # streams' slabs are still being written (rounds 1-3 did -- harmless for the timing, but the self-check then compares the oracle's run over the
@@ -349,10 +423,11 @@ def gpu_sensor_reader(torch, dev):
     return read
 
 
-def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync, cpu_leg, threads=0, prewarm=None):
+def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync, cpu_leg, threads=0, prewarm=None, arith=0):
     """Time K steps of one workload (after W warm-up steps) and describe the result; rank 0 gets the full dictionary.
-    cpu_leg: "full" = the CPU baseline (oracle timed on the host cores) + the self-check; "check" = the self-check alone (a few streams through
-    the oracle, compared with the engine's output: every line carries it); threads = N > 0: one process, a Shard + host thread per device."""
+    cpu_leg: "full" = the CPU baseline (oracle timed on the host cores) + the self-check on every stream; "check" = the self-check alone on a few
+    streams; "check_all" = the self-check alone on every stream of the shard (every line carries one of them); threads = N > 0: one process, a Shard +
+    host thread per device; arith: 0 = the engine's exact mode (bit-identical floats), 1 = its fast mode (fused multiply-add, tolerance 1e-5)."""
     import threading
     import habdec_amd
     w = dict(WORKLOADS[name])
@@ -365,14 +440,14 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
         same = bool(os.environ.get("HD_BENCH_SAME_DEVICE"))        # (tests on a one-GPU box: every shard on device 0 -- the threading is what is exercised)
 
         def make(d):
-            shards[d] = Shard(torch, w, S, 0 if same else d, d, sync)
+            shards[d] = Shard(torch, w, S, 0 if same else d, d, sync, arith)
         th = [threading.Thread(target=make, args=(d,)) for d in range(threads)]
         for t in th: t.start()
         for t in th: t.join()
         if any(x is None for x in shards):
             raise SystemExit("bench.py --threads: a device's engine or ring could not be built")
     else:
-        shards = [Shard(torch, w, S, local_rank, rank, sync)]
+        shards = [Shard(torch, w, S, local_rank, rank, sync, arith)]
     sh = shards[0]
     eng, ring, ring_chunks, texts = sh.eng, sh.ring, sh.ring_chunks, sh.texts
     K = K or ring_chunks
@@ -385,10 +460,11 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     sensors = [gpu_sensor_reader(torch, x.dev) for x in shards]
 
     def barrier():
-        if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+        # (device work first, then the ranks meet on the host -- gloo -- and every device is idle on both sides of the region)
         for x in shards:
             torch.cuda.synchronize(x.dev)
+        if dist is not None:
+            dist.barrier()
 
     def region():
         """W untimed warm-up steps, then EXACTLY K timed steps between barriers; the whole job's time (MAX over ranks / shards)."""
@@ -441,7 +517,7 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
             x.sensors = rd()
     rank_sensors = [x.sensors or {"sclk_mhz": None, "power_w": None} for x in shards]
     if dist is not None:                                # every rank's clock and power, gathered on rank 0 (a 2-float all-gather, outside the timed regions)
-        mine = torch.tensor([rank_sensors[0]["sclk_mhz"] or -1.0, rank_sensors[0]["power_w"] or -1.0], dtype=torch.float64, device=dev)
+        mine = torch.tensor([rank_sensors[0]["sclk_mhz"] or -1.0, rank_sensors[0]["power_w"] or -1.0], dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         rank_sensors = [{"sclk_mhz": (float(a[0]) if float(a[0]) >= 0 else None), "power_w": (float(a[1]) if float(a[1]) >= 0 else None)} for a in allr]
@@ -452,7 +528,14 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     for x in shards[1:]:
         x.eng.close()
         x.ring = None
+    chunks = [i % ring_chunks for i in range(steps_taken)]     # what the engine consumed: both regions, the pre-warm pass, the sampling pass (the self-check follows all of it)
     if rank != 0:
+        # Every rank checks ITS shard against the oracle -- behind rank 0's CPU-baseline timing, which has the host cores to itself
+        # until the barrier -- and rank 0's line carries the verdicts (per_rank[i].gpu_matches_oracle).
+        dist.barrier()
+        mine = oracle_sample_check(w, eng, ring, chunks, C, list(range(S)) if cpu_leg in ("full", "check_all") else sorted({0, min(7, S - 1), S // 2, S - 1}),
+                                   group=max(8, 128 // world))
+        dist.gather_object({k: mine[k] for k in ("gpu_matches_oracle_on_sample", "all_streams_of_the_shard", "bits_in_sample", "sentences_in_sample", "mismatches", "check_seconds")}, None, dst=0)
         eng.close()
         return None
 
@@ -512,8 +595,9 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     }
     res["roofline"].update(rp)
     if valu:
-        res["roofline"] = {"bound": "valu", "kernel": "FIR chain: " + kernel + " + k_fir_demod (exact mode: separately rounded multiply and add)",
-                           "achieved": round(tflops, 2), "peak": VALU_NONFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / VALU_NONFMA_TFLOPS, 4),
+        vpeak = VALU_FMA_TFLOPS if arith else VALU_NONFMA_TFLOPS
+        res["roofline"] = {"bound": "valu", "kernel": "FIR chain: " + kernel + " + k_fir_demod (" + ("fast mode: fused multiply-add" if arith else "exact mode: separately rounded multiply and add") + ")",
+                           "achieved": round(tflops, 2), "peak": vpeak, "unit": "TFLOP/s", "frac": round(tflops / vpeak, 4),
                            "traffic": traffic, "algorithmic_flop_per_sample": round(flops_per_sample(w), 1),
                            "stage1_hbm": {"achieved": round(achieved, 1), "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_front_ms, 5)}}
     if dt * 1e3 < 50.0:
@@ -523,7 +607,7 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
         # pass (outside the timed region, own engine) gives the stage-1 kernel's isolated duration next to the contract figure above.
         eng1 = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"],
                                  rtty_stops=w["stops"], lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"],
-                                 device=local_rank, pipeline=False)
+                                 device=local_rank, pipeline=False, arith=arith)
         eng1.set_timing(1)
         iso = []
         for i in range(4 + 24):
@@ -540,7 +624,6 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
                            "frac_of_measured_copy_peak": round(iso_bw / HBM_COPY_GBS, 4),
                            "note": "stage 1 alone: synchronous calls (nothing else on the GPU), 24 launches after the timed region"}
     res["box"] = box_identity(torch, dev)
-    chunks = [i % ring_chunks for i in range(steps_taken)]     # what the engine consumed: both regions, the pre-warm pass, the sampling pass (the self-check follows all of it)
     chunks_cpu = [i % ring_chunks for i in range(W + K)]       # the CPU baseline's bounded sample of the same workload
     if cpu_leg == "full":
         nproc = os.cpu_count() or 1
@@ -552,11 +635,30 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
         res["cpu_baseline"] = {"value": round(v, 1), "unit": "MS/s", "cores": min(c, physical_cores() or c), "threads": c, "nproc": nproc,
                                "physical_cores": physical_cores(), "kind": "port", "sample": sample,
                                "threads_calibration_MSps": calib}
-        res["cpu_baseline"].update(oracle_sample_check(w, eng, ring, chunks, C, list(range(S))))      # every stream of the shard
-    elif cpu_leg == "check":
+        if dist is not None:
+            dist.barrier()                                     # the other ranks' self-checks start here: the timing above had the host cores to itself
+        res["cpu_baseline"].update(oracle_sample_check(w, eng, ring, chunks, C, list(range(S)), group=max(8, 128 // world) if world > 1 else 64))      # every stream of the shard
+    elif cpu_leg in ("check", "check_all"):
         # no CPU timing asked for: the line still says whether what it timed decodes what the oracle decodes (a far-off-tune stream among them)
         res["cpu_baseline"] = {"value": None, "kind": "port", "note": "self-check only (--no-cpu-baseline / secondary workload): the oracle was not timed"}
-        res["cpu_baseline"].update(oracle_sample_check(w, eng, ring, chunks, C, sorted({0, min(7, S - 1), S // 2, S - 1})))
+        if dist is not None:
+            dist.barrier()
+        res["cpu_baseline"].update(oracle_sample_check(w, eng, ring, chunks, C, list(range(S)) if cpu_leg == "check_all" else sorted({0, min(7, S - 1), S // 2, S - 1}),
+                                                       group=max(8, 128 // world) if world > 1 else 64))
+    if "cpu_baseline" in res:
+        # every rank's verdict on its own shard beside its clock and power (rank 0's is the line's cpu_baseline block)
+        mine = {k: res["cpu_baseline"][k] for k in ("gpu_matches_oracle_on_sample", "all_streams_of_the_shard", "bits_in_sample", "sentences_in_sample", "mismatches", "check_seconds")}
+        allc = [mine]
+        if dist is not None:
+            allc = [None] * world
+            dist.gather_object(mine, allc, dst=0)
+        for i, c in enumerate(allc):
+            if i < len(res["per_rank"]) and c is not None:
+                res["per_rank"][i].update({"gpu_matches_oracle": c["gpu_matches_oracle_on_sample"], "self_check": {k: c[k] for k in c if k != "gpu_matches_oracle_on_sample"}})
+        res["all_ranks_match_oracle"] = all(c is not None and c["gpu_matches_oracle_on_sample"] is True for c in allc)
+    res["arith"] = "fast" if arith else "exact"
+    if arith:
+        res["float_parity"] = float_parity_probe(w, ring, ring_chunks, S, C, local_rank)
     eng.close()
     del ring
     torch.cuda.empty_cache()
@@ -575,6 +677,8 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the secondary line for BASELINE configs[2] (/4)")
     ap.add_argument("--sync", action="store_true", help="deliver each step's text before the next step starts (no pipelining of calls)")
     ap.add_argument("--threads", action="store_true", help="with --gpus N and no torchrun: ONE process, an engine + a host thread per device (no RCCL anywhere)")
+    ap.add_argument("--arith", default="both", choices=["exact", "fast", "both"],
+                    help="arithmetic of the FIR sums: exact (bit-identical floats; what `value` always is), fast (fused multiply-add, tolerance 1e-5), both (default: `value` exact and a `fast` block beside it)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: only the launch plumbing (ranks, gloo barrier, MAX over ranks, rank 0's line) -- CPU tests")
     args = ap.parse_args()
 
@@ -592,6 +696,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not args.threads and "--gpus" not in " ".join(sys.argv[1:]).replace("=", " ").split() and world > 1:
+        args.gpus = world                                 # `torchrun --nproc-per-node N bench.py` without --gpus: the job's size is what was asked for
     if not args.threads and world != max(1, args.gpus):
         raise SystemExit(f"bench.py --gpus {args.gpus} inside a job of {world} rank(s): the line would report another number of GPUs than asked for")
     if args.dry_run:
@@ -630,20 +736,32 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # gloo: the ranks share nothing on the data path (streams are sharded) -- what they exchange is a barrier, the MAX of a host
+        # timer, two floats of sensor readings and each rank's self-check verdict, all host-side.  No RCCL communicator, no HBM or xGMI traffic beside the kernels.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    r = run_workload(torch, dist, dev, rank, local_rank, world, args.workload, args.steps, args.warmup, args.streams, args.sync,
-                     cpu_leg="check" if args.no_cpu_baseline else "full", threads=threads, prewarm=args.prewarm)
+    world_arg = world
+    only_fast = args.arith == "fast"
+    r = run_workload(torch, dist, dev, rank, local_rank, world_arg, args.workload, args.steps, args.warmup, args.streams, args.sync,
+                     cpu_leg="check" if args.no_cpu_baseline else "full", threads=threads, prewarm=args.prewarm, arith=1 if only_fast else 0)
+    # The engine's fast mode (fused multiply-add in every FIR; floats within 1e-5, decisions compared with the oracle's as they are) beside the exact-mode
+    # `value`: the same workload, the same regions, its own engine and ring; every stream of the shard through the self-check.
+    fast = None
+    if args.arith == "both" and not threads:
+        fast = run_workload(torch, dist, dev, rank, local_rank, world_arg, args.workload, args.steps, args.warmup, args.streams, args.sync,
+                            cpu_leg="check" if args.no_cpu_baseline else "check_all", prewarm=args.prewarm, arith=1)
     if threads:
         world = threads
-    also = None
+    also = also_fast = None
     if args.workload == "cfg4" and not args.no_also and world == 1:
         # BASELINE configs[2] ("1024 batched IQ streams @ 2.048 MS/s, dec=2, on 1 MI355X"): the harder, VALU-bound single-GPU
         # configuration, measured beside the headline (its own ring, a short timed region).
-        also = run_workload(torch, dist, dev, rank, local_rank, world, "cfg3", 24, 4, 0, args.sync, cpu_leg="check")
+        also = run_workload(torch, dist, dev, rank, local_rank, world, "cfg3", 24, 4, 0, args.sync, cpu_leg="check", arith=1 if only_fast else 0)
+        if args.arith == "both":
+            also_fast = run_workload(torch, dist, dev, rank, local_rank, world, "cfg3", 24, 4, 0, args.sync, cpu_leg="check", arith=1)
     if rank != 0:
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier()
             dist.destroy_process_group()
         return
     w = r["w"]
@@ -672,9 +790,28 @@ def main():
                         "hbm_frac_end_to_end": also["pipeline"]["hbm_frac_end_to_end"], "launch_path": also["pipeline"]["launch_path"],
                         "gpu_matches_oracle_on_sample": also["cpu_baseline"]["gpu_matches_oracle_on_sample"],
                         "self_check": {k: also["cpu_baseline"][k] for k in ("streams_in_sample", "bits_in_sample", "chars_in_sample", "sentences_in_sample")}}
+    line["arith"] = r["arith"]
+    line["all_ranks_match_oracle"] = r.get("all_ranks_match_oracle")
+
+    def fast_block(f):
+        cb = f["cpu_baseline"]
+        return {"arith": "fast: v_pk_fma_f32 in every FIR of the chain (hd_engine_config.arith = HD_ARITH_FAST); discriminator and symbol extractor as in the exact mode",
+                "value": f["value"], "unit": "MS/s", "ms_per_step": f["ms_per_step"], "steps": f["steps"], "timed_region_ms": f["timed_region_ms"], "cold": f.get("cold"),
+                "roofline": f["roofline"], "hbm_frac_end_to_end": f["pipeline"]["hbm_frac_end_to_end"], "launch_path": f["pipeline"]["launch_path"],
+                "per_rank": f.get("per_rank"),
+                "parity": {"float": f.get("float_parity"), "streams": cb.get("streams_in_sample"), "all_streams_of_the_shard": cb.get("all_streams_of_the_shard"),
+                           "symbols_characters_sentences_equal": cb.get("gpu_matches_oracle_on_sample"), "all_ranks_match_oracle": f.get("all_ranks_match_oracle"),
+                           "bits": cb.get("bits_in_sample"), "chars": cb.get("chars_in_sample"), "sentences": cb.get("sentences_in_sample"), "steps_checked": cb.get("steps_checked"),
+                           "mismatches": cb.get("mismatches")}}
+    if fast:
+        line["fast"] = fast_block(fast)
+        line["fast"]["speedup_over_exact"] = round(fast["value"] / r["value"], 4) if r["value"] else None
+    if also_fast and "also" in line:
+        line["also"]["fast"] = fast_block(also_fast)
+        line["also"]["fast"]["speedup_over_exact"] = round(also_fast["value"] / also["value"], 4) if also["value"] else None
     print(json.dumps(line), flush=True)
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier()
         dist.destroy_process_group()
 
 

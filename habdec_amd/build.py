@@ -18,6 +18,9 @@ CSRC = HERE / "csrc"
 OUT = HERE / "libhabdec_amd.so"
 FAULT_OUT = HERE / "libhabdec_amd_fault.so"
 SOURCES = ["engine.cpp", "host_api.cpp", "kernels/decimate.hip", "kernels/fir_demod.hip", "kernels/backend.hip", "kernels/spectrum.hip", "kernels/spectrum_wave.hip", "kernels/symbols.hip", "kernels/tail.hip"]
+# the translation units that carry a FIR of the chain are compiled once per arithmetic mode (kernels/arith.h): as they are -> namespace hd::exact
+# (separately rounded multiply and add), with -DHD_FAST_ARITH -> namespace hd::fast (fused multiply-add); hd_engine_config.arith picks at run time
+MODE_SOURCES = ["kernels/decimate.hip", "kernels/fir_demod.hip", "kernels/backend.hip", "kernels/tail.hip", "kernels/symbols.hip"]
 ARCH = "gfx950"
 
 
@@ -63,12 +66,14 @@ def build(force: bool = False, verbose: bool = False, variant: str | None = None
               "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", *extra,
               "-Wall", "-Wno-unused-function", "-I", str(HERE.parent / "include"), "-I", str(CSRC)]
     procs = []
-    for src in SOURCES:
-        obj = build_dir / (src.replace("/", "_") + ".o")
-        cmd = common + ["-x", "hip", "-c", str(CSRC / src), "-o", str(obj)]
+    units = [(src, "", []) for src in SOURCES] + [(src, ".fast", ["-DHD_FAST_ARITH"]) for src in MODE_SOURCES]
+    units.sort(key=lambda u: 0 if "decimate" in u[0] else 1)      # the long compiles first
+    for src, tag, defs in units:
+        obj = build_dir / (src.replace("/", "_") + tag + ".o")
+        cmd = common + defs + ["-x", "hip", "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        procs.append((src + tag, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(str(obj))
     bad = False
     for src, p in procs:

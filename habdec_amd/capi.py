@@ -18,7 +18,7 @@ class hd_engine_config(C.Structure):
     _fields_ = [("device", C.c_int32), ("n_streams", C.c_uint32), ("max_chunk", C.c_uint32), ("sampling_rate", C.c_double),
                 ("decimation", C.c_uint32), ("baud", C.c_double), ("rtty_bits", C.c_uint32), ("rtty_stops", C.c_float),
                 ("lowpass_bw_hz", C.c_float), ("lowpass_trans", C.c_float), ("dc_remove", C.c_int32), ("lookup_mode", C.c_int32),
-                ("enable_spectrum", C.c_int32), ("ungated", C.c_int32), ("keep_filtered", C.c_int32), ("pipeline", C.c_int32)]
+                ("enable_spectrum", C.c_int32), ("ungated", C.c_int32), ("keep_filtered", C.c_int32), ("pipeline", C.c_int32), ("arith", C.c_int32)]
 
 
 class hd_afc_info(C.Structure):

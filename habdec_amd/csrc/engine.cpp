@@ -32,6 +32,9 @@
 #include "host/text_stage.hpp"
 #include "kernels/launch.h"
 
+// A launcher (or layout helper) of the kernels that exist once per arithmetic mode (kernels/arith.h): hd::exact::fn or hd::fast::fn by the engine's mode.
+#define HDK(fn, ...) (e->fast ? hd::fast::fn(__VA_ARGS__) : hd::exact::fn(__VA_ARGS__))
+
 namespace {
 
 thread_local std::string g_err;
@@ -117,6 +120,7 @@ struct hd_engine {
     uint32_t tail_cap = 0, backlog_cap = 0, slot_words = 0, flips_cap = 0, max_R = 0, min_R = 4;
     int bins_sep = 8;
     bool decode_enabled = true;
+    bool fast = false;         // hd_engine_config.arith == HD_ARITH_FAST: the hd::fast kernels (fused multiply-add in every FIR; tolerance 1e-5, not bit-identical floats)
     bool one_stream = false;
     bool no_fuse = false;      // HD_NO_FUSE: never use the fused back end (kernels/backend.hip); A/B measurements
     bool no_tail = false;      // HD_NO_TAIL: never use the one-wave stream tail (kernels/tail_body.h); A/B measurements
@@ -269,7 +273,7 @@ void hd_engine_config_default(hd_engine_config* c)
     std::memset(c, 0, sizeof(*c));
     c->device = 0; c->n_streams = 1; c->max_chunk = 65536; c->sampling_rate = 2.048e6; c->decimation = 64;
     c->baud = 300; c->rtty_bits = 8; c->rtty_stops = 2; c->lowpass_bw_hz = 1500; c->lowpass_trans = 0.025f;
-    c->dc_remove = 0; c->lookup_mode = 1; c->enable_spectrum = 1; c->ungated = 0; c->keep_filtered = 0; c->pipeline = 0;
+    c->dc_remove = 0; c->lookup_mode = 1; c->enable_spectrum = 1; c->ungated = 0; c->keep_filtered = 0; c->pipeline = 0; c->arith = HD_ARITH_EXACT;
 }
 
 int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
@@ -279,8 +283,10 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     if (cfg->n_streams < 1) return fail(HD_ERR_INVALID, "n_streams must be >= 1");
     if (!(cfg->sampling_rate > 0)) return fail(HD_ERR_INVALID, "sampling_rate must be > 0");
     if (cfg->max_chunk < 1) return fail(HD_ERR_INVALID, "max_chunk must be >= 1");
+    if (cfg->arith != HD_ARITH_EXACT && cfg->arith != HD_ARITH_FAST) return fail(HD_ERR_INVALID, "arith must be HD_ARITH_EXACT (0) or HD_ARITH_FAST (1)");
     std::unique_ptr<hd_engine> e(new hd_engine);
     e->cfg = *cfg;
+    e->fast = cfg->arith == HD_ARITH_FAST;
     if (!hd::decim_plan(cfg->decimation, e->stages))
         return fail(HD_ERR_INVALID, "Unsupported decimation factor: " + std::to_string(cfg->decimation));   // Decoder.h:317-319
     e->S = cfg->n_streams;
@@ -391,7 +397,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         // the clearing of step_ctr could land on top of the probe's answer -- seen in one test run of three as a silent fall-back to
         // fixed shares)
         HD_HIP(hipDeviceSynchronize());
-        const uint32_t seen = hd::probe_xcc_mask(e->qa, e->n_cus, e->step_ctr.p + 2 * 16 * 32);
+        const uint32_t seen = HDK(probe_xcc_mask, e->qa, e->n_cus, e->step_ctr.p + 2 * 16 * 32);
         if (n_xcd > 16 || seen != (n_xcd >= 32 ? 0xFFFFFFFFu : (1u << n_xcd) - 1u)) e->no_claim = true;
     } else
         e->no_claim = true;
@@ -462,26 +468,26 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         hd_engine::CallSlot& sl = e->slot[0];
         hipStream_t q = e->qa;
         const uint32_t T1 = e->stages.size() > 0 ? (uint32_t)e->stages[0].taps.size() : 0, T2 = e->stages.size() > 1 ? (uint32_t)e->stages[1].taps.size() : 0;
-        if (e->stages.empty()) hd::launch_passthrough(q, S, 1, e->staging.p, cfg->max_chunk, e->fbuf[0].p, e->fbuf_stride, sl.d_call.p, e->fir_hist_cap);
+        if (e->stages.empty()) HDK(launch_passthrough, q, S, 1, e->staging.p, cfg->max_chunk, e->fbuf[0].p, e->fbuf_stride, sl.d_call.p, e->fir_hist_cap);
         if (e->stages.size() >= 1)
-            hd::launch_decimate(q, e->stages[0].ratio, T1, S, 1, e->staging.p, cfg->max_chunk, e->hist1[0].p, e->hist1[1].p, e->stage_taps[0].p,
+            HDK(launch_decimate, q, e->stages[0].ratio, T1, S, 1, e->staging.p, cfg->max_chunk, e->hist1[0].p, e->hist1[1].p, e->stage_taps[0].p,
                                 e->stages.size() == 1 ? e->fbuf[0].p : e->dec1.p, e->stages.size() == 1 ? e->fbuf_stride : e->n1_cap, sl.d_call.p, 0,
                                 e->stages.size() == 1, e->fir_hist_cap, nullptr);
         if (e->stages.size() == 2)
-            hd::launch_decimate(q, e->stages[1].ratio, T2, S, 1, e->dec1.p, e->n1_cap, e->hist2[0].p, e->hist2[1].p, e->stage_taps[1].p, e->fbuf[0].p,
+            HDK(launch_decimate, q, e->stages[1].ratio, T2, S, 1, e->dec1.p, e->n1_cap, e->hist2[0].p, e->hist2[1].p, e->stage_taps[1].p, e->fbuf[0].p,
                                 e->fbuf_stride, sl.d_call.p, 1, 1, e->fir_hist_cap, nullptr);
-        hd::launch_dc_remove(q, S, e->fbuf[0].p, e->fbuf_stride, sl.d_call.p, e->fir_hist_cap);
+        HDK(launch_dc_remove, q, S, e->fbuf[0].p, e->fbuf_stride, sl.d_call.p, e->fir_hist_cap);
         if (cfg->enable_spectrum) {
-            hd::launch_fft_feed(q, S, e->fbuf[0].p, e->fbuf_stride, e->fft_in.p, sl.d_call.p, e->fir_hist_cap);
+            HDK(launch_fft_feed, q, S, e->fbuf[0].p, e->fbuf_stride, e->fft_in.p, sl.d_call.p, e->fir_hist_cap);
             void* in[1] = {e->fft_in.p};
             void* outb[1] = {e->fft_raw.p};
             if (rocfft_execute(e->fft_plan, in, outb, e->fft_info) != rocfft_status_success) return fail(HD_ERR_DEVICE, "rocfft_execute failed");
             hd::launch_spectrum_commit(q, S, e->fft_raw.p, e->spec.p, e->power.p, sl.h_stats.dev, sl.d_call.p, e->fsd, e->bins_sep);
         }
-        hd::launch_fir_demod(q, S, 0, 0, e->fbuf[0].p, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S, nullptr, e->carry[0].p,
+        HDK(launch_fir_demod, q, S, 0, 0, e->fbuf[0].p, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S, nullptr, e->carry[0].p,
                              e->carry[1].p, sl.d_call.p, e->fir_hist_cap, e->tail.p, e->tail_cap, e->d_symstate.p, e->fbuf[1].p,
                              e->fir_head.p, e->fir_head_n.p, e->fir_head.p + (size_t)S * e->head_cap, e->fir_head_n.p + S, e->head_cap);
-        hd::launch_symbols(q, S, 1, 1, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p, sl.d_call.p,
+        HDK(launch_symbols, q, S, 1, 1, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p, sl.d_call.p,
                            sl.h_slots.dev, e->slot_words, nullptr, 0, e->min_R, 0u);
         HD_HIP(hipStreamSynchronize(q));
         HD_HIP(hipGetLastError());        // a kernel this shape cannot launch (LDS, grid) fails the creation, not every later call
@@ -640,10 +646,10 @@ int run_pending_tail(hd_engine* e)
     hd::TailArgs lay = ta;
     if (lanes != 64) {      // the pending arguments carry the 64-lane carve of the step launch; a 256-lane kernel needs its own
         // (same buffers, other LDS offsets)
-        if (!hd::tail_layout(lay, lanes, e->pend.r2, e->pend.t2, e->pend_max_taps, e->max_R, e->min_R, e->tail_cap, e->pend.ta.pend_max, 64 * 1024)) return fail(HD_ERR_INVALID, "stream tail layout");
+        if (!HDK(tail_layout, lay, lanes, e->pend.r2, e->pend.t2, e->pend_max_taps, e->max_R, e->min_R, e->tail_cap, e->pend.ta.pend_max, 64 * 1024)) return fail(HD_ERR_INVALID, "stream tail layout");
     }
     const bool own_spectrum = !ta.fft_tw && e->cfg.enable_spectrum && e->pend.any_fft;       // a transform launch follows the tails: the event goes behind that one
-    if (!hd::launch_tail(e->qa, lanes, e->pend.r2, e->pend.t2, e->S, lay, own_spectrum ? nullptr : ps.ev_done)) return fail(HD_ERR_INVALID, "stream tail refused a shape it was selected for");
+    if (!HDK(launch_tail, e->qa, lanes, e->pend.r2, e->pend.t2, e->S, lay, own_spectrum ? nullptr : ps.ev_done)) return fail(HD_ERR_INVALID, "stream tail refused a shape it was selected for");
     if (own_spectrum) { if (!ta.fft_tw) { if (const int r = run_spectrum(e, e->qa, ps, e->pend.any_fft)) return r; } HD_HIP(hipEventRecord(ps.ev_done, e->qa)); }
     HD_HIP(hipGetLastError());
     return HD_OK;
@@ -871,16 +877,16 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     // ~2048 of them (e.g. /16 with 65536-sample pushes: 4096) the many-workgroup kernels finish a batch sooner (measured: 156 vs 173 GS/s).
     // (a handful of streams, long calls: the 256-lane tail in pieces of 1024 outputs where its windows fit -- one piece for a 65536-sample push at /64 --, of 256 otherwise)
     const bool tail = nst == 2 && !any_dc && !e->no_tail && max_n2 <= e->tail_max_n2 &&
-                      ((tail_lanes == 256 && max_n2 >= 512u && hd::tail_layout(ta, tail_lanes, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, 64 * 1024, 4)) ||
-                       hd::tail_layout(ta, tail_lanes, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, 64 * 1024));
+                      ((tail_lanes == 256 && max_n2 >= 512u && HDK(tail_layout, ta, tail_lanes, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, 64 * 1024, 4)) ||
+                       HDK(tail_layout, ta, tail_lanes, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, 64 * 1024));
     const bool fuse = tail || (nst == 2 && !any_dc && !e->no_fuse && ((R2 == 2 && T2 == 69) || (R2 == 4 && T2 == 139)) &&
-                      hd::backend_lds_bytes((int)T2, max_n1, max_n2, max_taps) <= 64 * 1024);
+                      HDK(backend_lds_bytes, (int)T2, max_n1, max_n2, max_taps) <= 64 * 1024);
     // Step mode: batch decoding of equally sized pushes through a single-wave first stage -- ONE launch per call, on one queue: this
     // call's stage 1 with the previous call's stream tails in front (kernels/decimate.hip k_step).
     hd::TailArgs ta_step{};
     const bool step = tail && e->cfg.pipeline && !e->one_stream && min_in == max_in && max_in && (R1 == 32 || R1 == 64) &&
-                      hd::step_lds_bytes((int)R1, (int)T1) &&
-                      hd::tail_layout(ta_step, 64, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, hd::step_lds_bytes((int)R1, (int)T1));
+                      HDK(step_lds_bytes, (int)R1, (int)T1) &&
+                      HDK(tail_layout, ta_step, 64, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, HDK(step_lds_bytes, (int)R1, (int)T1));
     const int path = step ? 3 : tail ? 2 : fuse ? 1 : 0;
     if (e->last_fuse >= 0 && e->last_fuse != path) {   // path switch: drain (a pending tail first)
         if (const int r = run_pending_tail(e)) return r;
@@ -911,7 +917,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         if (e->sym_dirty && e->calls > e->delivered) { if (int rc = flush_locked(e)) return rc; }   // symbol parameters are uploaded below: nothing may still read them
     } else if (!host_params) {
         // the parameter block is pulled on its own queue, so it does not wait for the previous call's stage 1 to drain
-        hd::launch_fetch_params(e->qc, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
+        HDK(launch_fetch_params, e->qc, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
         if (!e->one_stream) { HD_HIP(hipEventRecord(sl.ev_params, e->qc)); HD_HIP(hipStreamWaitEvent(qa, sl.ev_params, 0)); }
     }
     for (uint32_t s = 0; s < S; ++s) {
@@ -963,9 +969,9 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
                           uint32_t run_len_cu = 0 /* != 0: runs for a per-CU ring kernel's loaders */) {
         hd::StepClaim claim{};
         // (tiles: 64 outputs of a single-wave /32 or /64 first stage; for the per-CU ring kernels hd::ring_tiles -- 64 rows of 32 samples advancing by 57 or 58 at /32, 2048 input samples at the smaller ratios)
-        const uint32_t ntiles = run_len_cu ? hd::ring_tiles((int)R1, (int)T1, max_in) : (max_n1 + 63) / 64, n_xcd = e->n_cus / 32u, run_len = run_len_cu ? run_len_cu : e->step_run >= 2 ? e->step_run : 4u;   // (a run must hold the tile in front of which the next draw is issued: at least two; four re-read fewer halos than two)
+        const uint32_t ntiles = run_len_cu ? HDK(ring_tiles, (int)R1, (int)T1, max_in) : (max_n1 + 63) / 64, n_xcd = e->n_cus / 32u, run_len = run_len_cu ? run_len_cu : e->step_run >= 2 ? e->step_run : 4u;   // (a run must hold the tile in front of which the next draw is issued: at least two; four re-read fewer halos than two)
         const uint64_t runs = (uint64_t)S * ntiles / run_len;
-        const bool shape_ok = run_len_cu ? (hd::stage1_cu_supported((int)R1, (int)T1) && max_in % 2048u == 0) : ((R1 == 32 || R1 == 64) && max_n1 % 64 == 0);
+        const bool shape_ok = run_len_cu ? (HDK(stage1_cu_supported, (int)R1, (int)T1) && max_in % 2048u == 0) : ((R1 == 32 || R1 == 64) && max_n1 % 64 == 0);
         if (!e->no_claim && (nst == 2 || (run_len_cu && nst == 1)) && shape_ok && min_in == max_in && max_in && !any_zero1 && n_xcd && e->n_cus % 32u == 0 && n_xcd <= 16 &&
             ntiles && (ntiles % run_len == 0 || (run_len_cu && R1 >= 32 && ((uint64_t)S * ntiles) % run_len == 0)) && runs % n_xcd == 0 && (uint64_t)S * ntiles < (1ull << 32) && (uint64_t)ntiles * S >= 4ull * lin_wgs) {   // (the two counter sets alternate: a launch that takes one must really run that way)
             claim.ctr = e->step_ctr.p + (size_t)(e->step_launches & 1u) * 16 * 32;
@@ -996,11 +1002,11 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         // Where the per-CU step kernel can serve the plan and the sizes, this call's tails are laid out for ITS slice of LDS -- a quarter of what four
         // worker slots leave of the CU's 160 KB (23 KB: larger caches for the search phase than the 20 KB slot of the single-wave fallback) -- now; the
         // launch that runs them decides.
-        const bool cu_shape = !e->no_cu_step && !e->no_claim && !any_zero1 && max_in % 2048u == 0 && hd::step_cu_supported((int)R1, (int)T1, (int)R2, (int)T2);
-        const uint32_t cu_tail = cu_shape ? hd::step_cu_tail_lds((int)R1, (int)T1) : 0u;
+        const bool cu_shape = !e->no_cu_step && !e->no_claim && !any_zero1 && max_in % 2048u == 0 && HDK(step_cu_supported, (int)R1, (int)T1, (int)R2, (int)T2);
+        const uint32_t cu_tail = cu_shape ? HDK(step_cu_tail_lds, (int)R1, (int)T1) : 0u;
         if (cu_tail) {
             hd::TailArgs tacu{};
-            if (hd::tail_layout(tacu, 64, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, cu_tail)) ta_step = tacu;
+            if (HDK(tail_layout, tacu, 64, (int)R2, (int)T2, max_taps, e->max_R, e->min_R, e->tail_cap, max_pend, cu_tail)) ta_step = tacu;
         }
         fill_tail(ta_step);
         hd_engine::PendingTail prev = e->pend;
@@ -1011,7 +1017,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         bool ev_on_dispatch = false;
         uint32_t wgs = 32u * e->n_cus;                          // short runs of tiles: the dispatcher evens out the tail of the launch
         // One workgroup per CU (four stage-1 worker waves, the tails in the other four) where the plan and the sizes allow it
-        const uint32_t ring_run = pick_ring_run(hd::ring_tiles((int)R1, (int)T1, max_in));
+        const uint32_t ring_run = pick_ring_run(HDK(ring_tiles, (int)R1, (int)T1, max_in));
         const int cu_exp0 = e->cu_exp;             // timing experiments only (results wrong): 1 = no tails, 2 = no stage 1
         const bool want_cu = cu_tail && ((cu_exp0 & 1) || (ta_step.lds_bytes <= cu_tail && (!prev.valid || prev.ta.lds_bytes <= cu_tail)));
         const hd::StepClaim claim = make_claim(0, want_cu ? ring_run : 0u);
@@ -1024,7 +1030,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             if (cu_exp0 & 2) cl.runs_per_xcd = 0;
             ev_on_dispatch = ext_events && (!ps || prev.ta.fft_tw || !prev.any_fft);
             if (sl.timed && !ev_on_dispatch) HD_HIP(hipEventRecord(sl.t1, qa));
-            launched = hd::launch_step_cu(qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, e->n_cus, iq, stride,
+            launched = HDK(launch_step_cu, qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, e->n_cus, iq, stride,
                                           e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, prev.ta,
                                           (prev.valid && !(cu_exp0 & 1)) ? S : 0u, max_in, cl, tb,
                                           ev_on_dispatch && sl.timed ? sl.t1 : nullptr, !ev_on_dispatch ? nullptr : sl.timed ? sl.t2 : ps ? ps->ev_done : nullptr);
@@ -1038,7 +1044,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
                 --e->step_launches; fb = hd::StepClaim{};
                 wgs = 32u * e->n_cus;
             }
-            if (!hd::launch_step(qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, max_n1, iq, stride, e->hist1[hin].p,
+            if (!HDK(launch_step, qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, max_n1, iq, stride, e->hist1[hin].p,
                                  e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, wgs, prev.ta, prev.valid ? S : 0u,
                                  any_zero1 ? 0u : max_in, fb))
                 return fail(HD_ERR_INVALID, "no step kernel for this decimation plan");
@@ -1071,7 +1077,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     }
     if (nst == 0) {
         if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
-        hd::launch_passthrough(qa, S, max_in, iq, stride, fcur, e->fbuf_stride, dcall, e->fir_hist_cap);
+        HDK(launch_passthrough, qa, S, max_in, iq, stride, fcur, e->fbuf_stride, dcall, e->fir_hist_cap);
         if (sl.timed) HD_HIP(hipEventRecord(sl.t2, qa));
     } else {
         const bool single = nst == 1;
@@ -1083,11 +1089,11 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         const uint32_t lin1 = (min_in == max_in && max_in) ? wgs_cu * e->n_cus : 0u;
         // A /32 first stage over equally sized pushes: one workgroup per CU, LDS-DMA loader waves + computing waves (k_stage1_cu, stage1_ring.h)
         bool s1_cu = false;
-        if ((single ? R1 == 4 : R1 != 4) && min_in == max_in && max_in && !e->no_cu_step && !any_zero1 && max_in % 2048u == 0 && hd::stage1_cu_supported((int)R1, (int)T1)) {
-            const hd::StepClaim cl = make_claim(0, pick_ring_run(hd::ring_tiles((int)R1, (int)T1, max_in)));
+        if ((single ? R1 == 4 : R1 != 4) && min_in == max_in && max_in && !e->no_cu_step && !any_zero1 && max_in % 2048u == 0 && HDK(stage1_cu_supported, (int)R1, (int)T1)) {
+            const hd::StepClaim cl = make_claim(0, pick_ring_run(HDK(ring_tiles, (int)R1, (int)T1, max_in)));
             if (cl.ctr) {
                 if (sl.timed) HD_HIP(hipEventRecord(sl.t1, qa));
-                s1_cu = hd::launch_stage1_cu(qa, (int)R1, (int)T1, e->n_cus, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
+                s1_cu = HDK(launch_stage1_cu, qa, (int)R1, (int)T1, e->n_cus, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
                                              max_in, cl, e->ring_gave_up.dev, hd_engine::kS1Loaders, 16u, (e->cfg.pipeline && !fuse && !single) ? hd_engine::kS1Slots : 8u,   // (/4 as the only stage is bound by the vector pipes: eight slots, 0.838 against 0.904 ms per step with four)
                                              single ? (lean ? sl.h_call.dev : dcall) : nullptr, e->fir_hist_cap, single ? feed : nullptr);
                 if (!s1_cu) --e->step_launches;                // (the counter sets alternate per launch that really draws: this one did not)
@@ -1097,31 +1103,31 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         const hd::StepClaim claim1{};                      // (stage 1 alone is HBM-bound: drawing runs there cost 3 % -- more halo re-reads -- where the step launch gains 4 %: fixed shares)
         if (sl.timed && !s1_cu) HD_HIP(hipEventRecord(sl.t1, qa));
         if (!s1_cu)
-        if (!hd::launch_decimate(qa, R1, T1, S, max_n1, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
+        if (!HDK(launch_decimate, qa, R1, T1, S, max_n1, iq, stride, e->hist1[hin].p, e->hist1[hout].p, e->stage_taps[0].p, out1, out1_stride,
                                  (lean || free_front) ? sl.h_call.dev : dcall, 0, single ? 1 : 0, e->fir_hist_cap, single ? feed : nullptr, lin1,
                                  nullptr, claim1.ctr ? max_in : 0u, claim1))
             return fail(HD_ERR_INVALID, "no kernel for this decimation stage");
         if (sl.timed) HD_HIP(hipEventRecord(sl.t2, qa));
-        if (free_front) hd::launch_fetch_params(qa, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
+        if (free_front) HDK(launch_fetch_params, qa, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
         if (!single && !fuse) {
             // (Round 4 measured the second stage as a ring kernel too -- /2 with sixteen outputs per lane, /4 with eight: bit-identical, and SLOWER in the
             // pipelined step (/16: 0.338-0.342 against 0.326-0.338 ms): a ring kernel takes a CU's whole LDS, and the back half of the previous call
             // can no longer share the CU with it.  The classic grid stays.  NOTES.md.)
-            if (!hd::launch_decimate(qa, R2, T2, S, max_n2, d1, e->n1_cap, e->hist2[hin].p, e->hist2[hout].p, e->stage_taps[1].p, fcur,
+            if (!HDK(launch_decimate, qa, R2, T2, S, max_n2, d1, e->n1_cap, e->hist2[hin].p, e->hist2[hout].p, e->stage_taps[1].p, fcur,
                                      e->fbuf_stride, dcall, 1, 1, e->fir_hist_cap, feed))
                 return fail(HD_ERR_INVALID, "no kernel for this decimation stage");
         }
     }
     auto spectrum = [&](hipStream_t q) -> int {
         if (!(e->cfg.enable_spectrum && max_n2)) return HD_OK;
-        if (!fuse && (any_dc || nst == 0)) hd::launch_fft_feed(q, S, fcur, e->fbuf_stride, e->fft_in.p, dcall, e->fir_hist_cap);
+        if (!fuse && (any_dc || nst == 0)) HDK(launch_fft_feed, q, S, fcur, e->fbuf_stride, e->fft_in.p, dcall, e->fir_hist_cap);
         if (any_fft) {   // only when some stream's 4096-sample buffer completed (every call at >= 4096 decimated samples per push)
             if (const int r = transform_and_commit(e, q, sl.h_stats.dev, dcall)) return r;
         }
         return HD_OK;
     };
     if (!fuse) {
-        if (any_dc) hd::launch_dc_remove(qa, S, fcur, e->fbuf_stride, dcall, e->fir_hist_cap);
+        if (any_dc) HDK(launch_dc_remove, qa, S, fcur, e->fbuf_stride, dcall, e->fir_hist_cap);
         if (const int r = spectrum(qa)) return r;
     }
     if (!e->one_stream) HD_HIP(hipEventRecord(sl.ev_front, qa));
@@ -1132,28 +1138,28 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     bool done_on_dispatch = false;
     const bool ev_ride = !sl.timed && e->one_stream;   // (two queues: the event is not on the step's critical path, and /16 measured no better with it on the dispatch)
     if (tail) {
-        if (lean) hd::launch_fetch_params(qb, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
+        if (lean) HDK(launch_fetch_params, qb, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
         fill_tail(ta);
         // (the call's completion event rides on the tails' dispatch where nothing is launched behind them)
         done_on_dispatch = ev_ride && (ta.fft_tw || !(e->cfg.enable_spectrum && max_n2));
-        if (!hd::launch_tail(qb, tail_lanes, (int)R2, (int)T2, S, ta, done_on_dispatch ? sl.ev_done : nullptr)) return fail(HD_ERR_INVALID, "stream tail refused a shape it was selected for");
+        if (!HDK(launch_tail, qb, tail_lanes, (int)R2, (int)T2, S, ta, done_on_dispatch ? sl.ev_done : nullptr)) return fail(HD_ERR_INVALID, "stream tail refused a shape it was selected for");
         if (!ta.fft_tw) { if (const int r = spectrum(qb)) return r; }
     } else if (fuse) {
-        if (lean) hd::launch_fetch_params(qb, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
-        if (!hd::launch_backend(qb, (int)R2, (int)T2, S, max_n1, max_n2, max_taps, d1, e->n1_cap, e->hist2[hin].p, e->hist2[hout].p,
+        if (lean) HDK(launch_fetch_params, qb, sl.h_call.dev, sl.d_call.p, S * sizeof(hd::StreamCall));
+        if (!HDK(launch_backend, qb, (int)R2, (int)T2, S, max_n1, max_n2, max_taps, d1, e->n1_cap, e->hist2[hin].p, e->hist2[hout].p,
                                 e->stage_taps[1].p, fcur, fcur, fnext, e->fbuf_stride, e->fir_hist_cap, e->lp_taps.p, e->taps_cap, e->demod.p,
                                 e->demod.n / S, e->cfg.keep_filtered ? e->filtered.p : nullptr, e->carry[cin].p, e->carry[cout].p, dcall, feed,
                                 e->tail.p, e->tail_cap, e->d_symstate.p, e->fir_head.p, e->fir_head_n.p, e->head_cap, (uint32_t)cin))
             return fail(HD_ERR_INVALID, "fused back end refused a shape it was selected for");
         if (const int r = spectrum(qb)) return r;
     } else {
-        hd::launch_fir_demod(qb, S, max_m, max_taps, fcur, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S,
+        HDK(launch_fir_demod, qb, S, max_m, max_taps, fcur, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S,
                              e->cfg.keep_filtered ? e->filtered.p : nullptr, e->carry[cin].p, e->carry[cout].p, dcall, e->fir_hist_cap,
                              e->tail.p, e->tail_cap, e->d_symstate.p, fnext, e->fir_head.p + (size_t)cin * S * e->head_cap, e->fir_head_n.p + (size_t)cin * S,
                              e->fir_head.p + (size_t)cout * S * e->head_cap, e->fir_head_n.p + (size_t)cout * S, e->head_cap);
     }
     if (!tail)
-    hd::launch_symbols(qb, S, max_m, max_new, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p,
+    HDK(launch_symbols, qb, S, max_m, max_new, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p,
                        dcall, sl.h_slots.dev, e->slot_words, e->flips_cap ? e->flips_dbg.p : nullptr, e->flips_cap, e->min_R, sl.seq, ev_ride ? sl.ev_done : nullptr);
     if (!tail && ev_ride) done_on_dispatch = true;
     if (sl.timed) HD_HIP(hipEventRecord(sl.t3, qb));

@@ -19,10 +19,12 @@
 // take more VALU/LDS time from stage 1 than their head start returns).
 #include <hip/hip_runtime.h>
 
+#include "arith.h"
 #include "exact_math.h"
 #include "launch.h"
 
 namespace hd {
+namespace HD_ARITH_NS {
 
 constexpr int kBeLanes = 256;
 constexpr int kBePass = 2 * kBeLanes;            // low-pass outputs per pass: two adjacent outputs per lane
@@ -36,7 +38,7 @@ constexpr int kBePass = 2 * kBeLanes;            // low-pass outputs per pass: t
 #ifdef HD_STAMP_BE   // diagnostic build only (tools/micro/be_stamps.py): s_memtime at the phase boundaries, per stream
 __device__ unsigned long long g_be_stamps[8192 * 8];
 #define BSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_be_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-extern "C" void hd_debug_be_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_be_stamps), n * 8); }
+extern "C" void HD_DBG_NAME(hd_debug_be_stamps)(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_be_stamps), n * 8); }
 #else
 #define BSTAMP(i) do { } while (0)
 #endif
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__
     // Taps are consumed eight at a time in a rolled loop: only eight of them are live in scalar registers.
     float2* y2 = fin + f_old;
     for (uint32_t o = tid; o < n2; o += 2 * kBeLanes) {     // two outputs (o, o + 256) share each block of taps
+        HD_FIR_ARITH
         const bool has_b = o + kBeLanes < n2;
         const float4* p4 = reinterpret_cast<const float4*>(xin + (size_t)o * D2);
         const float4* q4 = has_b ? reinterpret_cast<const float4*>(xin + (size_t)(o + kBeLanes) * D2) : p4;
@@ -236,6 +239,7 @@ __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__
         const bool active = 2u * tid < live;
         float a0r = 0.f, a0i = 0.f, a1r = 0.f, a1i = 0.f;
         if (active) {
+            HD_FIR_ARITH
             const float4* p = reinterpret_cast<const float4*>(fin + i0) + tid;    // pair k: samples i0 + 2l + 2k, +1
             uint32_t t = 0;
             float4 P = p[0];
@@ -343,4 +347,5 @@ bool launch_backend(hipStream_t st, int ratio2, int ntaps2, uint32_t n_streams, 
     return false;
 }
 
+}  // namespace HD_ARITH_NS
 }  // namespace hd

@@ -31,13 +31,14 @@
 #define HD_DEC_MAXW 4     // most waves per SIMD the 256-lane stages are compiled for (their registers and LDS decide what they get: 3-4)
 
 namespace hd {
+namespace HD_ARITH_NS {
 
 #ifdef HD_STAMP_DEC   // diagnostic build only (tools/micro/dec_stamps.py): phase clocks of the D = HD_STAMP_DEC_D (default 32) kernel, per workgroup
 #ifndef HD_STAMP_DEC_D
 #define HD_STAMP_DEC_D 32
 #endif
 __device__ unsigned long long g_dec_stamps[4096 * 8];
-extern "C" void hd_debug_dec_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dec_stamps), n * 8); }
+extern "C" void HD_DBG_NAME(hd_debug_dec_stamps)(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dec_stamps), n * 8); }
 #define DSTAMP_DECL unsigned long long ds_t = __builtin_amdgcn_s_memtime(), ds_acc[4] = {0, 0, 0, 0}; const unsigned long long ds_r0 = __builtin_amdgcn_s_memrealtime(); unsigned long long ds_r1 = 0
 #define DSTAMP(i) do { if (D == HD_STAMP_DEC_D) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ds_acc[i] += t_ - ds_t; ds_t = t_; } } while (0)
 #define DSTAMP_ARRIVED() do { if (D == HD_STAMP_DEC_D) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DSTAMP(0); if (!ds_r1) ds_r1 = __builtin_amdgcn_s_memrealtime(); } } while (0)
@@ -66,7 +67,7 @@ constexpr int dec_tile_f4()                        // float4 slots of a workgrou
 }
 
 #ifdef HD_STAMP_TAIL  // diagnostic build only: the phase clocks of the tails that ran inside step launches (this translation unit's copy)
-extern "C" void hd_debug_step_tail_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tail_stamps), n * 8); }
+extern "C" void HD_DBG_NAME(hd_debug_step_tail_stamps)(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tail_stamps), n * 8); }
 #endif
 
 // The stage body.  (bx, by, gdx) are the workgroup's coordinates in the stage's own grid -- blockIdx / gridDim when the stage is a
@@ -314,6 +315,7 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
                 }
             };
             auto mac_part = [&](const f32x4 (&x)[8], const f32x2 (&k)[8], auto j0, auto j1) {    // a chunk only part of whose slots carry taps
+                HD_FIR_ARITH
 #pragma unroll
                 for (int j = decltype(j0)::value; j < decltype(j1)::value; ++j) {
                     const f32x2 smp = (j & 1) ? x[j >> 1].zw : x[j >> 1].xy;
@@ -347,7 +349,7 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
         } else
         if constexpr (OPL == 1) {
             float ar = 0.f, ai = 0.f;
-            auto mac = [&](float xr, float xi, float k) { ar = ar + xr * k; ai = ai + xi * k; };
+            auto mac = [&](float xr, float xi, float k) { HD_FIR_ARITH ar = ar + xr * k; ai = ai + xi * k; };
             constexpr int B = D >= 32 ? 32 : 16;               // slots per block; pad inside a block is compile-time
             constexpr int NS = T + JS;                          // slots [JS, NS) carry taps [0, T)
             constexpr int NFULL = NS / B;                       // full blocks; block 0 is peeled when JS (slot 0 unused)
@@ -400,6 +402,7 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
             constexpr int B_LO = (JS + (OPL - 1) * D + B - 1) / B;      // first block in which every output takes every slot
             constexpr int B_HI = (T + JS) / B - 1;                      // last such block
             auto edge_block = [&](auto bc) {                            // head / tail blocks: per (slot, output) compile-time guards
+                HD_FIR_ARITH
                 constexpr int j0 = decltype(bc)::value * B;
 #pragma unroll
                 for (int k = 0; k < B; k += 2) {
@@ -425,6 +428,7 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
             if constexpr (B_LO <= B_HI) {
 #pragma unroll 1
                 for (int b = B_LO; b <= B_HI; ++b) {                    // interior: rolled, ~B + (OPL-1)*D taps live in scalar registers
+                    HD_FIR_ARITH
                     const int j0 = b * B;
                     const float2* pb = p + j0 + 2 * (j0 / RD);
                     const float* tb = taps + (j0 - JS);
@@ -869,4 +873,5 @@ void launch_dc_remove(hipStream_t st, uint32_t n_streams, float2* fbuf, size_t s
     hipLaunchKernelGGL(k_dc_remove, dim3(n_streams), dim3(64), 0, st, fbuf, stride, call, fir_hist_cap);
 }
 
+}  // namespace HD_ARITH_NS
 }  // namespace hd

@@ -17,14 +17,16 @@
 // wave-uniform (scalar loads).
 #include <hip/hip_runtime.h>
 
+#include "arith.h"
 #include "exact_math.h"
 #include "launch.h"
 
 namespace hd {
+namespace HD_ARITH_NS {
 
 #ifdef HD_STAMP_FIR   // diagnostic build only (tools/micro/fir_stamps.py): per-workgroup clocks of k_fir_demod
 __device__ unsigned long long g_fir_stamps[8192 * 8];
-extern "C" void hd_debug_fir_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fir_stamps), n * 8); }
+extern "C" void HD_DBG_NAME(hd_debug_fir_stamps)(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fir_stamps), n * 8); }
 #define FSTAMP_DECL unsigned long long fs_t = __builtin_amdgcn_s_memtime(), fs_acc[4] = {0, 0, 0, 0}; const unsigned long long fs_r0 = __builtin_amdgcn_s_memrealtime()
 #define FSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); fs_acc[i] += t_ - fs_t; fs_t = t_; } while (0)
 #define FSTAMP_WRITE() do { const uint32_t w_ = blockIdx.y * gridDim.x + blockIdx.x; if (threadIdx.x == 64 && w_ < 8192) { unsigned long long* g_ = g_fir_stamps + w_ * 8; \
@@ -54,6 +56,7 @@ typedef float fd_f32x4 __attribute__((ext_vector_type(4)));
 // order with separately rounded multiply and add, and one wave keeps issuing back to back (a single chain waits out the add on every tap).
 __device__ __forceinline__ void fir_block16(fd_f32x2 (&acc)[kFirOut], const fd_f32x4 (&w)[kFirWin], const float (&k)[16])
 {
+    HD_FIR_ARITH
     auto smp = [&](int i) -> fd_f32x2 { return (i & 1) ? w[i >> 1].zw : w[i >> 1].xy; };
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
         }
         if (b < nblk) fir_block16(acc, w, k);                       // an odd count: the last block sits in the first image
         for (uint32_t t = nblk * 16u; t < T; ++t) {                 // the taps behind the last whole block, one at a time
+            HD_FIR_ARITH
             const float kt = tp[t];
             const float2* x = lds + (uint32_t)kFirOut * threadIdx.x + t;
             fd_f32x2 pr[kFirOut];
@@ -283,4 +287,5 @@ void launch_fft_feed(hipStream_t st, uint32_t n_streams, const float2* fbuf, siz
     hipLaunchKernelGGL(k_fft_feed, grid, dim3(256), 0, st, fbuf, stride, fft_in, call, fir_hist_cap);
 }
 
+}  // namespace HD_ARITH_NS
 }  // namespace hd

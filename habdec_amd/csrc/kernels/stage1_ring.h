@@ -40,9 +40,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "arith.h"
 #include "launch.h"
 
 namespace hd {
+namespace HD_ARITH_NS {
 
 typedef float r_f32x2 __attribute__((ext_vector_type(2)));
 typedef float r_f32x4 __attribute__((ext_vector_type(4)));
@@ -66,7 +68,7 @@ __host__ __device__ constexpr uint32_t ring_sys_tiles(uint32_t n, uint32_t adv) 
 
 #ifdef HD_STAMP_RING   // diagnostic build only (tools/micro/ring_stamps.py): where the loader and the consumers of k_step_cu spend their cycles
 __device__ unsigned long long g_ring_stamps[512 * 8 * 8];
-extern "C" void hd_debug_ring_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ring_stamps), n * 8); }
+extern "C" void HD_DBG_NAME(hd_debug_ring_stamps)(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ring_stamps), n * 8); }
 #define RSTAMP_DECL unsigned long long rs_t = __builtin_amdgcn_s_memtime(), rs_acc[6] = {0, 0, 0, 0, 0, 0}; const unsigned long long rs_r0 = __builtin_amdgcn_s_memrealtime()
 #define RSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); rs_acc[i] += t_ - rs_t; rs_t = t_; } while (0)
 #define RSTAMP_WRITE(wave_, n_) do { if ((threadIdx.x & 63u) == 0 && blockIdx.x < 512 && (wave_) < 8u) { unsigned long long* g_ = g_ring_stamps + ((size_t)blockIdx.x * 8 + (wave_)) * 8; \
@@ -82,8 +84,8 @@ __device__ unsigned int g_ring_fault_fired, g_ring_fault_mode;
 // (one fault per arming.  Mode 0: a loader never publishes its second tile and stops -- the computing waves' waits run out.  Mode 1: the feeding wave
 // stops handing out runs after its second -- the loaders' waits run out.)
 static void ring_fault_arm(unsigned int mode) { const unsigned int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ring_fault_mode), &mode, sizeof mode); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ring_fault_fired), &z, sizeof z); }
-extern "C" void hd_debug_ring_fault_arm() { ring_fault_arm(0u); }
-extern "C" void hd_debug_ring_fault_arm_starve() { ring_fault_arm(1u); }
+extern "C" void HD_DBG_NAME(hd_debug_ring_fault_arm)() { ring_fault_arm(0u); }
+extern "C" void HD_DBG_NAME(hd_debug_ring_fault_arm_starve)() { ring_fault_arm(1u); }
 #endif
 
 constexpr uint32_t kSlotFree = 0u, kSlotReady = 1u, kSlotTaken = 2u;     // state (high word) of a tile slot's word
@@ -362,8 +364,22 @@ __device__ __forceinline__ void ring_loader(const RingArgs& a, const RingGeom& g
 // independent ones).  Here the products run three taps ahead of the adds through four rotating temporaries, so an independent multiply sits
 // between consecutive adds.  Same instructions, same order of the adds, separately rounded multiply and add: bit-identical results.
 // Taps arrive as eight aligned scalar pairs; op_sel picks the pair's low or high word for both halves of the packed multiply.
+// (Fast mode: sixteen v_pk_fma_f32 into ONE accumulator -- the single-wave kernels' form; the worker waves split the chain in two, ring_fma16x2.)
 __device__ __forceinline__ void ring_mac16_asm(r_f32x2& acc, const r_f32x4 (&x)[8], const r_f32x2 (&kp)[8])
 {
+#ifdef HD_FAST_ARITH
+#define HD_FMA_E(xi, ki) "v_pk_fma_f32 %0, %" #xi ", %" #ki ", %0 op_sel_hi:[1,0,1]\n\t"
+#define HD_FMA_O(xi, ki) "v_pk_fma_f32 %0, %" #xi ", %" #ki ", %0 op_sel:[0,1,0]\n\t"
+    asm volatile(
+        HD_FMA_E(1, 17) HD_FMA_O(2, 17) HD_FMA_E(3, 18) HD_FMA_O(4, 18) HD_FMA_E(5, 19) HD_FMA_O(6, 19) HD_FMA_E(7, 20) HD_FMA_O(8, 20)
+        HD_FMA_E(9, 21) HD_FMA_O(10, 21) HD_FMA_E(11, 22) HD_FMA_O(12, 22) HD_FMA_E(13, 23) HD_FMA_O(14, 23) HD_FMA_E(15, 24) "v_pk_fma_f32 %0, %16, %24, %0 op_sel:[0,1,0]"
+        : "+v"(acc)
+        : "v"(x[0].xy), "v"(x[0].zw), "v"(x[1].xy), "v"(x[1].zw), "v"(x[2].xy), "v"(x[2].zw), "v"(x[3].xy), "v"(x[3].zw),
+          "v"(x[4].xy), "v"(x[4].zw), "v"(x[5].xy), "v"(x[5].zw), "v"(x[6].xy), "v"(x[6].zw), "v"(x[7].xy), "v"(x[7].zw),
+          "s"(kp[0]), "s"(kp[1]), "s"(kp[2]), "s"(kp[3]), "s"(kp[4]), "s"(kp[5]), "s"(kp[6]), "s"(kp[7]));
+#undef HD_FMA_E
+#undef HD_FMA_O
+#else
     r_f32x2 t0, t1, t2, t3;
 #define HD_MUL_E(t, xi, ki) "v_pk_mul_f32 %" #t ", %" #xi ", %" #ki " op_sel_hi:[1,0]\n\t"
 #define HD_MUL_O(t, xi, ki) "v_pk_mul_f32 %" #t ", %" #xi ", %" #ki " op_sel:[0,1]\n\t"
@@ -392,7 +408,26 @@ __device__ __forceinline__ void ring_mac16_asm(r_f32x2& acc, const r_f32x4 (&x)[
 #undef HD_MUL_E
 #undef HD_MUL_O
 #undef HD_ADD
+#endif
 }
+#ifdef HD_FAST_ARITH
+// Fast mode, worker waves: the sixteen taps of a chunk as two chains of eight -- even slots into `a`, odd slots into `b` (added once, when the sum leaves
+// the wave) -- so that consecutive v_pk_fma_f32 never depend on each other: a lone wave on its SIMD issues them back to back.
+__device__ __forceinline__ void ring_fma16x2(r_f32x2& a, r_f32x2& b, const r_f32x4 (&x)[8], const r_f32x2 (&kp)[8])
+{
+#define HD_FMA_A(xi, ki) "v_pk_fma_f32 %0, %" #xi ", %" #ki ", %0 op_sel_hi:[1,0,1]\n\t"
+#define HD_FMA_B(xi, ki) "v_pk_fma_f32 %1, %" #xi ", %" #ki ", %1 op_sel:[0,1,0]\n\t"
+    asm volatile(
+        HD_FMA_A(2, 18) HD_FMA_B(3, 18) HD_FMA_A(4, 19) HD_FMA_B(5, 19) HD_FMA_A(6, 20) HD_FMA_B(7, 20) HD_FMA_A(8, 21) HD_FMA_B(9, 21)
+        HD_FMA_A(10, 22) HD_FMA_B(11, 22) HD_FMA_A(12, 23) HD_FMA_B(13, 23) HD_FMA_A(14, 24) HD_FMA_B(15, 24) HD_FMA_A(16, 25) "v_pk_fma_f32 %1, %17, %25, %1 op_sel:[0,1,0]"
+        : "+v"(a), "+v"(b)
+        : "v"(x[0].xy), "v"(x[0].zw), "v"(x[1].xy), "v"(x[1].zw), "v"(x[2].xy), "v"(x[2].zw), "v"(x[3].xy), "v"(x[3].zw),
+          "v"(x[4].xy), "v"(x[4].zw), "v"(x[5].xy), "v"(x[5].zw), "v"(x[6].xy), "v"(x[6].zw), "v"(x[7].xy), "v"(x[7].zw),
+          "s"(kp[0]), "s"(kp[1]), "s"(kp[2]), "s"(kp[3]), "s"(kp[4]), "s"(kp[5]), "s"(kp[6]), "s"(kp[7]));
+#undef HD_FMA_A
+#undef HD_FMA_B
+}
+#endif
 
 // One input sample for EIGHT adjacent outputs (the /4 stage: output q takes this sample with tap t0 - 4 q): eight products, then eight adds, as ONE
 // statement -- every sum still receives its products in ascending tap order, separately rounded.  (As separate statements the compiler's block
@@ -401,6 +436,19 @@ template <bool ODD>
 __device__ __forceinline__ void ring_slot8(r_f32x2 (&acc)[8], const r_f32x2 smp, const r_f32x2 k0, const r_f32x2 k1, const r_f32x2 k2, const r_f32x2 k3,
                                            const r_f32x2 k4, const r_f32x2 k5, const r_f32x2 k6, const r_f32x2 k7)
 {
+#ifdef HD_FAST_ARITH
+#define HD_S8_FMA(a, k) "v_pk_fma_f32 %" #a ", %8, %" #k ", %" #a " op_sel_hi:[1,0,1]\n\t"
+#define HD_S8_FMAO(a, k) "v_pk_fma_f32 %" #a ", %8, %" #k ", %" #a " op_sel:[0,1,0]\n\t"
+#define HD_S8F_OPS : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])                      \
+                   : "v"(smp), "s"(k0), "s"(k1), "s"(k2), "s"(k3), "s"(k4), "s"(k5), "s"(k6), "s"(k7)
+    if constexpr (ODD)
+        asm volatile(HD_S8_FMAO(0, 9) HD_S8_FMAO(1, 10) HD_S8_FMAO(2, 11) HD_S8_FMAO(3, 12) HD_S8_FMAO(4, 13) HD_S8_FMAO(5, 14) HD_S8_FMAO(6, 15) "v_pk_fma_f32 %7, %8, %16, %7 op_sel:[0,1,0]" HD_S8F_OPS);
+    else
+        asm volatile(HD_S8_FMA(0, 9) HD_S8_FMA(1, 10) HD_S8_FMA(2, 11) HD_S8_FMA(3, 12) HD_S8_FMA(4, 13) HD_S8_FMA(5, 14) HD_S8_FMA(6, 15) "v_pk_fma_f32 %7, %8, %16, %7 op_sel_hi:[1,0,1]" HD_S8F_OPS);
+#undef HD_S8_FMA
+#undef HD_S8_FMAO
+#undef HD_S8F_OPS
+#else
     r_f32x2 t0, t1, t2, t3, t4, t5, t6, t7;
 #define HD_S8_MUL(t, k) "v_pk_mul_f32 %" #t ", %16, %" #k " op_sel_hi:[1,0]\n\t"
 #define HD_S8_MULO(t, k) "v_pk_mul_f32 %" #t ", %16, %" #k " op_sel:[0,1]\n\t"
@@ -417,14 +465,20 @@ __device__ __forceinline__ void ring_slot8(r_f32x2 (&acc)[8], const r_f32x2 smp,
 #undef HD_S8_MULO
 #undef HD_S8_ADDS
 #undef HD_S8_OPS
+#endif
 }
 // ... and for ONE output (the slots at either end of a lane's window, which not every output covers)
 template <bool ODD>
 __device__ __forceinline__ void ring_slot1(r_f32x2& acc, const r_f32x2 smp, const r_f32x2 k)
 {
+#ifdef HD_FAST_ARITH
+    if constexpr (ODD) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "v"(smp), "s"(k));
+    else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(smp), "s"(k));
+#else
     r_f32x2 t;
     if constexpr (ODD) asm volatile("v_pk_mul_f32 %1, %2, %3 op_sel:[0,1]\n\tv_pk_add_f32 %0, %0, %1" : "+v"(acc), "=&v"(t) : "v"(smp), "s"(k));
     else asm volatile("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[1,0]\n\tv_pk_add_f32 %0, %0, %1" : "+v"(acc), "=&v"(t) : "v"(smp), "s"(k));
+#endif
 }
 
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a compile-time constant inside the body
@@ -569,6 +623,7 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, const RingGeom&
             constexpr int c = C0 + decltype(ci)::value;
             const r_f32x4 (&x)[8] = xw[(c - C0) & 1];
             if constexpr (kResident) {
+                HD_FIR_ARITH
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const int slot_j = 16 * c + j;
@@ -821,10 +876,25 @@ __device__ __forceinline__ void ring_worker(const RingArgs& a, unsigned char* __
 
         const uint32_t origin = ct * ADV < rows - ADV ? ct * ADV : rows - ADV;
         r_f32x2 acc = {0.f, 0.f};
+#ifdef HD_FAST_ARITH
+        r_f32x2 acc_b = {0.f, 0.f};                     // fast mode: the odd slots' chain (ring_fma16x2); it travels with `acc` and joins it at the end
+#endif
         // chunk c of the slot sequence = chunk c % (D / 16) of the row of step c / (D / 16): all sixteen taps (the hand-scheduled form), or the few that exist
         auto mac_chunk = [&](const r_f32x2 (&k)[8], auto cc) {
             constexpr int c = decltype(cc)::value, j0 = JS > 16 * c ? JS - 16 * c : 0, j1 = NS < 16 * c + 16 ? NS - 16 * c : 16;
             const r_f32x4 (&xh)[8] = reinterpret_cast<const r_f32x4 (&)[8]>(x[8 * (c % (D / 16))]);
+#ifdef HD_FAST_ARITH
+            if constexpr (j0 == 0 && j1 == 16) ring_fma16x2(acc, acc_b, xh, k);
+            else {
+#pragma unroll
+                for (int j = j0; j < j1; ++j) {
+                    const r_f32x2 smp = (j & 1) ? xh[j >> 1].zw : xh[j >> 1].xy;
+                    const float kj = (j & 1) ? k[j >> 1].y : k[j >> 1].x;
+                    if (j & 1) acc_b = __builtin_elementwise_fma(smp, (r_f32x2){kj, kj}, acc_b);
+                    else acc = __builtin_elementwise_fma(smp, (r_f32x2){kj, kj}, acc);
+                }
+            }
+#else
             if constexpr (j0 == 0 && j1 == 16) ring_mac16_asm(acc, xh, k);
             else {
 #pragma unroll
@@ -833,12 +903,19 @@ __device__ __forceinline__ void ring_worker(const RingArgs& a, unsigned char* __
                     acc = acc + smp * ((j & 1) ? k[j >> 1].y : k[j >> 1].x);
                 }
             }
+#endif
         };
-        auto rot = [&]() {                              // lane l takes lane l - 1's sum (wave_ror:1)
+        auto rot1 = [&](r_f32x2& v) {                   // lane l takes lane l - 1's sum (wave_ror:1)
             // (through scalars: __builtin_bit_cast of an ext-vector ELEMENT reads the vector's first element whichever was named -- clang 20)
-            const float re = acc.x, im = acc.y;
-            acc.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, re), 0x13C, 0xF, 0xF, false));
-            acc.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, im), 0x13C, 0xF, 0xF, false));
+            const float re = v.x, im = v.y;
+            v.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, re), 0x13C, 0xF, 0xF, false));
+            v.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, im), 0x13C, 0xF, 0xF, false));
+        };
+        auto rot = [&]() {
+            rot1(acc);
+#ifdef HD_FAST_ARITH
+            rot1(acc_b);
+#endif
         };
         // A unit's taps (32 slots) are requested a unit ahead through the scalar cache.  Scalar loads return out of order, so waiting for any of them waits for
         // all that are outstanding: the wait for unit u's taps (forced by `arrived`) therefore sits IN FRONT of the request for unit u + 1's, which then has
@@ -859,6 +936,9 @@ __device__ __forceinline__ void ring_worker(const RingArgs& a, unsigned char* __
             if constexpr (32 * u + 16 < NS && JS < 32 * u + 32) mac_chunk(kk[u & 1][1], std::integral_constant<int, 2 * u + 1>{});
             if constexpr ((u + 1) % UPS == 0 && u + 1 < NU) rot();
         }, std::make_integer_sequence<int, NU>{});
+#ifdef HD_FAST_ARITH
+        acc = acc + acc_b;
+#endif
 #ifdef HD_STAMP_RING
         asm volatile("" : "+v"(acc));
         ++n_done;
@@ -883,4 +963,5 @@ __device__ __forceinline__ void ring_worker(const RingArgs& a, unsigned char* __
     RSTAMP_WRITE(role, n_done);
 }
 
+}  // namespace HD_ARITH_NS
 }  // namespace hd

@@ -187,6 +187,51 @@ __device__ __forceinline__ unsigned int sign_flags(const float (&wl)[KP], const 
     return nvalid >= (uint32_t)KP ? bits : bits & ((1u << nvalid) - 1u);
 }
 
+// FAST arithmetic mode (arith.h) only.  The same KP window sums, cheaper: acc[0] = w[0] + ... + w[R-1] as four interleaved partial sums (two packed chains
+// over the 16-byte reads, joined at the end), then each neighbour from its predecessor: acc[j] = acc[j-1] + (w[j-1+R] - w[j-1]) -- R / 2 + 2 (KP - 1) adds
+// per lane where the exact-order form needs (R + KP - 1) KP / 2 packed ones (R = 427 at /4 and 300 baud: a seventh).  Not std::accumulate's order, so not its
+// rounding: a sum of R terms carries R roundings either way, the slide adds two per step over at most KP - 1 steps from an exactly summed anchor, and the
+// difference stays at the level of the sums' own rounding noise (<= 1e-6 of the largest window sum; tests/test_gpu_fast.py compares every decision the
+// sums feed -- flags, flip points, bits, characters -- with the reference's on every stream).  `w` is 16-byte aligned and readable up to w[R + KP + 7].
+template <int KP>
+__device__ __forceinline__ void window_sums_slide(const float* __restrict__ w, uint32_t R, float (&acc)[KP])
+{
+    static_assert(KP % 4 == 0 && KP >= 4, "whole 16-byte chunks per lane");
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    float head[KP];                                         // w[0 .. KP): what the slide subtracts
+#pragma unroll
+    for (int c = 0; c < KP / 4; ++c) { const float4 x = w4[c]; head[4 * c] = x.x; head[4 * c + 1] = x.y; head[4 * c + 2] = x.z; head[4 * c + 3] = x.w; }
+    f32x2 a = {0.0f, 0.0f}, b = {0.0f, 0.0f};
+    uint32_t e = 0;
+    if (R >= 16u) {
+        float4 xa = w4[0], xb = w4[1], ya, yb;              // two images of eight elements taking turns, one ahead
+        for (; e + 24 <= R; e += 16) {
+            ya = w4[(e >> 2) + 2]; yb = w4[(e >> 2) + 3];
+            __builtin_amdgcn_sched_barrier(0);
+            a = a + (f32x2){xa.x, xa.y}; b = b + (f32x2){xa.z, xa.w}; a = a + (f32x2){xb.x, xb.y}; b = b + (f32x2){xb.z, xb.w};
+            xa = w4[(e >> 2) + 4]; xb = w4[(e >> 2) + 5];
+            __builtin_amdgcn_sched_barrier(0);
+            a = a + (f32x2){ya.x, ya.y}; b = b + (f32x2){ya.z, ya.w}; a = a + (f32x2){yb.x, yb.y}; b = b + (f32x2){yb.z, yb.w};
+        }
+        // xa, xb hold elements [e, e + 8), all inside the window (e + 8 <= R here: the loop leaves 8 <= R - e < 24)
+        a = a + (f32x2){xa.x, xa.y}; b = b + (f32x2){xa.z, xa.w}; a = a + (f32x2){xb.x, xb.y}; b = b + (f32x2){xb.z, xb.w};
+        e += 8;
+        if (e + 8 <= R) {
+            const float4 za = w4[e >> 2], zb = w4[(e >> 2) + 1];
+            a = a + (f32x2){za.x, za.y}; b = b + (f32x2){za.z, za.w}; a = a + (f32x2){zb.x, zb.y}; b = b + (f32x2){zb.z, zb.w};
+            e += 8;
+        }
+    }
+    float sum = (a.x + a.y) + (b.x + b.y);
+    for (; e < R; ++e) sum = sum + w[e];                    // the R % 8 elements left (the whole window when R < 16)
+    acc[0] = sum;
+    float tail[KP - 1];
+#pragma unroll
+    for (int d = 0; d < KP - 1; ++d) tail[d] = w[R + d];
+#pragma unroll
+    for (int j = 1; j < KP; ++j) { sum = sum + (tail[j - 1] - head[j - 1]); acc[j] = sum; }
+}
+
 constexpr int kWidePos = 8;
 __device__ __forceinline__ void window_sums8(const float* __restrict__ w, uint32_t R, float (&acc)[kWidePos]) { window_sums_wide<kWidePos>(w, R, acc); }
 

@@ -22,15 +22,17 @@
 #include <hip/hip_ext.h>
 #include <cstdlib>
 
+#include "arith.h"
 #include "launch.h"
 #include "sym_common.h"
 
 namespace hd {
+namespace HD_ARITH_NS {
 
 #ifdef HD_STAMP   // diagnostic build only: s_memtime at the phase boundaries of k_symbols, per stream
 __device__ unsigned long long g_sym_stamps[8192 * 8];
 #define STAMP(i) do { if (threadIdx.x == 0 && s < 8192) g_sym_stamps[s * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-extern "C" void hd_debug_sym_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sym_stamps), n * 8); }
+extern "C" void HD_DBG_NAME(hd_debug_sym_stamps)(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sym_stamps), n * 8); }
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -175,7 +177,9 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
         const bool any = (int32_t)(pend - p0) > 0;
         float wp[kAvgPos];
         if (any) {
-            if constexpr (kAvgPos >= 8) window_sums_wide<kAvgPos>(win + tid * kAvgPos, R, wp); else window_sums(win + tid * kAvgPos, R, wp);
+            // (fast mode: an exactly summed anchor per lane and its neighbours by sliding -- a seventh of the adds at R = 427; sym_common.h)
+            if constexpr (kFastArith && kFastWindows) window_sums_slide<kAvgPos>(win + tid * kAvgPos, R, wp);
+            else if constexpr (kAvgPos >= 8) window_sums_wide<kAvgPos>(win + tid * kAvgPos, R, wp); else window_sums(win + tid * kAvgPos, R, wp);
 #pragma unroll
             for (int j = 0; j < kAvgPos; ++j) {
                 wl[R + tid * kAvgPos + j] = wp[j];
@@ -438,4 +442,5 @@ void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t
                             slot_words, flips_dbg, flips_cap, fl_cap, seq);
 }
 
+}  // namespace HD_ARITH_NS
 }  // namespace hd

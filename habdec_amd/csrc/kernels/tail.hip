@@ -6,6 +6,7 @@
 #include "tail_body.h"
 
 namespace hd {
+namespace HD_ARITH_NS {
 
 template <int NT, int OP, int D2, int T2>
 __global__ __launch_bounds__(NT) void k_tail(const TailArgs a)
@@ -15,7 +16,7 @@ __global__ __launch_bounds__(NT) void k_tail(const TailArgs a)
 }
 
 #ifdef HD_RING_FAULT   // the tails of THIS translation unit (k_tail: synchronous delivery, the drain at hd_flush)
-extern "C" void hd_debug_tail_fault_arm_no_tag()
+extern "C" void HD_DBG_NAME(hd_debug_tail_fault_arm_no_tag)()
 {
     const unsigned int one = 1, zero = 0;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tail_fault_armed), &one, sizeof one);
@@ -23,7 +24,7 @@ extern "C" void hd_debug_tail_fault_arm_no_tag()
 }
 #endif
 #ifdef HD_STAMP_TAIL
-extern "C" void hd_debug_tail_stamps(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tail_stamps), n * 8); }
+extern "C" void HD_DBG_NAME(hd_debug_tail_stamps)(unsigned long long* host, size_t n) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tail_stamps), n * 8); }
 #endif
 
 // Stage-2 outputs per lane and piece: four for the one-wave tail; the 256-lane tail (a handful of streams) takes one -- pieces of 256 outputs, every wave busy
@@ -96,4 +97,5 @@ bool launch_tail(hipStream_t st, int lanes, int ratio2, int ntaps2, uint32_t n_s
     return false;
 }
 
+}  // namespace HD_ARITH_NS
 }  // namespace hd

@@ -20,12 +20,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "arith.h"
 #include "exact_math.h"
 #include "launch.h"
 #include "sym_common.h"
 #include "spectrum_wave.h"
 
 namespace hd {
+namespace HD_ARITH_NS {
 
 constexpr uint32_t kTailHdrBytes = 64;          // small shared scalars at the base of the workgroup's LDS scratch
 constexpr uint32_t kTailStrip = 512;            // samples per run-sum step (per wave)
@@ -42,6 +44,7 @@ __device__ __forceinline__ cfloat_ptr as_const(const float* p) { return (cfloat_
 // ONE wave issue back to back (a single chain waits out the add latency on every tap).
 #define HD_TB_TAP4(A_, B_, C_, D_, k_)                                                        \
     {                                                                                         \
+        HD_FIR_ARITH                                                                          \
         const f32x2 p0_ = (A_) * (k_), p1_ = (B_) * (k_), p2_ = (C_) * (k_), p3_ = (D_) * (k_); \
         a0 = a0 + p0_; a1 = a1 + p1_; a2 = a2 + p2_; a3 = a3 + p3_;                           \
     }
@@ -62,6 +65,7 @@ __device__ unsigned long long g_tail_stamps[8192 * 24];
 
 #define HD_TB_TAPN(A_, B_, C_, D_, k_, a0_, a1_, a2_, a3_)                                    \
     {                                                                                         \
+        HD_FIR_ARITH                                                                          \
         const f32x2 p0_ = (A_) * (k_), p1_ = (B_) * (k_), p2_ = (C_) * (k_), p3_ = (D_) * (k_); \
         a0_ = a0_ + p0_; a1_ = a1_ + p1_; a2_ = a2_ + p2_; a3_ = a3_ + p3_;                   \
     }
@@ -76,6 +80,7 @@ __device__ unsigned long long g_tail_stamps[8192 * 24];
 template <int U, int OP, int D2, int NWIN>
 __device__ __forceinline__ void tb_s2_tap(f32x2 (&acc)[OP], const f32x4 (&win)[NWIN], const float k)
 {
+    HD_FIR_ARITH
     f32x2 pr[OP];
 #pragma unroll
     for (int q = 0; q < OP; ++q) {
@@ -328,7 +333,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
             const bool any = KP * tid < cnt;
             float wp[KP];
             if (any) {
-                window_sums8(V + off + KP * tid, R, wp);
+                if constexpr (kFastArith && kFastWindows) window_sums_slide<(int)KP>(V + off + KP * tid, R, wp); else window_sums8(V + off + KP * tid, R, wp);
                 TSTAMP(19);
 #pragma unroll
                 for (int j = 0; j < (int)KP; ++j) WS[off + R + KP * tid + j] = wp[j];
@@ -995,4 +1000,5 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     TSTAMP_WRITE();
 }
 
+}  // namespace HD_ARITH_NS
 }  // namespace hd

@@ -27,6 +27,7 @@ class EngineConfig:
     ungated: bool = False
     keep_filtered: bool = False
     pipeline: int = 0        # 0 synchronous, 1 batch mode (results one call later), 2 batch mode with one more call in flight
+    arith: int = 0           # 0 exact (separately rounded multiply and add: bit-identical floats), 1 fast (fused multiply-add, tolerance 1e-5)
     device: int = 0
 
 
@@ -42,6 +43,7 @@ class Engine:
             setattr(c, k, getattr(cfg, k))
         c.dc_remove, c.enable_spectrum, c.ungated, c.keep_filtered = int(cfg.dc_remove), int(cfg.enable_spectrum), int(cfg.ungated), int(cfg.keep_filtered)
         c.pipeline = int(cfg.pipeline)
+        c.arith = int(cfg.arith)
         h = C.c_void_p()
         check(L.hd_engine_create(C.byref(c), C.byref(h)))
         self.h, self.L = h, L

@@ -72,7 +72,16 @@ typedef struct hd_engine_config {
      *     sized pushes through the step kernel): text arrives two calls late, and a host thread that is held up for the length of a
      *     launch does not leave the GPU idle.  Elsewhere 2 behaves like 1. */
     int32_t  pipeline;
+    /* Arithmetic of the FIR sums (decimator stages Decimator.h:128-138, low-pass FirFilter.h:155-161).
+     * 0 = HD_ARITH_EXACT (default): separately rounded multiply and add in ascending tap order, one accumulator per output -- every decimated, filtered
+     *     and demodulated float is bit-identical to the reference's CPU arithmetic.
+     * 1 = HD_ARITH_FAST: fused multiply-add (half the vector instructions of every FIR in the chain).  Intermediate floats agree with the exact mode to
+     *     <= 1e-5 of the signal's peak (measured <= 3e-7); the discriminator and the symbol extractor are the exact mode's code, and on every stream of
+     *     the parity suite the decoded characters and sentences are identical to the reference's.  Not bit-identical floats: choose it for throughput. */
+    int32_t  arith;
 } hd_engine_config;
+#define HD_ARITH_EXACT 0
+#define HD_ARITH_FAST 1
 
 /* Fill `cfg` with the reference defaults (dec 64, 300 baud 8N2, low-pass 1500 Hz / 0.025, spectrum on). */
 void hd_engine_config_default(hd_engine_config* cfg);

@@ -13,13 +13,13 @@ ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "habdec_amd" / "csrc"
 
 
-def kernel_table(src: Path, tmp: Path):
+def kernel_table(src: Path, tmp: Path, fast: bool = False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not Path(hipcc).exists():
         pytest.skip("hipcc not available")
     out = tmp / (src.stem + ".s")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
-           "-I", str(ROOT / "include"), "-I", str(CSRC), "-x", "hip", "--cuda-device-only", "-S", str(src), "-o", str(out)]
+           "-I", str(ROOT / "include"), "-I", str(CSRC), *(["-DHD_FAST_ARITH"] if fast else []), "-x", "hip", "--cuda-device-only", "-S", str(src), "-o", str(out)]
     try:
         subprocess.run(cmd, check=True, capture_output=True, timeout=900)
     except subprocess.CalledProcessError as ex:              # a hipcc that cannot target gfx950: nothing to check here
@@ -32,13 +32,20 @@ def kernel_table(src: Path, tmp: Path):
     for blk in re.split(r"\n  - \.agpr_count", meta)[1:]:
         g = lambda k: re.search(r"\.%s:\s+(\S+)" % k, blk).group(1)
         name = subprocess.run(["c++filt", g("name")], capture_output=True, text=True).stdout.strip()
-        name = re.sub(r"\(.*", "", name).replace("void hd::", "").replace("hd::", "").replace(" ", "")
+        name = re.sub(r"\(.*", "", name).replace("void hd::", "").replace("hd::", "").replace("exact::", "").replace("fast::", "").replace(" ", "")
         table[name] = dict(vgpr=int(g("vgpr_count")), spill=int(g("vgpr_spill_count")), scratch=int(g("private_segment_fixed_size")))
     return table
 
 
-def test_step_and_stage1_kernels_do_not_spill(tmp_path):
-    t = kernel_table(CSRC / "kernels" / "decimate.hip", tmp_path)
+@pytest.mark.parametrize("fast", [False, True], ids=["exact", "fast"])
+def test_step_and_stage1_kernels_do_not_spill(tmp_path, fast):
+    """(both arithmetic modes: the translation unit is compiled once per mode, kernels/arith.h)"""
+    t = kernel_table(CSRC / "kernels" / "decimate.hip", tmp_path, fast)
+    if fast:       # the fast mode's FIR loops are fused multiply-adds: the listing must carry them, and the exact mode's must not
+        txt = (tmp_path / "decimate.s").read_text()
+        assert txt.count("v_pk_fma_f32") > 2000, txt.count("v_pk_fma_f32")
+    else:
+        assert (tmp_path / "decimate.s").read_text().count("v_pk_fma_f32") == 0
     for k in ("k_step_cu<212,2,69>", "k_step_cu<174,4,139>"):
         assert t[k]["spill"] == 0 and t[k]["scratch"] == 0 and t[k]["vgpr"] <= 256, (k, t[k])
     for k in ("k_stage1_cu<212,32>", "k_stage1_cu<174,32>"):

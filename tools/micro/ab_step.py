@@ -58,7 +58,8 @@ def main():
             for k, x in env.items(): os.environ[k] = x
             capi._lib = L                                   # (Engine() and check() go through capi.lib())
             eng = engine.Engine(n_streams=S, max_chunk=Cn, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"],
-                                lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"], pipeline=0 if a.sync else 2)
+                                lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"], pipeline=0 if a.sync else 2,
+                                **({"arith": int(env["ARITH"])} if "ARITH" in env else {}))      # (ARITH=1: the library's fast mode -- a variant spec like default+f:ARITH=1)
             eng.set_timing(a.timing)
             for i in range(a.warmup): eng.process_device(base + (i % rc) * S * Cn * 8, Cn, Cn)
             eng.flush(); torch.cuda.synchronize()

@@ -7,9 +7,9 @@ import _variant
 w = dict(bench.WORKLOADS["cfg4"]); S = 1024; C = w["C"]
 dev = torch.device("cuda", 0)
 ring, rc, _ = bench.generate_ring(torch, dev, w, S, 0, 1234)
-eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"], pipeline=bool(int(os.environ.get("PIPE", "1"))))
+eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"], arith=int(__import__("os").environ.get("ARITH", "0")), pipeline=bool(int(os.environ.get("PIPE", "1"))))
 eng.set_timing(1)
-L = habdec_amd.lib(); f = L.hd_debug_ring_stamps; f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+L = habdec_amd.lib(); f = getattr(L, "hd_debug_ring_stamps" + ("_fast" if int(os.environ.get("ARITH", "0")) else "")); f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 for i in range(int(os.environ.get("NCALLS", "30"))):
     eng.process_device(ring.data_ptr() + (i % rc) * S * C * 8, C, C)
 eng.flush()

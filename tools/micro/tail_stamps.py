@@ -7,8 +7,8 @@ import _variant
 w = dict(bench.WORKLOADS["cfg4"]); S = 1024; C = w["C"]
 dev = torch.device("cuda", 0)
 ring, rc, _ = bench.generate_ring(torch, dev, w, S, 0, 1234)
-eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"], pipeline=bool(int(__import__("os").environ.get("PIPE", "0"))))
-L = habdec_amd.lib(); f = L.hd_debug_step_tail_stamps if int(__import__('os').environ.get('PIPE', '0')) else L.hd_debug_tail_stamps; f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"], arith=int(__import__("os").environ.get("ARITH", "0")), pipeline=bool(int(__import__("os").environ.get("PIPE", "0"))))
+L = habdec_amd.lib(); f = getattr(L, ('hd_debug_step_tail_stamps' if int(__import__('os').environ.get('PIPE', '0')) else 'hd_debug_tail_stamps') + ('_fast' if int(__import__('os').environ.get('ARITH', '0')) else '')); f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 acc = np.zeros(20); mx = np.zeros(20); n = 0; spans = []; ends = []
 for i in range(40):
     eng.process_device(ring.data_ptr() + (i % rc) * S * C * 8, C, C)
