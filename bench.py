@@ -177,7 +177,7 @@ def cpu_baseline(w, host_iq, chunks, C, lookup_mode=1):
     return total / dt / 1e6, best, sample, {str(k): round(v, 1) for k, v in table.items()}
 
 
-def oracle_sample_check(w, eng, ring, chunks, C, streams, lookup_mode=1, group=64):
+def oracle_sample_check(w, eng, ring, chunks, C, streams, lookup_mode=1, group=64, exact_floats=True):
     """The self-check every bench line carries: the oracle decodes the chunk sequence the engine consumed on `streams` (one pass, one thread per
     stream, `group` streams at a time: a group's share of the ring is transposed on the GPU and brought over in one copy) and the engine's symbols
     produced, characters and sentences per stream must equal the oracle's.  The headline line checks EVERY stream of the shard."""
@@ -187,7 +187,7 @@ def oracle_sample_check(w, eng, ring, chunks, C, streams, lookup_mode=1, group=6
     nuse = max(chunks) + 1
     streams = list(streams)
     t0 = time.perf_counter()
-    n_chars = n_bits = n_sent = 0
+    n_chars = n_bits = n_sent = n_ck = 0
     diff = []
     contiguous = streams == list(range(streams[0], streams[0] + len(streams)))
     for g0 in range(0, len(streams), group):
@@ -203,15 +203,21 @@ def oracle_sample_check(w, eng, ring, chunks, C, streams, lookup_mode=1, group=6
             got = (eng.take_sentences(s), eng.take_chars(s), eng.bits_total(s))
             want = (list(lg), lg.chars, lg.bits)
             n_chars += len(lg.chars); n_bits += lg.bits; n_sent += len(lg)
-            for f, g_, o_ in zip(("sentences", "chars", "bits"), got, want):
+            if exact_floats:                                # exact mode: every call's discriminator output, bit for bit, through the folded checksums
+                nck, unk, h = eng.demod_checksum_total(s)
+                if unk == 0 and nck == len(chunks):
+                    n_ck += nck
+                    got, want = got + (h,), want + (lg.demod_hash,)
+            for f, g_, o_ in zip(("sentences", "chars", "bits", "discriminator output of every call"), got, want):
                 if g_ != o_:
                     if not diff:
                         sys.stderr.write(f"[bench] self-check mismatch on stream {s} ({f}): gpu bits {got[2]} chars {got[1]!r} / oracle bits {want[2]} chars {want[1]!r}\n")
                     diff.append((int(s), f))
     return {"gpu_matches_oracle_on_sample": ((not diff) if n_bits else None), "mismatches": diff[:8],
-            "compared": "per stream: symbols produced, characters emitted, sentences -- GPU engine vs oracle over every step the engine took (both timed regions, pre-warm, warm-up, sampling pass)",
+            "compared": "per stream: symbols produced, characters emitted, sentences" + (", and every call's discriminator output bit for bit (folded checksums)" if exact_floats else "") + " -- GPU engine vs oracle over every step the engine took (both timed regions, pre-warm, warm-up, sampling pass)",
             "streams_in_sample": [int(x) for x in streams] if len(streams) <= 8 else len(streams), "all_streams_of_the_shard": len(streams) == eng.S,
             "bits_in_sample": n_bits, "chars_in_sample": n_chars, "sentences_in_sample": n_sent, "steps_checked": len(chunks),
+            "discriminator_checksums_compared": n_ck,       # (stream, call) pairs whose discriminator output was compared bit for bit (exact mode; 0 in fast mode)
             "check_seconds": round(time.perf_counter() - t0, 1)}
 
 
@@ -534,7 +540,7 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
         # until the barrier -- and rank 0's line carries the verdicts (per_rank[i].gpu_matches_oracle).
         dist.barrier()
         mine = oracle_sample_check(w, eng, ring, chunks, C, list(range(S)) if cpu_leg in ("full", "check_all") else sorted({0, min(7, S - 1), S // 2, S - 1}),
-                                   group=max(8, 128 // world))
+                                   group=max(8, 128 // world), exact_floats=not arith)
         dist.gather_object({k: mine[k] for k in ("gpu_matches_oracle_on_sample", "all_streams_of_the_shard", "bits_in_sample", "sentences_in_sample", "mismatches", "check_seconds")}, None, dst=0)
         eng.close()
         return None
@@ -637,14 +643,14 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
                                "threads_calibration_MSps": calib}
         if dist is not None:
             dist.barrier()                                     # the other ranks' self-checks start here: the timing above had the host cores to itself
-        res["cpu_baseline"].update(oracle_sample_check(w, eng, ring, chunks, C, list(range(S)), group=max(8, 128 // world) if world > 1 else 64))      # every stream of the shard
+        res["cpu_baseline"].update(oracle_sample_check(w, eng, ring, chunks, C, list(range(S)), group=max(8, 128 // world) if world > 1 else 64, exact_floats=not arith))      # every stream of the shard
     elif cpu_leg in ("check", "check_all"):
         # no CPU timing asked for: the line still says whether what it timed decodes what the oracle decodes (a far-off-tune stream among them)
         res["cpu_baseline"] = {"value": None, "kind": "port", "note": "self-check only (--no-cpu-baseline / secondary workload): the oracle was not timed"}
         if dist is not None:
             dist.barrier()
         res["cpu_baseline"].update(oracle_sample_check(w, eng, ring, chunks, C, list(range(S)) if cpu_leg == "check_all" else sorted({0, min(7, S - 1), S // 2, S - 1}),
-                                                       group=max(8, 128 // world) if world > 1 else 64))
+                                                       group=max(8, 128 // world) if world > 1 else 64, exact_floats=not arith))
     if "cpu_baseline" in res:
         # every rank's verdict on its own shard beside its clock and power (rank 0's is the line's cpu_baseline block)
         mine = {k: res["cpu_baseline"][k] for k in ("gpu_matches_oracle_on_sample", "all_streams_of_the_shard", "bits_in_sample", "sentences_in_sample", "mismatches", "check_seconds")}

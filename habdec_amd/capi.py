@@ -82,6 +82,7 @@ ENGINE_API = {
     "hd_stream_bits_total": (C.c_uint64, [_vp, _u32]),
     "hd_stream_flip_list_full": (C.c_uint64, [_vp, _u32]),
     "hd_stream_demod_checksum": (C.c_int, [_vp, _u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "hd_stream_demod_checksum_total": (C.c_int, [_vp, _u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "hd_min_chunk": (_u32, [_u32]),
     "hd_engine_timing": (_int, [_vp, C.POINTER(hd_timing)]),
     "hd_engine_set_timing": (None, [_vp, _int]),

@@ -83,7 +83,7 @@ struct SpectrumStatsDev {   // must match hd::SpectrumStats (host/afc_tracker.hp
     int32_t valid;
     int32_t peak1, peak2;
     float power1, power2;
-    float _pad;
+    uint32_t seq;           // the call's tag, stored LAST by the wave that wrote the statistics (as BitsHeader::seq: the host takes them as delivered when it reads the tag it expects)
     double mean, sigma;
 };
 

@@ -105,6 +105,8 @@ struct StreamHost {
     std::vector<uint32_t> last_words;
     uint32_t demod_ck[2] = {0, 0}, demod_ck_n = 0xFFFFFFFFu;   // discriminator checksum of the call delivered last (BitsHeader::demod_ck)
     uint64_t demod_ck_call = 0;                               // ... and that call's index (0 = the engine's first hd_process_* call)
+    uint64_t demod_ck_hash = 0xCBF29CE484222325ull;           // every delivered call's (n, ck[0], ck[1]) folded into one word (hd_stream_demod_checksum_total)
+    uint64_t demod_ck_calls = 0, demod_ck_unknown = 0;        // calls folded in / calls whose slot carried no checksum (the fused back end)
 };
 
 }  // namespace
@@ -143,13 +145,21 @@ struct hd_engine {
     static constexpr uint32_t kS1Slots = HD_S1_SLOTS_BATCH;     // tile slots of k_stage1_cu in batch mode on the separate-kernels path: four leave half of a CU's LDS to the back-half
                                                 // workgroups of the previous call on the other queue (/16: 0.334-0.343 ms per step against 0.342-0.351 with eight)
     PinBuf<unsigned int> ring_gave_up;     // mapped host word a wave of k_step_cu / k_stage1_cu sets when a bounded wait runs out (never in a correct run)
+    std::string fail_cause;                // what put the engine into its failed state (reported again by every later call)
     bool device_failed = false;            // ... after which the engine stays failed: the launch that gave up left stage-1 output incomplete, and up to
                                            // three calls are undelivered by the time a collect() sees the word -- which of them it was cannot be told
     uint64_t step_launches = 0;
     DevBuf<unsigned int> step_ctr;         // two sets of per-XCD run counters ([2][16][32] u32), alternating per step launch
     uint32_t pend_max_taps = 0;
     bool dec_wgs_forced = false;   // HD_DEC_WGS_PER_CU was given (tests of the linear split)
-    int cu_exp = 0;                // HD_CU_EXP: timing experiments only, results wrong -- 1: step launches without their tails, 2: without stage 1 (tools/micro/joules.py)
+    // Timing experiments (results wrong: step launches without their tails -- 1 -- or without stage 1 -- 2; tools/micro/joules.py) exist in a VARIANT build only
+    // (-DHD_TIMING_EXPERIMENT, HD_BUILD_VARIANT=timingexp: reads HD_CU_EXP): no environment variable makes the product library skip the result-slot tag
+    // check or deliver wrong results.
+#ifdef HD_TIMING_EXPERIMENT
+    int cu_exp = 0;
+#else
+    static constexpr int cu_exp = 0;
+#endif
     uint32_t n_cus = 0, dec_wgs_per_cu = 0;   // stage-1 linear split: workgroups per CU (0 = classic grid), see kernels/decimate.hip        // path of the previous call (the two paths use the stage-2 buffers on different queues)
     hipStream_t qa = nullptr, qb = nullptr, qc = nullptr;   // front (decimation, spectrum) and back (FIR, symbols, results) HIP streams
     // hd_process_host: copies run on their own stream into two alternating slabs; a call returns once ITS copy has landed, so the
@@ -173,6 +183,7 @@ struct hd_engine {
     DevBuf<hd::DemodCarry> carry[2];
     DevBuf<float2> fir_head;          // [2][S][head_cap]: first samples of the previous low-pass run's input (FirHistory, dev_types.h), halves alternate like the carries
     DevBuf<uint32_t> fir_head_n;      // [2][S]
+    DevBuf<uint32_t> demod_ck_acc;    // [S][2]: the discriminator checksum of the call in the back half of the separate-kernels path (k_fir_demod adds, k_symbols collects and clears)
     uint32_t head_cap = 0;
     DevBuf<hd::SymbolParams> d_sym;
     PinBuf<hd::SymbolParams> h_sym;
@@ -327,7 +338,9 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         // second queue, finds room underneath.
         e->dec_wgs_per_cu = cfg->pipeline ? 6u : 8u;
         if (const char* v = getenv("HD_DEC_WGS_PER_CU")) { e->dec_wgs_per_cu = (uint32_t)atoi(v); e->dec_wgs_forced = true; }
+#ifdef HD_TIMING_EXPERIMENT
         if (const char* v = getenv("HD_CU_EXP")) e->cu_exp = atoi(v);
+#endif
     }
     for (hipEvent_t* ev : {&e->ev_copy[0], &e->ev_copy[1], &e->ev_staging_free[0], &e->ev_staging_free[1]}) HD_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     if (e->one_stream) e->qb = e->qc = e->qa;
@@ -424,6 +437,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     e->head_cap = std::min<uint32_t>(e->taps_cap, 8192u);   // a tap-count jump of more than 8192 reads zeros beyond (documented)
     HD_HIP(e->fir_head.alloc((size_t)2 * S * e->head_cap));
     HD_HIP(e->fir_head_n.alloc((size_t)2 * S));
+    HD_HIP(e->demod_ck_acc.alloc((size_t)2 * S));
     HD_HIP(e->d_sym.alloc(S));
     HD_HIP(e->h_sym.alloc(S));
     for (auto& sl : e->slot) {
@@ -482,7 +496,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
             void* in[1] = {e->fft_in.p};
             void* outb[1] = {e->fft_raw.p};
             if (rocfft_execute(e->fft_plan, in, outb, e->fft_info) != rocfft_status_success) return fail(HD_ERR_DEVICE, "rocfft_execute failed");
-            hd::launch_spectrum_commit(q, S, e->fft_raw.p, e->spec.p, e->power.p, sl.h_stats.dev, sl.d_call.p, e->fsd, e->bins_sep);
+            hd::launch_spectrum_commit(q, S, e->fft_raw.p, e->spec.p, e->power.p, sl.h_stats.dev, sl.d_call.p, e->fsd, e->bins_sep, 0u);
         }
         HDK(launch_fir_demod, q, S, 0, 0, e->fbuf[0].p, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S, nullptr, e->carry[0].p,
                              e->carry[1].p, sl.d_call.p, e->fir_hist_cap, e->tail.p, e->tail_cap, e->d_symstate.p, e->fbuf[1].p,
@@ -614,24 +628,24 @@ int hd_stream_reset_frequency_correction(hd_engine* e, uint32_t s, double c)
 namespace {
 
 // rocFFT + commit for the streams whose 4096-sample buffer completed in the call that owns `sl` (Decoder.h:475-489)
-int transform_and_commit(hd_engine* e, hipStream_t q, hd::SpectrumStatsDev* stats_dev, const hd::StreamCall* dcall)
+int transform_and_commit(hd_engine* e, hipStream_t q, hd::SpectrumStatsDev* stats_dev, const hd::StreamCall* dcall, uint32_t seq)
 {
     if (e->own_fft) {   // one launch, one wave per stream (kernels/spectrum_wave.hip)
-        hd::launch_spectrum_wave(q, e->S, e->fft_in.p, e->fft_tw.p, e->spec.p, e->power.p, stats_dev, dcall, e->fsd, e->bins_sep);
+        hd::launch_spectrum_wave(q, e->S, e->fft_in.p, e->fft_tw.p, e->spec.p, e->power.p, stats_dev, dcall, e->fsd, e->bins_sep, seq);
         return HD_OK;
     }
     void* in[1] = {e->fft_in.p};
     void* outb[1] = {e->fft_raw.p};
     rocfft_execution_info_set_stream(e->fft_info, q);
     if (rocfft_execute(e->fft_plan, in, outb, e->fft_info) != rocfft_status_success) return fail(HD_ERR_DEVICE, "rocfft_execute failed");
-    hd::launch_spectrum_commit(q, e->S, e->fft_raw.p, e->spec.p, e->power.p, stats_dev, dcall, e->fsd, e->bins_sep);
+    hd::launch_spectrum_commit(q, e->S, e->fft_raw.p, e->spec.p, e->power.p, stats_dev, dcall, e->fsd, e->bins_sep, seq);
     return HD_OK;
 }
 
 int run_spectrum(hd_engine* e, hipStream_t q, hd_engine::CallSlot& sl, bool any_fft)
 {
     if (!e->cfg.enable_spectrum || !any_fft) return HD_OK;
-    return transform_and_commit(e, q, sl.h_stats.dev, sl.d_call.p);
+    return transform_and_commit(e, q, sl.h_stats.dev, sl.d_call.p, sl.seq);
 }
 
 // Step mode: the tails of the newest call have not been launched yet (they wait for the next call's launch).  Run them now, as a
@@ -678,23 +692,33 @@ int collect(hd_engine* e, hd_engine::CallSlot& sl)
     int rc = HD_OK;
     {   // every stream's slot must carry this call's tag (the kernels store it last); in practice it is there when the event has fired -- if not, wait for it
         const auto t_lim = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
-        const bool timing_experiment = e->cu_exp != 0;      // (HD_CU_EXP: step launches without their tails or without stage 1 -- nothing writes the slots)
-        for (uint32_t s = 0; s < e->S && !e->device_failed && !timing_experiment; ++s) {
-            const volatile uint32_t* tag = &reinterpret_cast<const volatile hd::BitsHeader*>(sl.h_slots.p + (size_t)s * e->slot_words)->seq;
-            while (*tag != sl.seq) {
+        const bool timing_experiment = e->cu_exp != 0;      // (only in the -DHD_TIMING_EXPERIMENT variant build: step launches without their tails or without stage 1 -- nothing writes the slots)
+        auto await = [&](const volatile uint32_t* tag, const char* what, uint32_t s) {
+            for (uint32_t spins = 0; *tag != sl.seq; ++spins) {
                 if (std::chrono::steady_clock::now() > t_lim) {
                     e->device_failed = true;
-                    rc = fail(HD_ERR_DEVICE, "result slot of stream " + std::to_string(s) + " does not carry its call's tag 200 ms after the completion event: the results of this engine are unreliable -- destroy the engine");
-                    break;
+                    e->fail_cause = std::string(what) + " of stream " + std::to_string(s) + " does not carry its call's tag 200 ms after the completion event";
+                    rc = fail(HD_ERR_DEVICE, e->fail_cause + ": the results of this engine are unreliable -- destroy the engine");
+                    return;
                 }
+                if (spins > 64u) std::this_thread::yield();      // (in practice the tag is there when the event has fired)
             }
+        };
+        for (uint32_t s = 0; s < e->S && !e->device_failed && !timing_experiment; ++s) {
+            await(&reinterpret_cast<const volatile hd::BitsHeader*>(sl.h_slots.p + (size_t)s * e->slot_words)->seq, "result slot", s);
+            // ... and the spectrum statistics of a stream whose buffer completed in this call: written by the tail itself (behind the same tag) or by a
+            // commit / spectrum launch of its own, whose stores no event of this engine fences
+            if (!e->device_failed && e->cfg.enable_spectrum && sl.h_stats.p && sl.h_call.p[s].fft_run)
+                await(reinterpret_cast<const volatile uint32_t*>(&sl.h_stats.p[s].seq), "spectrum statistics", s);
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
-    if (e->ring_gave_up.p && e->ring_gave_up.p[0]) e->device_failed = true;
-    if (e->device_failed && rc == HD_OK)
-        rc = fail(HD_ERR_DEVICE, "k_stage1_cu (loader / consumer waves): a bounded wait ran out inside a launch (word " + std::to_string(e->ring_gave_up.p ? e->ring_gave_up.p[0] : 0u) +
-                                 "): the results of this and of every later call of this engine are unreliable -- destroy the engine");
+    if (e->ring_gave_up.p && e->ring_gave_up.p[0] && !e->device_failed) {
+        e->device_failed = true;
+        e->fail_cause = "k_stage1_cu (loader / consumer waves): a bounded wait ran out inside a launch (word " + std::to_string(e->ring_gave_up.p[0]) + ")";
+    }
+    if (e->device_failed && rc == HD_OK)         // (a later call of a failed engine: the cause recorded when it failed)
+        rc = fail(HD_ERR_DEVICE, e->fail_cause + ": the results of this and of every later call of this engine are unreliable -- destroy the engine");
     if (e->device_failed) {
         // Nothing of this slot is delivered: the launch that gave up left stage-1 output incomplete, so the characters -- possibly CRC-passing
         // sentences -- framed from it would be handed to the callbacks as if they were results.  No AFC step, no framer push, no callbacks, no counters.
@@ -720,6 +744,10 @@ int collect(hd_engine* e, hd_engine::CallSlot& sl)
         st.last_nbits = hdr->nbits; st.last_nflips = hdr->nflips;
         st.bits_total += hdr->nbits;
         st.demod_ck[0] = hdr->demod_ck[0]; st.demod_ck[1] = hdr->demod_ck[1]; st.demod_ck_n = hdr->demod_n; st.demod_ck_call = e->delivered;
+        if (hdr->demod_n != 0xFFFFFFFFu) {
+            for (const uint32_t x : {hdr->demod_n, hdr->demod_ck[0], hdr->demod_ck[1]}) st.demod_ck_hash = (st.demod_ck_hash ^ x) * 0x100000001B3ull;
+            ++st.demod_ck_calls;
+        } else ++st.demod_ck_unknown;
         if (hdr->overflow & 1u) rc = fail(HD_ERR_CAPACITY, "symbol result slot overflow on stream " + std::to_string(s));
         if (hdr->overflow & 2u) ++st.flip_list_full;     // (the search stopped at the flip-list bound and resumes next call: bits arrive a call later)
         const uint32_t* words = slot + sizeof(hd::BitsHeader) / 4;
@@ -761,7 +789,7 @@ int hd_flush(hd_engine* e)
     if (e->in_callback) return fail(HD_ERR_INVALID, "hd_flush cannot be called from a sentence / character callback (the delivery it would join is the one running)");
     HD_HIP(hipSetDevice(e->cfg.device));
     const int rc = flush_locked(e);
-    if (e->device_failed) return fail(HD_ERR_DEVICE, "this engine is in its failed state (a bounded wait ran out inside an earlier launch) -- destroy the engine");
+    if (e->device_failed) return fail(HD_ERR_DEVICE, "this engine is in its failed state (" + e->fail_cause + ") -- destroy the engine");
     return rc;
 }
 
@@ -772,7 +800,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     if ((reinterpret_cast<uintptr_t>(d_iq) & 15) || (stride & 1)) return fail(HD_ERR_INVALID, "IQ base must be 16-byte aligned and stream_stride even");
     std::lock_guard<std::recursive_mutex> lock(e->mtx);
     if (e->in_callback) return fail(HD_ERR_INVALID, "hd_process_* cannot be called from a sentence / character callback");   // (a nested delivery would count the slot being delivered twice)
-    if (e->device_failed) return fail(HD_ERR_DEVICE, "this engine is in its failed state (a bounded wait ran out inside an earlier launch): no new calls are accepted -- destroy the engine");
+    if (e->device_failed) return fail(HD_ERR_DEVICE, "this engine is in its failed state (" + e->fail_cause + "): no new calls are accepted -- destroy the engine");
     const auto h0 = std::chrono::steady_clock::now();
     HD_HIP(hipSetDevice(e->cfg.device));
     const uint32_t S = e->S;
@@ -865,6 +893,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     sl.total_in = total_in;
     sl.r1 = R1;
     sl.seq = (uint32_t)(e->calls + 1u);           // (never the tag this slot carried four calls ago)
+    if (!sl.seq) sl.seq = 1u;                     // (0 is what a slot holds before its first call: skipped when the counter wraps after 2^32 calls)
     // ---- uploads: per-call parameters, changed low-pass designs, changed symbol parameters
     hipStream_t qa = e->qa, qb = e->qb;
     // Two-stage plans at batch-decoding sizes: stage 2, low-pass, discriminator and slide run as ONE kernel per call on qb
@@ -1002,7 +1031,12 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         // Where the per-CU step kernel can serve the plan and the sizes, this call's tails are laid out for ITS slice of LDS -- a quarter of what four
         // worker slots leave of the CU's 160 KB (23 KB: larger caches for the search phase than the 20 KB slot of the single-wave fallback) -- now; the
         // launch that runs them decides.
-        const bool cu_shape = !e->no_cu_step && !e->no_claim && !any_zero1 && max_in % 2048u == 0 && HDK(step_cu_supported, (int)R1, (int)T1, (int)R2, (int)T2);
+        // (... and only where the per-CU kernel's runs can be drawn at all for this stream count -- an odd count never divides among the XCDs --: such
+        // batches keep the 20 KB layout and ride in k_step as before.  What is left for the fallback further down are the transitions: a launch that cannot
+        // be the per-CU kernel although the previous call expected it.)
+        const uint32_t ring_nt = HDK(ring_tiles, (int)R1, (int)T1, max_in), ring_run0 = pick_ring_run(ring_nt), n_xcd0 = e->n_cus / 32u;
+        const bool runs_ok = ring_nt && n_xcd0 && ring_run0 >= 2u && ((uint64_t)S * ring_nt) % ring_run0 == 0 && ((uint64_t)S * ring_nt / ring_run0) % n_xcd0 == 0;
+        const bool cu_shape = !e->no_cu_step && !e->no_claim && !any_zero1 && max_in % 2048u == 0 && runs_ok && HDK(step_cu_supported, (int)R1, (int)T1, (int)R2, (int)T2);
         const uint32_t cu_tail = cu_shape ? HDK(step_cu_tail_lds, (int)R1, (int)T1) : 0u;
         if (cu_tail) {
             hd::TailArgs tacu{};
@@ -1017,7 +1051,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         bool ev_on_dispatch = false;
         uint32_t wgs = 32u * e->n_cus;                          // short runs of tiles: the dispatcher evens out the tail of the launch
         // One workgroup per CU (four stage-1 worker waves, the tails in the other four) where the plan and the sizes allow it
-        const uint32_t ring_run = pick_ring_run(HDK(ring_tiles, (int)R1, (int)T1, max_in));
+        const uint32_t ring_run = ring_run0;
         const int cu_exp0 = e->cu_exp;             // timing experiments only (results wrong): 1 = no tails, 2 = no stage 1
         const bool want_cu = cu_tail && ((cu_exp0 & 1) || (ta_step.lds_bytes <= cu_tail && (!prev.valid || prev.ta.lds_bytes <= cu_tail)));
         const hd::StepClaim claim = make_claim(0, want_cu ? ring_run : 0u);
@@ -1043,6 +1077,15 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             if (want_cu && claim.ctr) {                        // (runs cut for the ring kernel's tiles are not k_step's: fixed shares, and the counter set was not drawn from)
                 --e->step_launches; fb = hd::StepClaim{};
                 wgs = 32u * e->n_cus;
+            }
+            // The previous call's tails were laid out when THAT call was enqueued -- for k_step_cu's 23 KB slice where its shape held -- and the launch that runs
+            // them is this one.  If this launch is the single-wave fallback (the pushes grew, a stream count whose runs do not divide among the XCDs, a size
+            // that is not a multiple of 2048), a tail carved for more than k_step's static slot would read and write LDS past the workgroup's allocation
+            // (reads return 0, writes are dropped: wrong window sums and flips, no error -- ADVICE r05).  Such tails run as a launch of their own, in front,
+            // with the LDS they were laid out for; this launch then carries stage 1 only.
+            if (prev.valid && prev.ta.lds_bytes > HDK(step_lds_bytes, (int)R1, (int)T1)) {
+                if (const int r = run_pending_tail(e)) return r;     // (e->pend is still the previous call's; launches the tails, their spectra, records its ev_done)
+                prev.valid = false; ps = nullptr;
             }
             if (!HDK(launch_step, qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, max_n1, iq, stride, e->hist1[hin].p,
                                  e->hist1[hout].p, e->stage_taps[0].p, d1, e->n1_cap, sl.h_call.dev, sl.d_call.p, wgs, prev.ta, prev.valid ? S : 0u,
@@ -1122,7 +1165,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         if (!(e->cfg.enable_spectrum && max_n2)) return HD_OK;
         if (!fuse && (any_dc || nst == 0)) HDK(launch_fft_feed, q, S, fcur, e->fbuf_stride, e->fft_in.p, dcall, e->fir_hist_cap);
         if (any_fft) {   // only when some stream's 4096-sample buffer completed (every call at >= 4096 decimated samples per push)
-            if (const int r = transform_and_commit(e, q, sl.h_stats.dev, dcall)) return r;
+            if (const int r = transform_and_commit(e, q, sl.h_stats.dev, dcall, sl.seq)) return r;
         }
         return HD_OK;
     };
@@ -1156,11 +1199,12 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         HDK(launch_fir_demod, qb, S, max_m, max_taps, fcur, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S,
                              e->cfg.keep_filtered ? e->filtered.p : nullptr, e->carry[cin].p, e->carry[cout].p, dcall, e->fir_hist_cap,
                              e->tail.p, e->tail_cap, e->d_symstate.p, fnext, e->fir_head.p + (size_t)cin * S * e->head_cap, e->fir_head_n.p + (size_t)cin * S,
-                             e->fir_head.p + (size_t)cout * S * e->head_cap, e->fir_head_n.p + (size_t)cout * S, e->head_cap);
+                             e->fir_head.p + (size_t)cout * S * e->head_cap, e->fir_head_n.p + (size_t)cout * S, e->head_cap, e->demod_ck_acc.p);
     }
     if (!tail)
     HDK(launch_symbols, qb, S, max_m, max_new, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p,
-                       dcall, sl.h_slots.dev, e->slot_words, e->flips_cap ? e->flips_dbg.p : nullptr, e->flips_cap, e->min_R, sl.seq, ev_ride ? sl.ev_done : nullptr);
+                       dcall, sl.h_slots.dev, e->slot_words, e->flips_cap ? e->flips_dbg.p : nullptr, e->flips_cap, e->min_R, sl.seq, ev_ride ? sl.ev_done : nullptr,
+                       fuse ? nullptr : e->demod_ck_acc.p);      // (the fused back end, k_backend, leaves no checksum: its slots say demod_n = 0xFFFFFFFF)
     if (!tail && ev_ride) done_on_dispatch = true;
     if (sl.timed) HD_HIP(hipEventRecord(sl.t3, qb));
     if (!done_on_dispatch) HD_HIP(hipEventRecord(sl.ev_done, qb));
@@ -1435,6 +1479,16 @@ int hd_stream_demod_checksum(hd_engine* e, uint32_t s, uint64_t* call_index, uin
     if (call_index) *call_index = st.demod_ck_call;
     if (n) *n = st.demod_ck_n;
     if (ck) { ck[0] = st.demod_ck[0]; ck[1] = st.demod_ck[1]; }
+    return HD_OK;
+}
+int hd_stream_demod_checksum_total(hd_engine* e, uint32_t s, uint64_t* calls, uint64_t* calls_without, uint64_t* hash)
+{
+    if (check_stream(e, s)) return HD_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> l(e->mtx);
+    const StreamHost& st = e->st[s];
+    if (calls) *calls = st.demod_ck_calls;
+    if (calls_without) *calls_without = st.demod_ck_unknown;
+    if (hash) *hash = st.demod_ck_hash;
     return HD_OK;
 }
 uint32_t hd_stream_symbol_backlog(hd_engine* e, uint32_t s)

@@ -18,7 +18,7 @@ struct SpectrumStats {          // produced by the spectrum kernel, one per stre
     int32_t valid;              // 0 when the spectrum or its power held NaN/Inf (AFC.h:250-283)
     int32_t peak1, peak2;       // ordered so peak1 < peak2 (AFC.h:321-325)
     float power1, power2;       // dB power at those bins
-    float _pad;
+    uint32_t seq;               // (device side: the call's tag, see dev_types.h SpectrumStatsDev)
     double mean, sigma;         // AFC.h:103-104
 };
 

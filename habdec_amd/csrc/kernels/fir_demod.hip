@@ -78,9 +78,11 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
                                                           float* __restrict__ sym_ring, uint32_t ring_cap,
                                                           const SymState* __restrict__ sym, float2* __restrict__ fbuf_next,
                                                           const float2* __restrict__ head_in, const uint32_t* __restrict__ head_n_in,
-                                                          float2* __restrict__ head_out, uint32_t* __restrict__ head_n_out, uint32_t head_cap)
+                                                          float2* __restrict__ head_out, uint32_t* __restrict__ head_n_out, uint32_t head_cap,
+                                                          uint32_t* __restrict__ ck_acc /* [S][2]: the call's discriminator checksum, accumulated by the stream's tiles (or null) */)
 {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];   // [kFirTile + T + kFirSlack] inputs, then reused for outputs
+    __shared__ uint32_t s_ck[2];
     const uint32_t s = blockIdx.y;
     FSTAMP_DECL;
     const StreamCall c = call[s];
@@ -196,9 +198,10 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
         for (int q = 0; q < kFirOut; q += 2)
             reinterpret_cast<float4*>(lds)[(uint32_t)(kFirOut / 2) * threadIdx.x + (uint32_t)(q / 2)] = make_float4(acc[q].x, acc[q].y, acc[q + 1].x, acc[q + 1].y);
     }
+    if (threadIdx.x < 2) s_ck[threadIdx.x] = 0u;
     __syncthreads();
 
-    if (threadIdx.x == 0 || !active) return;           // lane 0 only supplied lane 1's predecessor
+    if (threadIdx.x != 0 && active) {                   // (lane 0 only supplied lane 1's predecessor)
     const long i = i0 + (long)kFirOut * (long)threadIdx.x;         // >= 0 here
     float pr, pi;
     if (i > 0) { const float2 q = lds[kFirOut * threadIdx.x - 1]; pr = q.x; pi = q.y; }
@@ -237,6 +240,17 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
         kc.re = y.x; kc.im = y.y;
         carry_out[s] = kc;
     }
+    if (ck_acc) {       // BitsHeader::demod_ck of this call: sum of the outputs' bit patterns, and of (index + 1) * bit pattern (mod 2^32)
+        uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+        for (int q = 0; q < kFirOut; ++q) if ((uint32_t)q < nv) { const uint32_t b = __builtin_bit_cast(uint32_t, d[q]); c0 += b; c1 += ((uint32_t)i + (uint32_t)q + 1u) * b; }
+        atomicAdd(&s_ck[0], c0); atomicAdd(&s_ck[1], c1);
+    }
+    }
+    if (ck_acc) {
+        __syncthreads();
+        if (threadIdx.x < 2) atomicAdd(&ck_acc[2 * (size_t)s + threadIdx.x], s_ck[threadIdx.x]);     // (k_symbols of this call hands the sums to the result slot and clears them)
+    }
     FSTAMP(3);
     FSTAMP_WRITE();
 }
@@ -271,13 +285,13 @@ void launch_fir_demod(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32
                       const float* taps, uint32_t taps_stride, float* demod, size_t demod_stride, float2* filtered,
                       const DemodCarry* carry_in, DemodCarry* carry_out, const StreamCall* call, uint32_t fir_hist_cap,
                       float* sym_ring, uint32_t ring_cap, const SymState* sym, float2* fbuf_next,
-                      const float2* head_in, const uint32_t* head_n_in, float2* head_out, uint32_t* head_n_out, uint32_t head_cap)
+                      const float2* head_in, const uint32_t* head_n_in, float2* head_out, uint32_t* head_n_out, uint32_t head_cap, uint32_t* ck_acc)
 {
     const uint32_t tiles = max_m ? (max_m + kFirAdvance - 1) / kFirAdvance : 1;
     const size_t lds = (size_t)(kFirTile + (max_taps ? max_taps : 1) + kFirSlack + 4) * sizeof(float2);
     dim3 grid(tiles, n_streams);
     hipLaunchKernelGGL(k_fir_demod, grid, dim3(kFirLanes), lds, st, fbuf, stride, taps, taps_stride, demod, demod_stride, filtered,
-                       carry_in, carry_out, call, fir_hist_cap, sym_ring, ring_cap, sym, fbuf_next, head_in, head_n_in, head_out, head_n_out, head_cap);
+                       carry_in, carry_out, call, fir_hist_cap, sym_ring, ring_cap, sym, fbuf_next, head_in, head_n_in, head_out, head_n_out, head_cap, ck_acc);
 }
 
 void launch_fft_feed(hipStream_t st, uint32_t n_streams, const float2* fbuf, size_t stride, float2* fft_in, const StreamCall* call,

@@ -51,10 +51,11 @@ constexpr uint32_t kStepLdsBytes = 20480;   // LDS of a stage-1 workgroup slot (
 
 // ---- launchers that do not depend on the arithmetic mode (symbols.hip, spectrum.hip, spectrum_wave.hip)
 void launch_spectrum_commit(hipStream_t st, uint32_t n_streams, const float2* raw, float2* spec, float* power,
-                            SpectrumStatsDev* stats, const StreamCall* call, double rate, int bins_sep);
+                            SpectrumStatsDev* stats, const StreamCall* call, double rate, int bins_sep,
+                            uint32_t seq /* the call's tag, stored last into every SpectrumStatsDev written (SpectrumStatsDev::seq) */);
 // The transform and the commit in one launch, one wave per stream (kernels/spectrum_wave.hip); tw4096[m] = (cos, -sin)(2 pi m / 4096).
 void launch_spectrum_wave(hipStream_t st, uint32_t n_streams, const float2* fft_in, const float2* tw4096, float2* spec, float* power,
-                          SpectrumStatsDev* stats, const StreamCall* call, double rate, int bins_sep);
+                          SpectrumStatsDev* stats, const StreamCall* call, double rate, int bins_sep, uint32_t seq);
 
 // ---- launchers of the mode-dependent kernels, once per arithmetic mode (arith.h)
 namespace exact {

@@ -47,7 +47,7 @@ __device__ __forceinline__ void block_argmax(float& v, int& idx, float* sv, int*
 
 __global__ __launch_bounds__(kSpecLanes) void k_spectrum_commit(const float2* __restrict__ raw, float2* __restrict__ spec,
                                                                   float* __restrict__ power, SpectrumStatsDev* __restrict__ stats,
-                                                                  const StreamCall* __restrict__ call, double rate, int bins_sep)
+                                                                  const StreamCall* __restrict__ call, double rate, int bins_sep, const uint32_t seq)
 {
     __shared__ float P[kFftBins];
     __shared__ double dscratch[4];
@@ -110,16 +110,19 @@ __global__ __launch_bounds__(kSpecLanes) void k_spectrum_commit(const float2* __
         if (b < a) { const int ti = a; a = b; b = ti; const float tv = av; av = bvv; bvv = tv; }
         SpectrumStatsDev o;
         o.valid = bad ? 0 : 1;
-        o.peak1 = a; o.peak2 = b; o.power1 = av; o.power2 = bvv; o._pad = 0.f;
+        o.peak1 = a; o.peak2 = b; o.power1 = av; o.power2 = bvv; o.seq = 0u;
         o.mean = mean; o.sigma = sigma;
         stats[s] = o;
+        // the call's tag, last: behind a wait for the stores above (the statistics live in mapped host memory; the engine's events carry no system fence)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&stats[s].seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
 void launch_spectrum_commit(hipStream_t st, uint32_t n_streams, const float2* raw, float2* spec, float* power,
-                            SpectrumStatsDev* stats, const StreamCall* call, double rate, int bins_sep)
+                            SpectrumStatsDev* stats, const StreamCall* call, double rate, int bins_sep, uint32_t seq)
 {
-    hipLaunchKernelGGL(k_spectrum_commit, dim3(n_streams), dim3(kSpecLanes), 0, st, raw, spec, power, stats, call, rate, bins_sep);
+    hipLaunchKernelGGL(k_spectrum_commit, dim3(n_streams), dim3(kSpecLanes), 0, st, raw, spec, power, stats, call, rate, bins_sep, seq);
 }
 
 }  // namespace hd

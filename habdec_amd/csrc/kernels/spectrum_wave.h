@@ -121,7 +121,7 @@ constexpr uint32_t kSpecWaveLds = 64 * 65 * 4;                      // the trans
 
 __device__ __forceinline__ void spectrum_wave_body(const float2* __restrict__ fft_in, const float2* __restrict__ tw4096, float2* __restrict__ spec,
                                                    float* __restrict__ power, SpectrumStatsDev* __restrict__ stats, const uint32_t s, const double rate,
-                                                   const int bins_sep, float* __restrict__ plane)
+                                                   const int bins_sep, float* __restrict__ plane, const uint32_t seq)
 {
     const uint32_t l = threadIdx.x & 63u;
     const float2* x = fft_in + (size_t)s * kFftBins;
@@ -233,9 +233,12 @@ __device__ __forceinline__ void spectrum_wave_body(const float2* __restrict__ ff
         if (pb < pa) { const int ti = pa; pa = pb; pb = ti; const float tv = av; av = bvv; bvv = tv; }
         SpectrumStatsDev o;
         o.valid = bad ? 0 : 1;
-        o.peak1 = pa; o.peak2 = pb; o.power1 = av; o.power2 = bvv; o._pad = 0.f;
+        o.peak1 = pa; o.peak2 = pb; o.power1 = av; o.power2 = bvv; o.seq = 0u;
         o.mean = mean; o.sigma = sigma;
         stats[s] = o;
+        // the call's tag, last (as k_spectrum_commit: the statistics live in mapped host memory and the host waits for the tag, not for an event's fence)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&stats[s].seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 #undef HD_SW_P
 }

@@ -46,6 +46,9 @@ extern "C" void HD_DBG_NAME(hd_debug_sym_stamps)(unsigned long long* host, size_
 constexpr int kSymLanes = 256;
 // the call's tag goes into the result slot LAST, behind a wait for the header and bit stores of the same lane (BitsHeader::seq, dev_types.h)
 #define HD_SLOT_DONE() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __hip_atomic_store(&hdr->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+// the call's discriminator checksum (BitsHeader::demod_ck): k_fir_demod's tiles left it in ck_acc; it goes into the slot and the accumulators are cleared for the next call
+#define HD_SLOT_CK() do { if (ck_acc) { hdr->demod_ck[0] = ck_acc[2 * (size_t)s]; hdr->demod_ck[1] = ck_acc[2 * (size_t)s + 1]; hdr->demod_n = m; ck_acc[2 * (size_t)s] = 0u; ck_acc[2 * (size_t)s + 1] = 0u; } \
+                          else hdr->demod_n = 0xFFFFFFFFu; } while (0)
 constexpr uint32_t kRunStrip = 512;                       // samples per run-sum step
 
 
@@ -53,7 +56,8 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
                                                         unsigned long long* __restrict__ flipmask, float* __restrict__ weight,
                                                         const SymbolParams* __restrict__ sp, const StreamCall* __restrict__ call,
                                                         uint32_t* __restrict__ slots, uint32_t slot_words,
-                                                        uint32_t* __restrict__ flips_dbg, uint32_t flips_cap, uint32_t fl_cap, const uint32_t seq)
+                                                        uint32_t* __restrict__ flips_dbg, uint32_t flips_cap, uint32_t fl_cap, const uint32_t seq,
+                                                        uint32_t* __restrict__ ck_acc /* [S][2] from k_fir_demod, or null */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // carve: [lmask: ring_cap/64 u64][flips, runinfo: fl_cap u32 each][win: span + R + 16 floats][wl: span + R floats];
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     const SymState old = sym[s];
     const SymbolParams q = sp[s];                           // (requested with the two above: one round trip, not two)
     if (!m) {                                               // symbol stage not reached this call
-        if (tid == 0) { hdr->nbits = 0; hdr->held_after = old.held; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = old.base + old.held - old.cached; hdr->demod_n = 0xFFFFFFFFu; HD_SLOT_DONE(); }
+        if (tid == 0) { hdr->nbits = 0; hdr->held_after = old.held; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = old.base + old.held - old.cached; HD_SLOT_CK(); HD_SLOT_DONE(); }
         return;
     }
     SymState st = state_after_push(old, q, m);
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
     // run finds one sweep of work instead of two -- busy streams alternate between the two kinds of call.
     const bool search = !(h < q.min_held || h < q.spb);
     if (!search && (q.min_held == 0xFFFFFFFFu || h < q.R)) {
-        if (tid == 0) { sym[s] = st; hdr->nbits = 0; hdr->held_after = h; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = st.base + h - st.cached; hdr->demod_n = 0xFFFFFFFFu; HD_SLOT_DONE(); }
+        if (tid == 0) { sym[s] = st; hdr->nbits = 0; hdr->held_after = h; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = st.base + h - st.cached; HD_SLOT_CK(); HD_SLOT_DONE(); }
         return;
     }
     const uint32_t R = q.R, rmask = ring_cap - 1;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
         if (tid == 0) {
             if ((int32_t)(pend - st.cached) > 0) st.cached = pend;
             sym[s] = st;
-            hdr->nbits = 0; hdr->held_after = h; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = end - st.cached; hdr->demod_n = 0xFFFFFFFFu; HD_SLOT_DONE();
+            hdr->nbits = 0; hdr->held_after = h; hdr->nflips = 0; hdr->overflow = 0; hdr->uncached = end - st.cached; HD_SLOT_CK(); HD_SLOT_DONE();
         }
         STAMP(2); STAMP(3); STAMP(4); STAMP(5);
         return;
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
         st.base += last;
         st.held = h - last;
         sym[s] = st;
-        hdr->nbits = nbits; hdr->held_after = st.held; hdr->nflips = nfl; hdr->overflow = overflow; hdr->uncached = end - st.cached; hdr->demod_n = 0xFFFFFFFFu; HD_SLOT_DONE();
+        hdr->nbits = nbits; hdr->held_after = st.held; hdr->nflips = nfl; hdr->overflow = overflow; hdr->uncached = end - st.cached; HD_SLOT_CK(); HD_SLOT_DONE();
 #if defined(HD_STAMP) && defined(HD_STAMP_SWEEP)
         g_sym_stamps[s * 8 + 6] = sw_acc[0]; g_sym_stamps[s * 8 + 7] = sw_acc[1];
 #elif defined(HD_STAMP)
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(kSymLanes) void k_symbols(const float* __restrict__
 
 void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t max_new, uint32_t max_R, const float* tail,
                     uint32_t ring_cap, SymState* sym, unsigned long long* flipmask, float* weight, const SymbolParams* sp,
-                    const StreamCall* call, uint32_t* slots, uint32_t slot_words, uint32_t* flips_dbg, uint32_t flips_cap, uint32_t min_R, uint32_t seq, hipEvent_t ev_stop)
+                    const StreamCall* call, uint32_t* slots, uint32_t slot_words, uint32_t* flips_dbg, uint32_t flips_cap, uint32_t min_R, uint32_t seq, hipEvent_t ev_stop, uint32_t* ck_acc)
 {
     (void)max_m; (void)max_new;
     // a flip point moves the search on by R, so a call finds at most backlog / R + 1 of them (the backlog never exceeds the ring)
@@ -437,9 +441,9 @@ void launch_symbols(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32_t
     const size_t lds = (size_t)(ring_cap / 64) * 8 + (size_t)fl_cap * 8 +
                  (size_t)(((kAvgSpan + max_R + 16 + 3) & ~3u) + ((kAvgSpan + max_R + 3) & ~3u)) * 4;
     if (ev_stop) hipExtLaunchKernelGGL(k_symbols, dim3(n_streams), dim3(kSymLanes), (uint32_t)lds, st, nullptr, ev_stop, 0u, tail, ring_cap, sym, flipmask, weight, sp, call, slots,
-                                       slot_words, flips_dbg, flips_cap, fl_cap, seq);
+                                       slot_words, flips_dbg, flips_cap, fl_cap, seq, ck_acc);
     else hipLaunchKernelGGL(k_symbols, dim3(n_streams), dim3(kSymLanes), lds, st, tail, ring_cap, sym, flipmask, weight, sp, call, slots,
-                            slot_words, flips_dbg, flips_cap, fl_cap, seq);
+                            slot_words, flips_dbg, flips_cap, fl_cap, seq, ck_acc);
 }
 
 }  // namespace HD_ARITH_NS

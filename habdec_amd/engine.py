@@ -155,6 +155,12 @@ class Engine:
         check(self.L.hd_stream_demod_checksum(self.h, s, C.byref(ci), C.byref(n), ck))
         return int(ci.value), (None if n.value == 0xFFFFFFFF else int(n.value)), int(ck[0]), int(ck[1])
 
+    def demod_checksum_total(self, s=0):
+        """(calls folded in, delivered calls without a checksum, hash): every delivered call's discriminator checksum folded into one word -- no flush."""
+        n, u, h = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        check(self.L.hd_stream_demod_checksum_total(self.h, s, C.byref(n), C.byref(u), C.byref(h)))
+        return int(n.value), int(u.value), int(h.value)
+
     def timing(self) -> dict:
         t = capi.hd_timing()
         check(self.L.hd_engine_timing(self.h, C.byref(t)))

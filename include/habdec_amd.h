@@ -171,8 +171,13 @@ size_t hd_stream_fir_taps(hd_engine* e, uint32_t stream, float* taps, size_t cap
 uint32_t hd_stream_symbol_backlog(hd_engine* e, uint32_t stream);                          /* samples held by the symbol extractor */
 /* Checksum of the discriminator output (getDemodulated(), Decoder.h:131) of the call DELIVERED last for this stream, without flushing the
  * pipeline: ck[0] = sum of the samples' bit patterns, ck[1] = sum of (i + 1) * bit pattern, mod 2^32, over n samples; *call_index counts
- * hd_process_* calls from 0.  n = 0xFFFFFFFF when the launch path that served the call does not compute it (only the stream tail does). */
+ * hd_process_* calls from 0.  n = 0xFFFFFFFF when the launch path that served the call does not compute it (the fused back end k_backend; the
+ * stream tail and the separate kernels do). */
 int hd_stream_demod_checksum(hd_engine* e, uint32_t stream, uint64_t* call_index, uint32_t* n, uint32_t ck[2]);
+/* ... and every call delivered so far folded into one word, so that a free-running batch can be compared with a CPU run call by call without reading a
+ * sample: hash = fold over the delivered calls, in order, of (n, ck[0], ck[1]) with h = (h ^ x) * 0x100000001B3 starting from 0xCBF29CE484222325 (FNV-1a over
+ * 32-bit words); *calls = calls folded in, *calls_without = delivered calls whose launch path left no checksum (not folded in). */
+int hd_stream_demod_checksum_total(hd_engine* e, uint32_t stream, uint64_t* calls, uint64_t* calls_without, uint64_t* hash);
 uint64_t hd_stream_bits_total(hd_engine* e, uint32_t stream);                              /* symbols produced since the engine was created (delivered calls) */
 uint64_t hd_stream_flip_list_full(hd_engine* e, uint32_t stream);                          /* delivered calls in which the device's flip list (512 flip points per call) filled up: the symbol search
                                                                                              * stopped there and went on in the next call -- the same bits as SymbolExtractor::operator() (SymbolExtractor.h:129-158,

@@ -652,6 +652,9 @@ struct orc_decoder {
     orc_rtty rtty;
     std::string rtty_stream, last_sentence, sentence_log, match_log, chars_log;
     uint64_t total_bits = 0;     /* symbols produced so far (bench self-check) */
+    /* every process() call's discriminator output folded into one word, the way the engine folds the checksums its kernels leave in the result slots
+     * (include/habdec_amd.h: hd_stream_demod_checksum_total): per call (n, sum of the samples' bit patterns, sum of (i + 1) * bit pattern), FNV-1a over 32-bit words */
+    uint64_t demod_hash = 0xCBF29CE484222325ull;
     /* introspection of the last call */
     std::vector<cf32> last_decimated, last_filtered;
     std::vector<float> last_demod;
@@ -705,7 +708,19 @@ void orc_decoder_push(orc_decoder* d, const float* iq, size_t n, double rate)   
 }
 void orc_decoder_reset_correction(orc_decoder* d, double c) { orc_afc_reset_correction(&d->afc, c); }
 
-void orc_decoder_process(orc_decoder* d)                       /* Decoder.h:416-638 */
+static void orc_decoder_process_body(orc_decoder* d);
+void orc_decoder_process(orc_decoder* d)
+{
+    orc_decoder_process_body(d);
+    /* test infrastructure, not reference behaviour: this call's discriminator output (empty when the low-pass did not run) folded into demod_hash */
+    uint32_t c0 = 0, c1 = 0;
+    for (size_t i = 0; i < d->last_demod.size(); ++i) {
+        uint32_t b; std::memcpy(&b, &d->last_demod[i], 4);
+        c0 += b; c1 += (uint32_t)(i + 1) * b;
+    }
+    for (const uint32_t x : {(uint32_t)d->last_demod.size(), c0, c1}) d->demod_hash = (d->demod_hash ^ x) * 0x100000001B3ull;
+}
+static void orc_decoder_process_body(orc_decoder* d)           /* Decoder.h:416-638 */
 {
     d->last_decimated.clear(); d->last_filtered.clear(); d->last_demod.clear(); d->last_bits.clear();
     if (!d->in_rate) return;
@@ -837,7 +852,7 @@ double orc_bench_run(const orc_bench_cfg* cfg, const float* const* iq, const uin
                 orc_decoder_push(d, iq[i] + 2 * (size_t)chunk_idx[c] * chunk, chunk, cfg->sampling_rate);
                 orc_decoder_process(d);
             }
-            if (r == 0) logs[i] = d->sentence_log + '\x1f' + d->chars_log + '\x1f' + std::to_string(d->total_bits);
+            if (r == 0) logs[i] = d->sentence_log + '\x1f' + d->chars_log + '\x1f' + std::to_string(d->total_bits) + '\x1f' + std::to_string(d->demod_hash);
             orc_decoder_free(d);
         }
     };

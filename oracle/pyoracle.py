@@ -473,17 +473,18 @@ def bench_run(streams, chunk_idx, chunk, repeats, *, fs, factor, baud, bits, sto
     parts = buf.value.decode("latin-1").split("\x1e")[:len(keep)]
     out = []
     for p in parts:
-        f = (p.split("\x1f") + ["", "0"])[:3]
-        out.append(BenchLog([x for x in f[0].split("\n") if x], f[1], int(f[2] or 0)))
+        f = (p.split("\x1f") + ["", "0", "0"])[:4]
+        out.append(BenchLog([x for x in f[0].split("\n") if x], f[1], int(f[2] or 0), int(f[3] or 0)))
     return dt, out
 
 
 class BenchLog(list):
     """One stream's first-pass results of bench_run: the list itself is the sentence list; .chars is every printable character the
-    decoder emitted, .bits the number of symbols it produced."""
-    def __init__(self, sentences, chars, bits):
+    decoder emitted, .bits the number of symbols it produced, .demod_hash every call's discriminator checksum folded into one word (the engine's
+    hd_stream_demod_checksum_total folds the same way)."""
+    def __init__(self, sentences, chars, bits, demod_hash=0):
         super().__init__(sentences)
-        self.chars, self.bits = chars, bits
+        self.chars, self.bits, self.demod_hash = chars, bits, demod_hash
 
 
 def atan2f_libm_mismatches(n=200000, seed=1):

@@ -118,6 +118,7 @@ def test_a_result_slot_without_its_tag_fails_the_engine_instead_of_delivering_st
     L.hd_debug_tail_fault_arm_no_tag()
     codes = [L.hd_process_device(h, iq.data_ptr(), CH, None, CH) for _ in range(3)]
     assert codes[0] == HD_ERR_DEVICE and all(c == HD_ERR_DEVICE for c in codes), codes
-    assert b"tag" in L.hd_last_error() or b"failed state" in L.hd_last_error(), L.hd_last_error()
+    assert b"does not carry its call's tag" in L.hd_last_error(), L.hd_last_error()      # (every later call of the failed engine names the cause it failed with)
     assert L.hd_flush(h) == HD_ERR_DEVICE
+    assert b"tag" in L.hd_last_error(), L.hd_last_error()
     L.hd_engine_destroy(h)

@@ -437,3 +437,74 @@ def test_long_idle_backlog_vent_and_parameter_change(pipeline):
     for s in range(S):
         assert eng.take_chars(s) == orcs[s].text("chars_log")
     eng.close()
+
+
+@pytest.mark.parametrize("case", ["odd_stream_count", "pushes_grow"])
+def test_tails_meet_a_launch_other_than_the_one_they_were_laid_out_for(case):
+    """in step mode a call's tails are laid out when the call is enqueued and run inside the NEXT call's launch.  Where the per-CU kernel serves the
+    shape they get its 23 KB slice of LDS -- and must not then ride in the single-wave fallback, whose workgroups own 20 KB (reads past the allocation
+    return 0, writes are dropped: wrong window sums and flips, no error).  Two ways to get there: a stream count whose tile runs never divide among the XCDs
+    (1001: every launch is the fallback -- such batches keep the 20 KB layout), and pushes that grow (16384 -> 32768 -> 65536 samples: the launch that
+    carries the last small call's tails restarts the stage-1 histories and cannot be the per-CU kernel -- those tails run as a launch of their own).  50 baud
+    with bench.py's carrier offsets: seconds of backlog, the search phase's caches full.  Free running, every call of the sampled streams compared through
+    the folded discriminator checksums, then symbols, characters and backlog."""
+    torch = pytest.importorskip("torch")
+    import bench
+    import habdec_amd
+    from oracle import pyoracle
+    w = dict(bench.WORKLOADS["cfg4"])
+    S = 1001 if case == "odd_stream_count" else 1024
+    fs = w["fs"]
+    ring, ring_chunks, _ = bench.generate_ring(torch, torch.device("cuda", 0), w, S, 0, seed=4242)
+    sizes = [C] * 40 if case == "odd_stream_count" else [16384] * 12 + [32768] * 12 + [C] * 12
+    check = [0, 1, 7, 15, 127, 500, 503, 775, S - 2, S - 1]
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"],
+                            lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], pipeline=1)
+    orcs = {s: pyoracle.Decoder("oracle", factor=w["D"], baud=w["baud"], bits=w["bits"], stops=w["stops"], lowpass_bw=w["lp_bw"]) for s in check}
+    host = {s: ring[:, s].cpu().numpy().view(np.complex64).reshape(ring_chunks, C) for s in check}
+    want = {s: 0xCBF29CE484222325 for s in check}
+    obits = {s: 0 for s in check}
+    variants = set()
+    for k, n in enumerate(sizes):
+        eng.process_device(ring[k % ring_chunks].data_ptr(), C, n)
+        variants.add((eng.timing()["path"], eng.timing()["step_variant"]))
+        for s, o in orcs.items():
+            o(host[s][k % ring_chunks][:n], fs)
+            obits[s] += len(o.bits())
+            d = o.array("last_demod").view(np.uint32).astype(np.uint64)
+            for x in (len(d), int(d.sum() & 0xFFFFFFFF), int((d * np.arange(1, len(d) + 1, dtype=np.uint64)).sum() & 0xFFFFFFFF)):
+                want[s] = ((want[s] ^ x) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    eng.flush()
+    assert all(p == 3 for p, _ in variants), variants
+    if case == "odd_stream_count":
+        assert variants == {(3, 0)}, variants                  # never the per-CU kernel
+    else:
+        assert (3, 1) in variants and (3, 0) in variants, variants     # both kernels took turns
+    for s, o in orcs.items():
+        ncalls, unknown, h = eng.demod_checksum_total(s)
+        assert (ncalls, unknown) == (len(sizes), 0), (s, ncalls, unknown)
+        assert h == want[s], ("discriminator output of some call differs", s)
+        assert eng.bits_total(s) == obits[s], ("symbols produced", s)
+        assert eng.take_chars(s) == o.text("chars_log"), ("chars", s)
+        assert eng.symbol_backlog(s) == o.symex_held(), ("backlog", s)
+    assert sum(obits.values()) > 100
+    eng.close()
+    del ring
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name,steps", [("cfg4", 40), ("cfg2", 12), ("cfg3", 12), ("cfg5", 4)])
+def test_every_stream_of_the_workload_against_the_oracle(name, steps):
+    """bench.py's own loop at the workload's FULL stream count inside the suite -- symbols produced, characters, sentences and (through the
+    folded checksums the kernels leave in the result slots) every call's discriminator output bit for bit, for every stream of the shard over every step the
+    engine took (cfg4: 1024 streams through k_step_cu; cfg2 / cfg3 / cfg5: the separate kernels on two queues)."""
+    torch = pytest.importorskip("torch")
+    import bench
+    r = bench.run_workload(torch, None, torch.device("cuda", 0), 0, 0, 1, name, steps, 2, 0, False, cpu_leg="check_all", prewarm=0)
+    cb = r["cpu_baseline"]
+    S = bench.WORKLOADS[name]["S"]
+    assert r["arith"] == "exact" and cb["all_streams_of_the_shard"] is True and cb["streams_in_sample"] == S, cb
+    assert cb["gpu_matches_oracle_on_sample"] is True, cb
+    assert cb["discriminator_checksums_compared"] == S * cb["steps_checked"] and cb["steps_checked"] >= steps + 2, cb
+    assert cb["bits_in_sample"] > 0
+    assert r["per_rank"][0]["gpu_matches_oracle"] is True and r["all_ranks_match_oracle"] is True

@@ -13,8 +13,8 @@ KB = 1024.0
 
 
 def short(name):
-    m = re.search(r"hd::(k_\w+)(<[^>]*>)?", name)
-    if m: return m.group(1) + (m.group(2) or "").replace(" ", "")
+    m = re.search(r"hd::(?:exact::|(fast)::)?(k_\w+)(<[^>]*>)?", name)
+    if m: return m.group(2) + (m.group(3) or "").replace(" ", "") + ("[fast]" if m.group(1) else "")
     if "fft_rtc" in name: return name.split("(")[0][:60]
     return None
 

@@ -26,7 +26,8 @@ bash tools/gpu_profile.sh cfg5 --workload cfg5 > $o/profile_cfg5.log 2>&1
 } > $o/pmc_sq.txt 2>&1
 {
   echo "== tools/micro/joules.py: board power (hwmon) x time per step over >= 3 s loops, one box"
-  timeout 200 python3 tools/micro/joules.py idle default default+s1:HD_CU_EXP=1 default+tails:HD_CU_EXP=2 2>&1 | grep -v amdgpu.ids
+  HD_BUILD_VARIANT=timingexp python3 -m habdec_amd.build > /dev/null 2>&1
+  timeout 300 python3 tools/micro/joules.py idle default default+f:ARITH=1 timingexp+s1:HD_CU_EXP=1 timingexp+tails:HD_CU_EXP=2 2>&1 | grep -v amdgpu.ids
   timeout 100 python3 tools/micro/joules.py --sync default 2>&1 | tail -1
   for w in cfg1 cfg2 cfg3 cfg5; do timeout 100 python3 tools/micro/joules.py --workload $w default 2>&1 | tail -1 | sed "s/^default /$w    /"; done
 } > $o/joules.txt 2>&1

@@ -12,8 +12,8 @@ import csv,glob,re
 f=glob.glob('$out/**/*kernel_stats.csv',recursive=True)[0]
 for r in csv.DictReader(open(f)):
     n=r['Name']
-    m=re.search(r'hd::(k_\w+)(<[^>]*>)?',n)
-    if m or 'fft' in n: print(f"{(m.group(1)+(m.group(2) or '')) if m else n[:40]:40s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:8.1f} us  min {float(r['MinNs'])/1e3:8.1f} max {float(r['MaxNs'])/1e3:8.1f}")
+    m=re.search(r'hd::(?:exact::|(fast)::)?(k_\w+)(<[^>]*>)?',n)
+    if m or 'fft' in n: print(f"{(m.group(2)+(m.group(3) or '')+('[fast]' if m.group(1) else '')) if m else n[:40]:40s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:8.1f} us  min {float(r['MinNs'])/1e3:8.1f} max {float(r['MaxNs'])/1e3:8.1f}")
 P
 python3 -c "
 import json;d=json.load(open('$out/bench.json'));print('bench', d['value'], 'MS/s', d['ms_per_step'],'ms/step')"

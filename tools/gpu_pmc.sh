@@ -13,9 +13,9 @@ f=glob.glob('$out/**/*counter_collection.csv',recursive=True)
 if not f: print(open('$out/err.log').read()[-2000:]); raise SystemExit
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f[0])):
-    m=re.search(r'hd::(k_\w+)(<[^>]*>)?',r['Kernel_Name'])
+    m=re.search(r'hd::(?:exact::|(fast)::)?(k_\w+)(<[^>]*>)?',r['Kernel_Name'])
     if not m: continue
-    acc[m.group(1)+(m.group(2) or '')][r['Counter_Name']].append(float(r['Counter_Value']))
+    acc[m.group(2)+(m.group(3) or '')+('[fast]' if m.group(1) else '')][r['Counter_Name']].append(float(r['Counter_Value']))
 for k,v in acc.items():
     n=len(next(iter(v.values())))
     if n < 5: continue

@@ -6,7 +6,7 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-args="--steps 20 --warmup 5 --no-cpu-baseline --no-also $*"   # (the driver's command; bench.py itself runs ~300 steps around the timed regions)
+args="--steps 20 --warmup 5 --no-cpu-baseline --no-also --arith exact $*"   # (the driver's command; bench.py itself runs ~300 steps around the timed regions)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o stats -- python3 $root/bench.py $args > $out/stats_bench.json 2> $out/stats.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- python3 $root/bench.py $args > $out/fetch_bench.json 2> $out/fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o write -- python3 $root/bench.py $args > $out/write_bench.json 2> $out/write.err

@@ -2,7 +2,8 @@
 runs a loop of at least --seconds; J/step = mean power x time per step.  Variants as in ab_step.py: label[:ENV=val,...], label
 `default` = the product library, anything else gpurun_in/variants/libhd_<label>.so; the pseudo-variant `idle` sleeps instead of launching.
 
-    python3 tools/micro/joules.py [--workload cfg4] [--seconds 3] [--sync] default default+s1:HD_CU_EXP=1 default+tails:HD_CU_EXP=2 idle
+    python3 tools/micro/joules.py [--workload cfg4] [--seconds 3] [--sync] default default+f:ARITH=1 timingexp+s1:HD_CU_EXP=1 timingexp+tails:HD_CU_EXP=2 idle
+(`timingexp`: HD_BUILD_VARIANT=timingexp python3 -m habdec_amd.build -- the timing-experiment build; HD_CU_EXP does not exist in the product library.  ARITH=1: the fast mode.)
 """
 import argparse, glob, os, sys, threading, time
 from pathlib import Path
@@ -58,7 +59,8 @@ def main():
         for k, x in env.items(): os.environ[k] = x
         capi._lib = load(label)
         eng = engine.Engine(n_streams=S, max_chunk=Cn, sampling_rate=w["fs"], decimation=w["D"], baud=w["baud"], rtty_bits=w["bits"], rtty_stops=w["stops"],
-                            lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"], pipeline=0 if a.sync else 2)
+                            lowpass_bw_hz=w["lp_bw"], lowpass_trans=w["lp_trans"], ungated=w["ungated"], pipeline=0 if a.sync else 2,
+                            **({"arith": int(env["ARITH"])} if "ARITH" in env else {}))
         eng.set_timing(0)
         i = 0
         t_end = time.perf_counter() + 1.0

@@ -6,8 +6,8 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 flt = sys.argv[3] if len(sys.argv) > 3 else ""
 ks = []
 for r in rows:
-    m = re.search(r"hd::(k_\w+)(<[^>]*>)?", r["Kernel_Name"])
-    name = (m.group(1) + (m.group(2) or "")) if m else ("rocfft" if "fft" in r["Kernel_Name"] else None)
+    m = re.search(r"hd::(?:exact::|(fast)::)?(k_\w+)(<[^>]*>)?", r["Kernel_Name"])
+    name = (m.group(2) + (m.group(3) or "") + ("[fast]" if m.group(1) else "")) if m else ("rocfft" if "fft" in r["Kernel_Name"] else None)
     if name and flt in name:
         ks.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Queue_Id", "?")))
 ks.sort()
