@@ -561,12 +561,18 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     tf = ROOT / "profiles" / "traffic.json"
     if tf.exists():
         try:
-            prof = json.loads(tf.read_text()).get(name + ("_sync" if sync else ""), {})
+            prof = json.loads(tf.read_text()).get(name + ("_sync" if sync else "") + ("_fast" if arith else ""), {})
             traffic = prof.get("front_kernel_hbm_bytes_per_launch")
         except Exception:
             traffic, prof = None, {}
-    if prof.get("front_kernel") != kernel.replace(" ", ""):
+    traffic_note = None
+    if prof.get("front_kernel") != kernel.replace(" ", "") + ("[fast]" if arith else ""):
         traffic, prof = None, {}                               # (the committed profile is of another kernel: say nothing rather than the wrong thing)
+    elif prof:
+        from habdec_amd.build import source_id
+        if prof.get("csrc_id") != source_id():                 # ... or of the same kernel NAME built from other sources
+            traffic_note = f"profiles/traffic.json was recorded on sources {prof.get('csrc_id')}, the loaded library's are {source_id()}: traffic and the rocprof figures are not quoted"
+            traffic, prof = None, {}
     if prof.get("rocprof_avg_launch_ms"):
         # the committed rocprofv3 --kernel-trace --stats summary of the same command (tools/collect_profiles.py): the live figure must agree with it
         rp = {"rocprof_avg_launch_ms": prof["rocprof_avg_launch_ms"], "rocprof_launches": prof.get("rocprof_launches"), "rocprof_source": prof.get("stats_source"),
@@ -606,6 +612,8 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
                            "achieved": round(tflops, 2), "peak": vpeak, "unit": "TFLOP/s", "frac": round(tflops / vpeak, 4),
                            "traffic": traffic, "algorithmic_flop_per_sample": round(flops_per_sample(w), 1),
                            "stage1_hbm": {"achieved": round(achieved, 1), "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_front_ms, 5)}}
+    if traffic_note:
+        res["roofline"]["traffic_note"] = traffic_note
     if dt * 1e3 < 50.0:
         res["pipeline"]["note"] = f"timed region is only {dt * 1e3:.1f} ms ({K} steps): start-up and the final flush weigh in; --steps 0 times one pass over the ring"
     if not sync and path in (0, 1, 2, 3):

@@ -24,6 +24,17 @@ MODE_SOURCES = ["kernels/decimate.hip", "kernels/fir_demod.hip", "kernels/backen
 ARCH = "gfx950"
 
 
+def source_id() -> str:
+    """Identity of the product library's SOURCES: sha256 over every file under csrc/ and include/habdec_amd.h (relative path + contents), first 16 hex digits.
+    tools/collect_profiles.py stores it beside the PMC traffic it records; bench.py quotes that traffic only while the sources are still the ones profiled."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(p for p in CSRC.rglob("*") if p.is_file() and p.suffix in {".hip", ".cpp", ".h", ".hpp", ".inc"}) + [HERE.parent / "include" / "habdec_amd.h"]
+    for f in files:
+        h.update(str(f.relative_to(HERE.parent)).encode()); h.update(b"\0"); h.update(f.read_bytes()); h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
 def hipcc() -> str:
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and Path(c).exists():

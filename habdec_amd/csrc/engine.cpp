@@ -168,7 +168,7 @@ struct hd_engine {
     DevBuf<float2> staging2;
     hipEvent_t ev_copy[2] = {nullptr, nullptr}, ev_staging_free[2] = {nullptr, nullptr};
     bool staging_used[2] = {false, false};
-    uint64_t host_calls = 0;
+    uint64_t host_calls = 0, host_calls_in_place = 0;   // hd_process_host calls through the staging slabs / served in place from page-locked memory
     uint32_t timing_every = 8;   // HIP-event timing on every Nth call (0 = off): each event record is a barrier packet worth ~6 us of queue time
     hd_timing last_timing{};
     rocfft_plan fft_plan = nullptr;
@@ -542,6 +542,7 @@ int hd_engine_timing(hd_engine* e, hd_timing* out)
 {
     if (!e || !out) return fail(HD_ERR_INVALID, "null argument");
     *out = e->last_timing;
+    out->host_calls_in_place = e->host_calls_in_place;
     return HD_OK;
 }
 
@@ -1227,6 +1228,14 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     return rc;
 }
 
+void* hd_pinned_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void hd_pinned_free(void* p) { if (p) (void)hipHostFree(p); }
+
 int hd_process_host(hd_engine* e, const float* iq, size_t stride, const uint32_t* n_per_stream, uint32_t n_uniform)
 {
     if (!e) return fail(HD_ERR_INVALID, "null engine");
@@ -1234,6 +1243,17 @@ int hd_process_host(hd_engine* e, const float* iq, size_t stride, const uint32_t
     std::lock_guard<std::recursive_mutex> lock(e->mtx);   // (recursive: hd_process_device below takes it again)
     if (e->in_callback) return fail(HD_ERR_INVALID, "hd_process_* cannot be called from a sentence / character callback");
     HD_HIP(hipSetDevice(e->cfg.device));
+    // Synchronous delivery from page-locked, mapped memory (hd_pinned_alloc, or any hipHostMalloc'ed / registered buffer): the kernels are done when the
+    // call returns, so the first decimation stage may read the caller's buffer in place over PCIe -- no staging copy in front of it.  (Pageable memory,
+    // batch mode -- the caller may reuse the buffer while the call is still queued -- or a base the 16-byte loads cannot take: the copy below.)
+    if (!e->cfg.pipeline && !(reinterpret_cast<uintptr_t>(iq) & 15) && !(stride & 1)) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, iq) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) {
+            ++e->host_calls_in_place;
+            return hd_process_device(e, at.devicePointer, stride, n_per_stream, n_uniform);
+        }
+        (void)hipGetLastError();                          // (an ordinary pointer: the query's error is not the call's)
+    }
     const size_t dstride = e->cfg.max_chunk;
     // validate the sizes before anything is queued (hd_process_device checks the rest and leaves every stream untouched on error)
     for (uint32_t s = 0; s < e->S; ++s)

@@ -196,9 +196,14 @@ __device__ __forceinline__ void decimate_body(const float2* __restrict__ in, siz
         // Per sweep of TO pairs: plain aligned 16-byte loads when the whole sweep lies inside this call's input (wave-uniform
         // test); only the sweeps that touch the history in front of the stream (first tile: the first ceil((T-1)/2/TO) sweeps)
         // or the end of the input take the address-selecting path.
+        // (The lane number is made opaque here: with it visible the compiler hoists every sweep's `k < NP` and address comparisons out of the tile loop as
+        // loop invariants -- dozens of scalar register pairs live across the loop, parked in vector lanes, and in k_step<32,212,2,69> two vector registers
+        // spilled to scratch for it.  Recomputing a few compares per edge tile is free.)
+        uint32_t tid_ = threadIdx.x;
+        asm volatile("" : "+v"(tid_));
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
-            const int k = threadIdx.x + it * TO;
+            const int k = (int)tid_ + it * TO;
             const long lo = xe + 2L * it * TO, hi = lo + 2L * TO;
             if (lo >= 0 && hi <= (long)n) {
                 r[it] = src[k];                              // (k < NP or not: the extra pairs of the last sweep are in range and unused)

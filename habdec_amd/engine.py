@@ -54,6 +54,9 @@ class Engine:
         if getattr(self, "h", None):
             self.L.hd_engine_destroy(self.h)
             self.h = None
+        for p in getattr(self, "_pinned", []):
+            self.L.hd_pinned_free(p)
+        self._pinned = []
 
     def __del__(self):
         try:
@@ -70,6 +73,17 @@ class Engine:
         assert iq.shape[0] == self.S
         n = iq.shape[1] if n is None else n
         check(self.L.hd_process_host(self.h, iq.ctypes.data, iq.shape[1], None, n))
+
+    def pinned_array(self, shape, dtype=np.complex64) -> np.ndarray:
+        """A numpy array in page-locked, GPU-mapped memory (hd_pinned_alloc): process_host() of a synchronous engine reads it in place over PCIe."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.L.hd_pinned_alloc(n)
+        if not p:
+            raise HabdecError("hd_pinned_alloc failed")
+        buf = (C.c_char * n).from_address(p)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", []) + [p]
+        return arr
 
     def process_device(self, dev_ptr: int, stride: int, n: int):
         check(self.L.hd_process_device(self.h, dev_ptr, stride, None, n))
@@ -166,7 +180,7 @@ class Engine:
         check(self.L.hd_engine_timing(self.h, C.byref(t)))
         return {"ms_total": t.ms_total, "ms_front": t.ms_front, "front_bytes": t.front_bytes, "samples": t.samples,
                 "host_enqueue_us": t.host_enqueue_us, "host_wait_us": t.host_wait_us, "host_text_us": t.host_text_us,
-                "timed_calls": t.timed_calls, "path": t.path, "step_variant": t.step_variant}
+                "timed_calls": t.timed_calls, "path": t.path, "step_variant": t.step_variant, "host_calls_in_place": t.host_calls_in_place}
 
     def set_timing(self, every: int):
         """HIP-event timing on every `every`-th call (0 = off); see hd_engine_set_timing."""

@@ -48,14 +48,14 @@ public:
     Decoder() = default;
     Decoder(const Decoder&) = delete;
     Decoder& operator=(const Decoder&) = delete;
-    ~Decoder() { if (engine_) hd_engine_destroy(engine_); }
+    ~Decoder() { if (engine_) hd_engine_destroy(engine_); queue_.release(); }
 
     // ---- feed
     bool pushSamples(const TIQVector& chunk)
     {
         {
             std::lock_guard<std::mutex> l(queue_mtx_);
-            queue_.insert(queue_.end(), chunk.begin(), chunk.end());
+            queue_.append(chunk.data(), chunk.size());
         }
         if (!input_rate_) input_rate_ = static_cast<float>(chunk.samplingRate());   // init(const float), first vector only
         return true;
@@ -175,30 +175,29 @@ public:
         std::string chars_now;
         {
             std::lock_guard<std::mutex> l(mtx_);
-            std::vector<TComplex> work;
-            {
-                std::lock_guard<std::mutex> q(queue_mtx_);
-                if ((int)queue_.size() < factor_) return;
-                const size_t take = queue_.size() - queue_.size() % (size_t)factor_;
-                // Inputs shorter than a decimation stage's history are undefined behaviour in the reference (Decimator.h:140-143) and
-                // refused by the engine: leave them queued until the next push has made them long enough.
-                if (take < (size_t)hd_min_chunk((uint32_t)factor_)) return;
-                work.assign(queue_.begin(), queue_.begin() + take);
-                queue_.erase(queue_.begin(), queue_.begin() + take);
-            }
-            if (!ensure_engine(work.size())) return;
+            // The queue's lock is held across the engine calls, as the reference holds its one mutex across process() (Decoder.h:209, :423: pushSamples
+            // waits while a round runs): the samples are read IN PLACE -- the queue lives in page-locked memory the GPU addresses (hd_pinned_alloc), the
+            // engine is synchronous, and hd_process_host then hands the kernels the buffer itself instead of copying it.
+            std::lock_guard<std::mutex> q(queue_mtx_);
+            if ((int)queue_.size() < factor_) return;
+            const size_t take = queue_.size() - queue_.size() % (size_t)factor_;
+            // Inputs shorter than a decimation stage's history are undefined behaviour in the reference (Decimator.h:140-143) and
+            // refused by the engine: leave them queued until the next push has made them long enough.
+            if (take < (size_t)hd_min_chunk((uint32_t)factor_)) return;
+            if (!ensure_engine(take)) { queue_.consume(take); return; }     // (no device: the samples are dropped, as before)
             events_ = &fire;
             size_t done = 0;
-            while (done < work.size()) {                     // one engine call per max_chunk (a single call in normal use)
-                size_t n = std::min(work.size() - done, (size_t)max_chunk_);
-                const size_t left = work.size() - done - n;
+            while (done < take) {                            // one engine call per max_chunk (a single call in normal use)
+                size_t n = std::min(take - done, (size_t)max_chunk_);
+                const size_t left = take - done - n;
                 if (left && left < (size_t)hd_min_chunk((uint32_t)factor_)) n -= (size_t)hd_min_chunk((uint32_t)factor_);   // never leave a too-short last call
-                if (hd_process_host(engine_, reinterpret_cast<const float*>(work.data() + done), n, nullptr, (uint32_t)n) != HD_OK) {
+                if (hd_process_host(engine_, reinterpret_cast<const float*>(queue_.front() + done), n, nullptr, (uint32_t)n) != HD_OK) {
                     std::cout << "habdec_amd: " << hd_last_error() << std::endl;
                     break;
                 }
                 done += n;
             }
+            queue_.consume(take);
             events_ = nullptr;
             // character_callback_: at most every 250 ms, like the reference (Decoder.h:617-629)
             const auto now = std::chrono::steady_clock::now();
@@ -320,8 +319,42 @@ private:
     hd_engine* engine_ = nullptr;
     std::vector<Event>* events_ = nullptr;   // where the engine's sentence callback parks its events during process()
     mutable std::mutex mtx_;                 // process() vs. getters/setters from the server thread
+    // iq_in_buffer_ (Decoder.h:206-219) as one linear buffer in page-locked, GPU-mapped memory (ordinary memory where that cannot be had): samples are
+    // appended behind `tail`, a round consumes a prefix; what is left (less than one decimation factor, normally) is moved to the front when the space
+    // behind `tail` runs out.  Always accessed under queue_mtx_.
+    struct InputQueue {
+        TComplex* p = nullptr;
+        size_t cap = 0, head = 0, tail = 0;
+        bool pinned = false;
+        size_t size() const { return tail - head; }
+        const TComplex* front() const { return p + head; }
+        void consume(size_t n) { head += n; if (head == tail) head = tail = 0; }
+        void release() { if (p) { if (pinned) hd_pinned_free(p); else std::free(p); } p = nullptr; cap = head = tail = 0; }
+        void append(const TComplex* x, size_t n)
+        {
+            if (tail + n > cap) {
+                const size_t keep = tail - head;
+                // (the kept samples start at an EVEN index again: the engine's 16-byte loads want the base of a round aligned)
+                if (keep + n <= cap) { std::memmove(p, p + head, keep * sizeof(TComplex)); }
+                else {
+                    size_t ncap = std::max<size_t>((size_t)1 << 18, cap);
+                    while (ncap < keep + n) ncap *= 2;
+                    bool npinned = true;
+                    TComplex* np_ = static_cast<TComplex*>(hd_pinned_alloc(ncap * sizeof(TComplex)));
+                    if (!np_) { npinned = false; np_ = static_cast<TComplex*>(std::malloc(ncap * sizeof(TComplex))); }
+                    if (!np_) return;                        // out of memory: the push is lost
+                    if (keep) std::memcpy(np_, p + head, keep * sizeof(TComplex));
+                    if (p) { if (pinned) hd_pinned_free(p); else std::free(p); }
+                    p = np_; cap = ncap; pinned = npinned;
+                }
+                head = 0; tail = keep;
+            }
+            std::memcpy(p + tail, x, n * sizeof(TComplex));
+            tail += n;
+        }
+    };
     std::mutex queue_mtx_;
-    std::vector<TComplex> queue_;            // iq_in_buffer_
+    InputQueue queue_;
     double input_rate_ = 0;
     int factor_ = 1;
     uint32_t max_chunk_ = 1u << 20;

@@ -125,6 +125,12 @@ void hd_set_chars_callback(hd_engine* e, hd_chars_cb cb, void* user);         /*
  * remainder queued on the host exactly like Decoder.h:429-435).  Returns after the decoded text of this
  * call has been delivered (callbacks fired, getters updated). */
 int hd_process_host(hd_engine* e, const float* iq, size_t stream_stride, const uint32_t* n_per_stream, uint32_t n);
+/* Page-locked host memory the GPU addresses in place.  An IQ buffer that lives in such memory and is handed to hd_process_host of a SYNCHRONOUS engine
+ * (pipeline = 0: the call returns when its kernels are done) is read by the first decimation stage straight over PCIe -- no staging copy inside the call
+ * (one 65536-sample push of one stream: 512 KiB in ~10 us instead of a ~40 us pageable copy in front of the kernels).  The Decoder facade keeps its input
+ * queue (the reference's iq_in_buffer_, Decoder.h:206-219) in it.  NULL when no HIP device is present or the allocation fails: use ordinary memory then. */
+void* hd_pinned_alloc(size_t bytes);
+void  hd_pinned_free(void* p);
 /* Same, but `d_iq` is DEVICE memory on the engine's GPU (HBM-resident batches; base 16-byte aligned,
  * stream_stride even). */
 int hd_process_device(hd_engine* e, const void* d_iq, size_t stream_stride, const uint32_t* n_per_stream, uint32_t n);
@@ -198,6 +204,7 @@ typedef struct hd_timing {
                              * (k_tail), 3 step kernel (k_step: stage 1 + the previous call's stream tails in one launch; ms_front is ITS duration) */
     uint32_t step_variant;  /* 1 = the kernel that touches full-rate IQ is one workgroup per CU with LDS-DMA loader waves (stage1_ring.h): k_step_cu on path 3,
                              * k_stage1_cu (stage 1 alone) on paths 0-2; 0 = single-wave / classic workgroups (k_step, k_decimate) */
+    uint64_t host_calls_in_place;   /* hd_process_host calls so far whose IQ was read in place from page-locked memory (hd_pinned_alloc): no staging copy */
 } hd_timing;
 int hd_engine_timing(hd_engine* e, hd_timing* out);
 /* Bracket the kernels with HIP events on every `every`-th call (default 8; 0 = never; 1 = every call).  Each event record is

@@ -621,3 +621,39 @@ def test_flip_list_bound_delays_bits_but_loses_none(hd):
         assert len(ob[s]) > 1000 and gb[s] == ob[s], (s, len(gb[s]), len(ob[s]))
         assert eng.symbol_backlog(s) == orcs[s].symex_held()
     eng.close()
+
+
+def test_host_pushes_from_page_locked_memory_are_read_in_place(hd):
+    """hd_pinned_alloc + hd_process_host on a synchronous engine (what the Decoder facade's input queue does since round 6): stage 1 reads the caller's
+    buffer over PCIe, no staging copy (hd_timing.host_calls_in_place counts such calls) -- and the results are those of the copying path and of the oracle.
+    In batch mode, and from a base the 16-byte loads cannot take, the same call copies as before."""
+    from oracle import pyoracle
+    S, fs = 3, 2.048e6
+    iq, _ = make_streams(S, fs, 300, 8, 2, seed0=500)
+    nch = iq.shape[1] // C
+    eng = hd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=64, keep_filtered=True)
+    pin = eng.pinned_array((S, C + 2))
+    orcs = [pyoracle.Decoder("oracle", factor=64) for _ in range(S)]
+    for k in range(nch):
+        pin[:, :C] = iq[:, k * C:(k + 1) * C]
+        hd.capi.check(eng.L.hd_process_host(eng.h, pin.ctypes.data, C + 2, None, C))
+        for s in range(S):
+            orcs[s](iq[s, k * C:(k + 1) * C], fs)
+            assert same_bits(eng.decimated(s), orcs[s].array("last_decimated")), (k, s)
+            assert same_bits(eng.demodulated(s), orcs[s].array("last_demod")), (k, s)
+    assert eng.timing()["host_calls_in_place"] == nch
+    for s in range(S):
+        assert eng.take_sentences(s) == orcs[s].sentences() and eng.take_chars(s) == orcs[s].text("chars_log")
+    # a base at an odd sample: the copying path
+    hd.capi.check(eng.L.hd_process_host(eng.h, pin.ctypes.data + 8, C + 2, None, C))
+    assert eng.timing()["host_calls_in_place"] == nch
+    eng.close()
+    # batch mode never reads in place: the caller may reuse the buffer while the call is still queued
+    eng = hd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=64, pipeline=1)
+    pin = eng.pinned_array((S, C))
+    for k in range(4):
+        pin[:] = iq[:, k * C:(k + 1) * C]
+        eng.process_host(pin)
+    eng.flush()
+    assert eng.timing()["host_calls_in_place"] == 0
+    eng.close()

@@ -54,7 +54,9 @@ def test_step_and_stage1_kernels_do_not_spill(tmp_path, fast):
     # instruction of the kernel touches -- no vector spills, no scratch_ instruction in the listing)
     k = "k_stage1_cu<54,8>"
     assert t[k]["spill"] == 0 and t[k]["scratch"] <= 32 and t[k]["vgpr"] <= 256, (k, t[k])
-    # the single-wave fallback of the step launch is allowed its two spilled registers (12 bytes of scratch), no more
-    assert t["k_step<32,212,2,69>"]["spill"] <= 2 and t["k_step<32,212,2,69>"]["scratch"] <= 12, t["k_step<32,212,2,69>"]
+    # the single-wave fallback of the step launch: no spills either (round 6: its tile loader's loop-invariant lane masks no longer live in scalar
+    # registers across the tile loop -- 12 bytes of scratch and 256 registers before)
+    for k in ("k_step<32,212,2,69>", "k_step<32,174,4,139>"):
+        assert t[k]["spill"] == 0 and t[k]["scratch"] == 0 and t[k]["vgpr"] <= 256, (k, t[k])
     # the DC blocker's 64-lane recurrence: a handful of registers, nothing spilled (fully unrolled it had parked 130 scalars)
     assert t["k_dc_remove"]["spill"] == 0 and t["k_dc_remove"]["scratch"] == 0 and t["k_dc_remove"]["vgpr"] <= 32, t["k_dc_remove"]

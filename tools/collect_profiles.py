@@ -9,6 +9,8 @@ which bench.py reports as roofline.traffic.
 import csv, json, sys, re, collections, pathlib
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from habdec_amd.build import source_id
 KB = 1024.0
 
 
@@ -70,7 +72,8 @@ def main():
                      "fetch_bytes_x2_corrected": table[front]["fetch_bytes"], "write_bytes": table[front]["write_bytes"],
                      "source": f"profiles/{rnd}_pmc_traffic.json",
                      "rocprof_avg_launch_ms": round(float(st[3]) / 1e6, 5) if st else None, "rocprof_launches": int(st[1]) if st else None,
-                     "stats_source": f"profiles/{rnd}_kernel_stats.csv"}
+                     "stats_source": f"profiles/{rnd}_kernel_stats.csv",
+                     "csrc_id": source_id()}      # the sources this was measured on: bench.py quotes the figures only while habdec_amd.build.source_id() still says so
     tf.write_text(json.dumps(cur, indent=1) + "\n")
     for b in ("stats", "fetch", "write"):
         p = src / f"{b}_bench.json"

@@ -4,7 +4,7 @@ there when the call returns, main.cpp:234-245) -- with the one-core CPU oracle b
 
 Per configuration two rates: `host_fed` -- every push hands over a HOST buffer (hd_process_host: H2D copy over PCIe included, the facade's path) -- and
 `hbm_resident` (hd_process_device on a slab already on the GPU).  The oracle decodes the same pushes on one thread; characters, sentences and the last
-discriminator output must be identical.  One JSON line per configuration (-> profiles/r05_single_stream.jsonl).
+discriminator output must be identical.  One JSON line per configuration (-> profiles/r06_single_stream.jsonl).
 
     python3 tools/single_stream.py [--pushes 300]
 """
@@ -49,6 +49,20 @@ def main():
         chars_host, sent_host, demod_host = eng.take_chars(0), eng.take_sentences(0), eng.demodulated(0)
         path = eng.timing()["path"]
         eng.close()
+        # --- host-fed from page-locked memory (what the Decoder facade's input queue lives in since round 6: hd_pinned_alloc): read in place by stage 1, no copy
+        eng = habdec_amd.Engine(**kw)
+        pin = eng.pinned_array((nchunks, C))
+        pin[:] = iq.reshape(nchunks, C)
+        for k in range(10): eng.process_host(pin[k % nchunks][None, :])
+        eng.flush()
+        c0 = eng.timing()["host_calls_in_place"]
+        _ = eng.take_chars(0), eng.take_sentences(0)
+        t0 = time.perf_counter()
+        for k in pushes: eng.process_host(pin[k][None, :])
+        eng.flush()
+        dt_pin = time.perf_counter() - t0
+        in_place = eng.timing()["host_calls_in_place"] - c0
+        eng.close()
         # --- HBM-resident
         slab = torch.from_numpy(iq.view(np.float32).reshape(nchunks, C, 2)).cuda()
         eng = habdec_amd.Engine(**kw)
@@ -67,6 +81,8 @@ def main():
                 np.array_equal(demod_host.view(np.uint32), o.array("last_demod").view(np.uint32)))
         print(json.dumps({"workload": f"{cfg['name']}: {cfg['desc']}", "streams": 1, "mode": "sync (text delivered by the call that pushed the samples)", "chunk_samples": C, "pushes": N,
                           "host_fed": {"value": round(N * C / dt_host / 1e6, 1), "unit": "MS/s", "us_per_push": round(dt_host / N * 1e6, 1), "note": "hd_process_host: pageable host buffer, H2D over PCIe inside the call"},
+                          "host_fed_pinned": {"value": round(N * C / dt_pin / 1e6, 1), "unit": "MS/s", "us_per_push": round(dt_pin / N * 1e6, 1), "calls_read_in_place": int(in_place),
+                                              "note": "hd_process_host on hd_pinned_alloc memory (the facade's input queue): stage 1 reads the buffer over PCIe, no staging copy"},
                           "hbm_resident": {"value": round(N * C / dt_dev / 1e6, 1), "unit": "MS/s", "us_per_push": round(dt_dev / N * 1e6, 1)},
                           "cpu_baseline": {"value": round(N * C / dt_cpu / 1e6, 1), "unit": "MS/s", "cores": 1, "kind": "port", "us_per_push": round(dt_cpu / N * 1e6, 1),
                                            "sample": f"the same {N} pushes through oracle/liboracle.so on one thread"},
