@@ -723,13 +723,17 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
             dist.barrier()
         dt = job_time(dist if world > 1 else None, 1e-3 * (rank + 1))
+        verdicts = [{"rank": 0, "gpu_matches_oracle": None}]
         if world > 1:
+            # (the real run's last exchange: every rank's self-check verdict gathered on rank 0 -- here a placeholder per rank)
+            verdicts = [None] * world
+            dist.gather_object({"rank": rank, "gpu_matches_oracle": None}, verdicts if rank == 0 else None, dst=0)
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
             w = WORKLOADS[args.workload]; S = args.streams or w["S"]; K = args.steps or 1
             print(json.dumps({"metric": "IQ Msamples/s (batched 2.048 MS/s streams)", "value": round(world * S * w["C"] * K / dt / 1e6, 1), "unit": "MS/s", "n_gpus": world,
-                              "steps": K, "warmup": args.warmup, "dry_run": True, "slowest_rank_ms": round(dt * 1e3, 3),
+                              "steps": K, "warmup": args.warmup, "dry_run": True, "slowest_rank_ms": round(dt * 1e3, 3), "per_rank": verdicts, "process_group": "gloo",
                               "shards": [[shard(r, world, S)[0], shard(r, world, S)[-1] + 1] for r in range(world)]}), flush=True)
         return
     import torch

@@ -91,6 +91,7 @@ def test_bench_gpus_n_as_a_plain_command_starts_n_ranks():
     assert line["n_gpus"] == 2 and line["dry_run"] is True and line["steps"] == 3
     assert line["shards"] == [[0, 1024], [1024, 2048]]
     assert line["slowest_rank_ms"] == pytest.approx(2.0)            # the MAX over ranks (rank r reports r + 1 ms)
+    assert [v["rank"] for v in line["per_rank"]] == [0, 1] and line["process_group"] == "gloo"     # every rank's verdict reaches rank 0's line; no RCCL
     rc1, line1, _ = _bench("--dry-run")
     assert rc1 == 0 and line1["n_gpus"] == 1
     # asked for two, started inside a one-rank job: refused, not a silently smaller run
@@ -99,3 +100,21 @@ def test_bench_gpus_n_as_a_plain_command_starts_n_ranks():
     # without GPUs the real run fails in every rank -- and so does the launcher
     rc3, line3, _ = _bench("--gpus", "2", "--steps", "1")
     assert rc3 != 0 and line3 is None
+
+
+def test_bench_under_torchrun_without_gpus_flag_adopts_the_world_size():
+    """`torchrun --nproc-per-node N bench.py` without --gpus used to stop with an error since round 5; the job's size is what was asked for."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        str(ROOT / "bench.py"), "--dry-run", "--steps", "2"], capture_output=True, text=True, timeout=300, env=e)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and lines, p.stderr[-2000:]
+    line = json.loads(lines[-1])
+    assert line["n_gpus"] == 2 and len(line["per_rank"]) == 2
