@@ -137,6 +137,7 @@ struct hd_engine {
     uint32_t step_run = 0;     // HD_STEP_RUN: tiles per drawn run (default 4, minimum 2)
     bool no_cu_step = false;   // HD_NO_CU_STEP: step launches as single-wave workgroups (k_step) instead of one workgroup per CU (k_step_cu)
     uint32_t ring_run = 0;     // HD_RING_RUN: tiles per drawn run of the per-CU ring kernels (default: pick_ring_run)
+    uint32_t ring_short_pct = 25;   // HD_RING_SHORT_PCT: share of an XCD's tiles the worker waves draw as SINGLE tiles at the end of a launch (guided hand-out; 0 = whole runs to the end)
     static constexpr uint32_t kS1Loaders = 2;   // LDS-DMA loader waves of k_stage1_cu at /8 and /4 (round 4: with the nt policy on the body rows one loader's three
                                                 // tiles in flight bound the launch -- 102.7 us with one loader, 94.7 with two, one box, alternating)
 #ifndef HD_S1_SLOTS_BATCH
@@ -327,6 +328,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     if (const char* v = getenv("HD_STEP_RUN")) e->step_run = (uint32_t)atoi(v);
     e->no_cu_step = getenv("HD_NO_CU_STEP") != nullptr;
     if (const char* v = getenv("HD_RING_RUN")) e->ring_run = (uint32_t)atoi(v);
+    if (const char* v = getenv("HD_RING_SHORT_PCT")) e->ring_short_pct = std::min<uint32_t>((uint32_t)atoi(v), 100u);
     if (const char* v = getenv("HD_TAIL_MAX_N2")) e->tail_max_n2 = (uint32_t)strtoul(v, nullptr, 0);
     {
         hipDeviceProp_t prop;
@@ -1007,6 +1009,11 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             claim.ctr = e->step_ctr.p + (size_t)(e->step_launches & 1u) * 16 * 32;
             claim.ctr_next = e->step_ctr.p + (size_t)((e->step_launches & 1u) ^ 1u) * 16 * 32;
             claim.n_xcd = n_xcd; claim.runs_per_xcd = (uint32_t)(runs / n_xcd); claim.run_len = run_len;
+            if (run_len_cu && R1 >= 32 && e->ring_short_pct) {
+                // the worker waves' guided hand-out (stage1_ring.h): the last ring_short_pct per cent of an XCD's tiles go out as single tiles
+                const uint32_t tpx = claim.runs_per_xcd * run_len, whole = (uint32_t)((uint64_t)tpx * (100u - e->ring_short_pct) / 100u) / run_len;
+                claim.tiles_per_xcd = tpx; claim.short_from = whole; claim.runs_per_xcd = whole + (tpx - whole * run_len);
+            }
             ++e->step_launches;
         }
         return claim;
@@ -1062,7 +1069,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         if (want_cu && claim.ctr) {
             const uint32_t tb = std::max(ta_step.lds_bytes, prev.valid ? prev.ta.lds_bytes : 0u);
             hd::StepClaim cl = claim;
-            if (cu_exp0 & 2) cl.runs_per_xcd = 0;
+            if (cu_exp0 & 2) { cl.runs_per_xcd = 0; cl.tiles_per_xcd = 0; cl.short_from = 0xFFFFFFFFu; }
             ev_on_dispatch = ext_events && (!ps || prev.ta.fft_tw || !prev.any_fft);
             if (sl.timed && !ev_on_dispatch) HD_HIP(hipEventRecord(sl.t1, qa));
             launched = HDK(launch_step_cu, qa, (int)R1, (int)T1, prev.valid ? prev.r2 : (int)R2, prev.valid ? prev.t2 : (int)T2, S, e->n_cus, iq, stride,

@@ -766,8 +766,10 @@ uint32_t ring_tiles(int ratio, int ntaps, uint32_t n)
 // what a publication word of the ring protocol can name (stage1_ring.h, RingCtl::pub): 24 bits of sequence number, 20 of stream, 12 of tile
 static bool ring_limits_ok(uint32_t ntiles, const StepClaim& claim, bool workers = false /* worker waves: a run may run on into the next stream */)
 {
-    const uint64_t total = (uint64_t)claim.runs_per_xcd * claim.n_xcd * claim.run_len;
-    if (workers) return ntiles && claim.run_len >= 2u && total % ntiles == 0 && total < (1ull << 32);
+    const uint64_t total = claim.tiles_per_xcd ? (uint64_t)claim.tiles_per_xcd * claim.n_xcd : (uint64_t)claim.runs_per_xcd * claim.n_xcd * claim.run_len;
+    if (workers) return ntiles && claim.run_len >= 2u && total % ntiles == 0 && total < (1ull << 32) &&
+                        (!claim.tiles_per_xcd || (uint64_t)claim.tiles_per_xcd == (uint64_t)(claim.short_from < claim.runs_per_xcd ? claim.short_from : claim.runs_per_xcd) * claim.run_len +
+                                                                                    (claim.runs_per_xcd - (claim.short_from < claim.runs_per_xcd ? claim.short_from : claim.runs_per_xcd)));
     return ntiles && ntiles <= 4096u && claim.run_len && ntiles % claim.run_len == 0 && total < (1ull << 24) && total / ntiles <= (1ull << 20);
 }
 

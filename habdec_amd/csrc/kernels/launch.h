@@ -21,6 +21,10 @@ struct StepClaim {
     unsigned int* ctr = nullptr;             // this launch's counters, [n_xcd][32]
     unsigned int* ctr_next = nullptr;        // the other set
     uint32_t n_xcd = 0, runs_per_xcd = 0, run_len = 0;
+    // Worker-wave kernels (stage1_ring.h: ring_worker) only -- guided hand-out: tickets [0, short_from) are runs of run_len tiles, the tickets behind them
+    // are SINGLE tiles, so that the end of a launch is ragged by one tile's time instead of one run's (runs_per_xcd counts the tickets of both kinds;
+    // tiles_per_xcd = short_from * run_len + (runs_per_xcd - short_from)).  short_from = 0xFFFFFFFF: every ticket is a whole run.
+    uint32_t short_from = 0xFFFFFFFFu, tiles_per_xcd = 0;
 };
 
 // ---- the fused stream tail (tail_body.h / tail.hip): stage 2 + low-pass + discriminator + symbol extractor, one wave per stream

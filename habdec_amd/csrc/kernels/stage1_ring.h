@@ -817,15 +817,19 @@ __device__ __forceinline__ void ring_worker(const RingArgs& a, unsigned char* __
     const uint32_t xcd = xcd0 < a.claim.n_xcd ? xcd0 : a.claim.n_xcd - 1;
     unsigned int* my_ctr = a.claim.ctr + (size_t)xcd * 32;
     unsigned int* next_ctr = a.claim.ctr_next + (size_t)xcd * 32;
-    const uint32_t runs = a.claim.runs_per_xcd, run_len = a.claim.run_len;
+    // Guided hand-out (round 6): the XCD's first tickets are runs of run_len tiles (neighbouring tiles share their halo rows through the XCD's L2), its last
+    // ones single tiles -- the workers of an XCD then run dry within one tile's time of each other instead of one run's (a launch used to end over 9 us,
+    // p10 to p90 of its workgroups, with runs of four to the end).
+    const uint32_t runs = a.claim.runs_per_xcd, run_len = a.claim.run_len, short_from = a.claim.short_from < runs ? a.claim.short_from : runs;
+    const uint32_t tpx = a.claim.tiles_per_xcd ? a.claim.tiles_per_xcd : runs * run_len;
     auto draw = [&]() -> unsigned int { unsigned int t = 0; if (lane == 0) t = __hip_atomic_fetch_add(my_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return t; };
-    uint32_t s = 0, tile = 0, left = 0;             // the run's cursor: (s, tile) is the next tile to issue, `left` of the run are still to be issued
+    uint32_t s = 0, tile = 0, left = 0, this_run = 0;   // the run's cursor: (s, tile) is the next tile to issue, `left` of the run's this_run tiles are still to be issued
     auto take_run = [&](const unsigned int ticket) -> bool {          // the ticket's run, or false: the XCD's share is used up
         const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
         if (t == runs && lane == 0) (void)__hip_atomic_exchange(next_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t >= runs) return false;
-        const uint32_t g0 = (xcd * runs + t) * run_len;
-        s = g0 / a.ntiles; tile = g0 - s * a.ntiles; left = run_len;
+        const uint32_t g0 = xcd * tpx + (t < short_from ? t * run_len : short_from * run_len + (t - short_from));
+        s = g0 / a.ntiles; tile = g0 - s * a.ntiles; left = this_run = t < short_from ? run_len : 1u;
         return true;
     };
     auto advance = [&]() { ++tile; --left; if (tile == a.ntiles) { tile = 0; ++s; } };
@@ -869,7 +873,7 @@ __device__ __forceinline__ void ring_worker(const RingArgs& a, unsigned char* __
         uint32_t ns = 0, nt = 0;
         if (more) {
             ns = s; nt = tile;
-            issue(ns, nt, left == run_len); advance();
+            issue(ns, nt, left == this_run); advance();
             if (!left) ticket = draw();
         }
         RSTAMP(4);

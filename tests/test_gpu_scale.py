@@ -36,7 +36,7 @@ def headline_ring():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("shares", ["drawn", "drawn2", "fixed", "deep", "rocfft", "single_wave", "run9", "run12"])
+@pytest.mark.parametrize("shares", ["drawn", "drawn2", "fixed", "deep", "rocfft", "single_wave", "run9", "run12", "short0", "short60"])
 def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, shares):
     """shares: which step kernel serves the batch and how its stage-1 tiles are handed out -- k_step_cu (one workgroup per CU: stage-1 worker waves
     that load their own tiles with LDS-DMA and sum them with the systolic tap loop, runs of four 57-output tiles drawn from per-XCD counters: the
@@ -55,6 +55,8 @@ def test_headline_workload_through_the_step_kernel(monkeypatch, headline_ring, s
         monkeypatch.setenv("HD_NO_CU_STEP", "1")
     if shares in ("run9", "run12"):                          # k_step_cu with nine- / twelve-tile runs (fewer run changes; 36 tiles per stream and call)
         monkeypatch.setenv("HD_RING_RUN", shares[3:])
+    if shares in ("short0", "short60"):                      # the worker waves' guided hand-out: whole runs to the end of the launch / the last 60 % of an XCD's tiles as single tiles (default 25 %)
+        monkeypatch.setenv("HD_RING_SHORT_PCT", shares[5:])
     w, ring, ring_chunks = headline_ring
     S, fs = w["S"], w["fs"]
     # 7/8 of the streams are within +-200 Hz, every 8th is far off: sample both kinds (and the first / last stream of XCD blocks)

@@ -6,7 +6,7 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/pmc_$tag
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-timeout 300 rocprofv3 --pmc $ctr --output-format csv -d $out -o pmc -- python3 $root/bench.py --no-cpu-baseline --no-also "$@" > $out/bench.json 2> $out/err.log
+timeout 300 rocprofv3 --pmc $ctr --output-format csv -d $out -o pmc -- python3 $root/bench.py --no-cpu-baseline --no-also --arith exact "$@" > $out/bench.json 2> $out/err.log
 python3 - <<P
 import csv,glob,re,collections
 f=glob.glob('$out/**/*counter_collection.csv',recursive=True)

@@ -6,6 +6,8 @@ cd $GRAFT_REPO_ROOT
 rnd=$1; o=gpurun_out/headline; mkdir -p $o
 bash tools/gpu_profile.sh step > $o/profile_step.log 2>&1
 python3 tools/collect_profiles.py step ${rnd}_step cfg4 > $o/collect.log 2>&1
+bash tools/gpu_profile.sh stepfast --arith fast > $o/profile_stepfast.log 2>&1            # the same three passes on the fast mode's step launch
+python3 tools/collect_profiles.py stepfast ${rnd}_step_fast cfg4_fast > $o/collect_fast.log 2>&1
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 2>$o/driver.err | tail -1 > $o/driver_bench_line.json
 timeout 600 python3 bench.py 2>$o/default.err | tail -1 > $o/default_bench_line.json
 cp profiles/${rnd}_step_* profiles/traffic.json $o/
