@@ -29,7 +29,7 @@ class hd_afc_info(C.Structure):
 class hd_timing(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("ms_front", C.c_double), ("front_bytes", C.c_uint64), ("samples", C.c_uint64),
                 ("host_enqueue_us", C.c_double), ("host_wait_us", C.c_double), ("host_text_us", C.c_double), ("timed_calls", C.c_uint64),
-                ("path", C.c_uint32), ("step_variant", C.c_uint32), ("host_calls_in_place", C.c_uint64)]
+                ("path", C.c_uint32), ("step_variant", C.c_uint32), ("host_calls_in_place", C.c_uint64), ("lowpass_fft_calls", C.c_uint64)]
 
 
 SENTENCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p)

@@ -174,6 +174,18 @@ struct hd_engine {
     hd_timing last_timing{};
     rocfft_plan fft_plan = nullptr;
     rocfft_execution_info fft_info = nullptr;
+    // Fast mode, long low-pass filters (>= kLpFftMinTaps taps: configs[4]'s 4097): the filter as transforms (kernels/fir_demod.hip: k_lp_gather / k_lp_mul around
+    // rocFFT, k_fir_demod with the filtered samples handed in).  Two transform lengths, the smaller one where [history | inputs] of every stream fits it.
+    static constexpr uint32_t kLpFftMinTaps = 1024;
+    uint32_t lpf_N[2] = {0, 0};
+    rocfft_plan lpf_fwd[2] = {nullptr, nullptr}, lpf_inv[2] = {nullptr, nullptr};
+    rocfft_execution_info lpf_info = nullptr;
+    DevBuf<char> lpf_workbuf;
+    DevBuf<float2> lpf_x, lpf_k;           // [S][lpf_N[1]]: the input images / filtered samples of the call in the back half; the taps' spectra
+    PinBuf<uint32_t> lpf_ntaps;            // [S]: tap counts the spectra in lpf_k were made from
+    uint32_t lpf_k_N = 0;                  // ... and the transform length (0: none yet)
+    bool lpf_k_stale = true;
+    uint64_t lpf_calls = 0;
     DevBuf<char> fft_work;
 
     DevBuf<float2> staging, dec1, dec1b, dec1c, hist1[2], hist2[2], fbuf[3], fft_in, fft_raw, spec, filtered;   // dec1/b/c: stage-1 output, rotating per call
@@ -223,6 +235,8 @@ struct hd_engine {
     {
         if (fft_plan) rocfft_plan_destroy(fft_plan);
         if (fft_info) rocfft_execution_info_destroy(fft_info);
+        for (rocfft_plan pl : {lpf_fwd[0], lpf_fwd[1], lpf_inv[0], lpf_inv[1]}) if (pl) rocfft_plan_destroy(pl);
+        if (lpf_info) rocfft_execution_info_destroy(lpf_info);
         if (qa) (void)hipStreamDestroy(qa);
         if (qb && qb != qa) (void)hipStreamDestroy(qb);
         if (qc && qc != qa) (void)hipStreamDestroy(qc);
@@ -479,6 +493,25 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         }
         rocfft_execution_info_set_stream(e->fft_info, e->qa);
     }
+    if (e->fast && e->taps_cap >= hd_engine::kLpFftMinTaps && getenv("HD_NO_LP_FFT") == nullptr) {     // (HD_NO_LP_FFT=1: long filters as direct sums in fast mode too)
+        std::call_once(g_rocfft_once, [] { rocfft_setup(); });
+        uint32_t N = 1;
+        while (N < m_cap + e->taps_cap) N <<= 1;
+        e->lpf_N[1] = N; e->lpf_N[0] = N / 2;
+        size_t wmax = 0;
+        for (int w = 0; w < 2; ++w) {
+            const size_t len = e->lpf_N[w];
+            if (rocfft_plan_create(&e->lpf_fwd[w], rocfft_placement_inplace, rocfft_transform_type_complex_forward, rocfft_precision_single, 1, &len, S, nullptr) != rocfft_status_success ||
+                rocfft_plan_create(&e->lpf_inv[w], rocfft_placement_inplace, rocfft_transform_type_complex_inverse, rocfft_precision_single, 1, &len, S, nullptr) != rocfft_status_success)
+                return fail(HD_ERR_DEVICE, "rocfft_plan_create (low-pass transforms) failed");
+            for (rocfft_plan pl : {e->lpf_fwd[w], e->lpf_inv[w]}) { size_t wsz = 0; rocfft_plan_get_work_buffer_size(pl, &wsz); wmax = std::max(wmax, wsz); }
+        }
+        if (rocfft_execution_info_create(&e->lpf_info) != rocfft_status_success) return fail(HD_ERR_DEVICE, "rocfft_execution_info_create failed");
+        if (wmax) { HD_HIP(e->lpf_workbuf.alloc(wmax)); rocfft_execution_info_set_work_buffer(e->lpf_info, e->lpf_workbuf.p, wmax); }
+        HD_HIP(e->lpf_x.alloc((size_t)S * N));
+        HD_HIP(e->lpf_k.alloc((size_t)S * N));
+        HD_HIP(e->lpf_ntaps.alloc(S));
+    }
     // Pay first-use costs now (rocFFT's first execute alone stalls ~7 ms): run every kernel once on an all-idle call.
     {
         hd_engine::CallSlot& sl = e->slot[0];
@@ -545,6 +578,7 @@ int hd_engine_timing(hd_engine* e, hd_timing* out)
     if (!e || !out) return fail(HD_ERR_INVALID, "null argument");
     *out = e->last_timing;
     out->host_calls_in_place = e->host_calls_in_place;
+    out->lowpass_fft_calls = e->lpf_calls;
     return HD_OK;
 }
 
@@ -957,6 +991,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         if (!st.taps_dirty) continue;
         HD_HIP(hipMemcpyAsync(e->lp_taps.p + (size_t)s * e->taps_cap, st.lp.taps.data(), st.lp.taps.size() * 4, hipMemcpyHostToDevice, qa));
         st.taps_dirty = false;
+        e->lpf_k_stale = true;
     }
     if (e->sym_dirty) {
         uint32_t mr = 4;
@@ -1204,10 +1239,40 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             return fail(HD_ERR_INVALID, "fused back end refused a shape it was selected for");
         if (const int r = spectrum(qb)) return r;
     } else {
-        HDK(launch_fir_demod, qb, S, max_m, max_taps, fcur, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S,
+        // Fast mode, a long low-pass (configs[4]: 4097 taps): filter through transforms -- [history | inputs | zeros] of N per stream, X conj(K), back -- and hand
+        // k_fir_demod the filtered samples (it still does the discriminator, the ring append, the carries, the slide).
+        uint32_t lpN = 0;
+        // (Not the run that starts a stream's filter from zeros: a transform's rounding is ~1e-6 of the input's PEAK everywhere, and the start-up transient -- outputs
+        // that are exactly zero or tiny in the direct sum -- would come out as noise at that floor, which the discriminator turns into arbitrary phases.)
+        bool any_lp_restart = false;
+        for (uint32_t s = 0; s < S && !any_lp_restart; ++s) any_lp_restart = sl.h_call.p[s].fir_m && sl.h_call.p[s].fir_zero_hist;
+        if (e->fast && e->lpf_N[1] && max_taps >= hd_engine::kLpFftMinTaps && max_m && !any_lp_restart) {
+            const uint32_t Lmax = max_m + max_taps - 1;
+            const int w = Lmax <= e->lpf_N[0] ? 0 : Lmax <= e->lpf_N[1] ? 1 : -1;
+            if (w >= 0) {
+                lpN = e->lpf_N[w];
+                rocfft_execution_info_set_stream(e->lpf_info, qb);
+                if (e->lpf_k_stale || e->lpf_k_N != lpN) {           // the taps' spectra, once per design and transform length (a design change has drained the pipeline)
+                    for (uint32_t s = 0; s < S; ++s) e->lpf_ntaps.p[s] = (uint32_t)e->st[s].lp.taps.size();
+                    HDK(launch_lp_taps_gather, qb, S, e->lp_taps.p, e->taps_cap, e->lpf_ntaps.dev, e->lpf_k.p, lpN);
+                    void* kb[1] = {e->lpf_k.p};
+                    if (rocfft_execute(e->lpf_fwd[w], kb, nullptr, e->lpf_info) != rocfft_status_success) return fail(HD_ERR_DEVICE, "rocfft_execute (low-pass taps) failed");
+                    e->lpf_k_N = lpN; e->lpf_k_stale = false;
+                }
+                HDK(launch_lp_gather, qb, S, fcur, e->fbuf_stride, e->lpf_x.p, lpN, dcall, e->fir_hist_cap, e->fir_head.p + (size_t)cin * S * e->head_cap,
+                    e->fir_head_n.p + (size_t)cin * S, e->head_cap);
+                void* xb[1] = {e->lpf_x.p};
+                if (rocfft_execute(e->lpf_fwd[w], xb, nullptr, e->lpf_info) != rocfft_status_success) return fail(HD_ERR_DEVICE, "rocfft_execute (low-pass forward) failed");
+                HDK(launch_lp_mul, qb, S, e->lpf_x.p, e->lpf_k.p, lpN, dcall);
+                if (rocfft_execute(e->lpf_inv[w], xb, nullptr, e->lpf_info) != rocfft_status_success) return fail(HD_ERR_DEVICE, "rocfft_execute (low-pass inverse) failed");
+                ++e->lpf_calls;
+            }
+        }
+        HDK(launch_fir_demod, qb, S, max_m, lpN ? 0u : max_taps, fcur, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S,
                              e->cfg.keep_filtered ? e->filtered.p : nullptr, e->carry[cin].p, e->carry[cout].p, dcall, e->fir_hist_cap,
                              e->tail.p, e->tail_cap, e->d_symstate.p, fnext, e->fir_head.p + (size_t)cin * S * e->head_cap, e->fir_head_n.p + (size_t)cin * S,
-                             e->fir_head.p + (size_t)cout * S * e->head_cap, e->fir_head_n.p + (size_t)cout * S, e->head_cap, e->demod_ck_acc.p);
+                             e->fir_head.p + (size_t)cout * S * e->head_cap, e->fir_head_n.p + (size_t)cout * S, e->head_cap, e->demod_ck_acc.p,
+                             lpN ? e->lpf_x.p : nullptr, lpN, lpN ? 1.0f / (float)lpN : 1.0f);
     }
     if (!tail)
     HDK(launch_symbols, qb, S, max_m, max_new, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p,

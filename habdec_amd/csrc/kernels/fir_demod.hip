@@ -79,7 +79,9 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
                                                           const SymState* __restrict__ sym, float2* __restrict__ fbuf_next,
                                                           const float2* __restrict__ head_in, const uint32_t* __restrict__ head_n_in,
                                                           float2* __restrict__ head_out, uint32_t* __restrict__ head_n_out, uint32_t head_cap,
-                                                          uint32_t* __restrict__ ck_acc /* [S][2]: the call's discriminator checksum, accumulated by the stream's tiles (or null) */)
+                                                          uint32_t* __restrict__ ck_acc /* [S][2]: the call's discriminator checksum, accumulated by the stream's tiles (or null) */,
+                                                          const float2* __restrict__ pre /* fast mode, long filters: the low-pass output already computed by FFT (k_lp_gather ... below), [S][pre_stride], to be scaled by pre_scale; null = filter here */,
+                                                          const uint32_t pre_stride, const float pre_scale)
 {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];   // [kFirTile + T + kFirSlack] inputs, then reused for outputs
     __shared__ uint32_t s_ck[2];
@@ -118,6 +120,21 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
     if (i0 + kFirOut >= (long)m) return;
     const long b0 = (long)fir_hist_cap - (long)(T - 1) + i0;       // buffer index of tile-local sample 0
     const uint32_t live = (uint32_t)min((long)kFirTile, (long)m - i0);   // outputs of this tile that exist
+    const bool active = (uint32_t)kFirOut * threadIdx.x < live;
+    fd_f32x2 acc[kFirOut];
+#pragma unroll
+    for (int q = 0; q < kFirOut; ++q) acc[q] = fd_f32x2{0.f, 0.f};
+    if (pre) {
+        // the filtered samples exist already (the transform route): this kernel is the discriminator, the symbol ring's append, the carries and the slide
+        if (active) {
+            const float2* ps = pre + (size_t)s * pre_stride;
+#pragma unroll
+            for (int q = 0; q < kFirOut; ++q) {
+                const long i = i0 + (long)kFirOut * (long)threadIdx.x + q;
+                if (i >= 0 && i < (long)m) { const float2 v = ps[i]; acc[q] = fd_f32x2{v.x * pre_scale, v.y * pre_scale}; }
+            }
+        }
+    } else {
     const uint32_t need = ((live + (uint32_t)kFirOut - 1u) / (uint32_t)kFirOut) * (uint32_t)kFirOut + T + kFirSlack;   // + what whole blocks read past the last tap (zero-filled)
     const long end = (long)fir_hist_cap + (long)m;                 // one past the last valid input
     constexpr int LB = 4;                                          // loads in flight per lane before the first LDS store
@@ -150,10 +167,6 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
 
     typedef const float __attribute__((address_space(4)))* ctaps_t;
     const ctaps_t tp = (ctaps_t)(uintptr_t)(taps + (size_t)s * taps_stride);   // per stream, wave-uniform: scalar loads
-    const bool active = (uint32_t)kFirOut * threadIdx.x < live;
-    fd_f32x2 acc[kFirOut];
-#pragma unroll
-    for (int q = 0; q < kFirOut; ++q) acc[q] = fd_f32x2{0.f, 0.f};
     if (active) {
         // lane l's outputs 6l .. 6l+5 take samples 6l + t + q: a rolling window of twenty-two samples per sixteen taps, eleven 16-byte reads per
         // block of 192 packed operations, the next block's samples and taps requested before this block's arithmetic.
@@ -190,6 +203,7 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
 #pragma unroll
             for (int q = 0; q < kFirOut; ++q) acc[q] = acc[q] + pr[q];
         }
+    }
     }
     FSTAMP(2);
     __syncthreads();                       // everyone is done reading inputs: reuse LDS for the outputs
@@ -285,13 +299,75 @@ void launch_fir_demod(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32
                       const float* taps, uint32_t taps_stride, float* demod, size_t demod_stride, float2* filtered,
                       const DemodCarry* carry_in, DemodCarry* carry_out, const StreamCall* call, uint32_t fir_hist_cap,
                       float* sym_ring, uint32_t ring_cap, const SymState* sym, float2* fbuf_next,
-                      const float2* head_in, const uint32_t* head_n_in, float2* head_out, uint32_t* head_n_out, uint32_t head_cap, uint32_t* ck_acc)
+                      const float2* head_in, const uint32_t* head_n_in, float2* head_out, uint32_t* head_n_out, uint32_t head_cap, uint32_t* ck_acc,
+                      const float2* pre, uint32_t pre_stride, float pre_scale)
 {
     const uint32_t tiles = max_m ? (max_m + kFirAdvance - 1) / kFirAdvance : 1;
     const size_t lds = (size_t)(kFirTile + (max_taps ? max_taps : 1) + kFirSlack + 4) * sizeof(float2);
     dim3 grid(tiles, n_streams);
     hipLaunchKernelGGL(k_fir_demod, grid, dim3(kFirLanes), lds, st, fbuf, stride, taps, taps_stride, demod, demod_stride, filtered,
-                       carry_in, carry_out, call, fir_hist_cap, sym_ring, ring_cap, sym, fbuf_next, head_in, head_n_in, head_out, head_n_out, head_cap, ck_acc);
+                       carry_in, carry_out, call, fir_hist_cap, sym_ring, ring_cap, sym, fbuf_next, head_in, head_n_in, head_out, head_n_out, head_cap, ck_acc, pre, pre_stride, pre_scale);
+}
+
+// ---- Fast mode, long low-pass filters (configs[4]: 4097 taps over 4096 samples per call = 67 MFLOP per stream and call done directly): the same correlation
+// y[i] = sum_t buf[i + t] tap[t] (FirFilter.h:155-161) through N-point transforms -- x = [history (T-1) | the run's m inputs | zeros], Y = IFFT(FFT(x) conj(FFT(taps))),
+// y[i] = Y[i] / N for i < m (no wrap-around: T - 1 + m <= N).  rocFFT does the transforms in place on a [S][N] work buffer; these kernels build the input image --
+// with the history exactly as k_fir_demod's tile loader builds it: zeros on a restart (Q5), the FirHistory reconstruction after a tap-count change -- and
+// multiply the spectra; k_fir_demod then runs with `pre` set.  The result differs from the direct sum by the transforms' rounding (~1e-6 of the input's peak,
+// tests/test_gpu_fast.py); the exact mode never takes this route.
+__global__ __launch_bounds__(256) void k_lp_gather(const float2* __restrict__ fbuf, size_t stride, float2* __restrict__ work, uint32_t N, const StreamCall* __restrict__ call,
+                                                    uint32_t fir_hist_cap, const float2* __restrict__ head_in, const uint32_t* __restrict__ head_n_in, uint32_t head_cap)
+{
+    const uint32_t s = blockIdx.y;
+    const StreamCall c = call[s];
+    const uint32_t m = c.fir_m, T = c.fir_taps;
+    if (!m || !T) return;
+    const uint32_t Tp = c.fir_taps_prev ? c.fir_taps_prev : T, H = T - 1, L = H + m;
+    const float2* buf = fbuf + (size_t)s * stride;
+    const bool refold = Tp != T && !c.fir_zero_hist;
+    const uint32_t head_n = refold ? head_n_in[s] : 0u;
+    float2* w = work + (size_t)s * N;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < N; j += gridDim.x * 256u) {
+        float2 v = make_float2(0.f, 0.f);
+        if (j < L) {
+            if (j >= H) v = buf[fir_hist_cap + (j - H)];                     // the run's inputs: pending + new decimated samples
+            else if (c.fir_zero_hist) v = make_float2(0.f, 0.f);              // history restarts from zeros
+            else if (!refold) v = buf[fir_hist_cap - H + j];
+            else if (j < Tp - 1) v = buf[fir_hist_cap - (Tp - 1) + j];        // first run after a tap-count change (FirHistory, dev_types.h)
+            else if (j - (Tp - 1) < head_n) v = head_in[(size_t)s * head_cap + j - (Tp - 1)];
+        }
+        w[j] = v;
+    }
+}
+// the taps as a complex sequence of N (zero-padded): transformed once per design into `kf`
+__global__ __launch_bounds__(256) void k_lp_taps_gather(const float* __restrict__ taps, uint32_t taps_stride, const uint32_t* __restrict__ ntaps, float2* __restrict__ kf, uint32_t N)
+{
+    const uint32_t s = blockIdx.y, T = ntaps[s];
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < N; j += gridDim.x * 256u)
+        kf[(size_t)s * N + j] = make_float2(j < T ? taps[(size_t)s * taps_stride + j] : 0.f, 0.f);
+}
+// X[f] *= conj(K[f])
+__global__ __launch_bounds__(256) void k_lp_mul(float2* __restrict__ work, const float2* __restrict__ kf, uint32_t N, const StreamCall* __restrict__ call)
+{
+    const uint32_t s = blockIdx.y;
+    if (!call[s].fir_m || !call[s].fir_taps) return;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < N; j += gridDim.x * 256u) {
+        const float2 x = work[(size_t)s * N + j], k = kf[(size_t)s * N + j];
+        work[(size_t)s * N + j] = make_float2(x.x * k.x + x.y * k.y, x.y * k.x - x.x * k.y);
+    }
+}
+void launch_lp_gather(hipStream_t st, uint32_t n_streams, const float2* fbuf, size_t stride, float2* work, uint32_t N, const StreamCall* call, uint32_t fir_hist_cap,
+                      const float2* head_in, const uint32_t* head_n_in, uint32_t head_cap)
+{
+    hipLaunchKernelGGL(k_lp_gather, dim3((N + 1023) / 1024, n_streams), dim3(256), 0, st, fbuf, stride, work, N, call, fir_hist_cap, head_in, head_n_in, head_cap);
+}
+void launch_lp_taps_gather(hipStream_t st, uint32_t n_streams, const float* taps, uint32_t taps_stride, const uint32_t* ntaps, float2* kf, uint32_t N)
+{
+    hipLaunchKernelGGL(k_lp_taps_gather, dim3((N + 1023) / 1024, n_streams), dim3(256), 0, st, taps, taps_stride, ntaps, kf, N);
+}
+void launch_lp_mul(hipStream_t st, uint32_t n_streams, float2* work, const float2* kf, uint32_t N, const StreamCall* call)
+{
+    hipLaunchKernelGGL(k_lp_mul, dim3((N + 1023) / 1024, n_streams), dim3(256), 0, st, work, kf, N, call);
 }
 
 void launch_fft_feed(hipStream_t st, uint32_t n_streams, const float2* fbuf, size_t stride, float2* fft_in, const StreamCall* call,

@@ -180,7 +180,7 @@ class Engine:
         check(self.L.hd_engine_timing(self.h, C.byref(t)))
         return {"ms_total": t.ms_total, "ms_front": t.ms_front, "front_bytes": t.front_bytes, "samples": t.samples,
                 "host_enqueue_us": t.host_enqueue_us, "host_wait_us": t.host_wait_us, "host_text_us": t.host_text_us,
-                "timed_calls": t.timed_calls, "path": t.path, "step_variant": t.step_variant, "host_calls_in_place": t.host_calls_in_place}
+                "timed_calls": t.timed_calls, "path": t.path, "step_variant": t.step_variant, "host_calls_in_place": t.host_calls_in_place, "lowpass_fft_calls": t.lowpass_fft_calls}
 
     def set_timing(self, every: int):
         """HIP-event timing on every `every`-th call (0 = off); see hd_engine_set_timing."""

@@ -205,6 +205,7 @@ typedef struct hd_timing {
     uint32_t step_variant;  /* 1 = the kernel that touches full-rate IQ is one workgroup per CU with LDS-DMA loader waves (stage1_ring.h): k_step_cu on path 3,
                              * k_stage1_cu (stage 1 alone) on paths 0-2; 0 = single-wave / classic workgroups (k_step, k_decimate) */
     uint64_t host_calls_in_place;   /* hd_process_host calls so far whose IQ was read in place from page-locked memory (hd_pinned_alloc): no staging copy */
+    uint64_t lowpass_fft_calls;     /* calls so far whose low-pass ran through transforms (fast mode, >= 1024 taps: configs[4]'s 4097-tap filter) */
 } hd_timing;
 int hd_engine_timing(hd_engine* e, hd_timing* out);
 /* Bracket the kernels with HIP events on every `every`-th call (default 8; 0 = never; 1 = every call).  Each event record is

@@ -117,13 +117,52 @@ def test_fast_mode_every_decimation_plan(hd, factor):
     run_fast(hd, iq, fs, factor=factor, baud=300, bits=8, stops=2, ungated=True)
 
 
-def test_fast_mode_4097_tap_lowpass(hd):
-    """configs[4] shape: 10 MS/s, /256, lp_trans = 4/4096 -> 4097 taps (2^20-sample pushes): the longest sums of the chain."""
+@pytest.mark.parametrize("route", ["transforms", "direct"])
+def test_fast_mode_4097_tap_lowpass(hd, monkeypatch, route):
+    """configs[4] shape: 10 MS/s, /256, lp_trans = 4/4096 -> 4097 taps (2^20-sample pushes): the longest sums of the chain -- in fast mode through N-point
+    transforms (the default from 1024 taps on; every run but the one that starts the filter from zeros), or as direct fused multiply-add sums (HD_NO_LP_FFT=1)."""
+    if route == "direct":
+        monkeypatch.setenv("HD_NO_LP_FFT", "1")
     S, fs, big = 2, 10e6, 1 << 20
     b = synth.rtty_bits(synth.make_sentence("BIG", "1,2,3") * 2, 8, 2, 4, 4)
     iq = np.stack([synth.fsk_iq(b, fs, 300, sigma=0.05, seed=s, n_samples=6 * big) for s in range(S)])
     eng, orcs, worst = run_fast(hd, iq, fs, factor=256, baud=300, bits=8, stops=2, lowpass_trans=4.0 / 4096, chunk=big)
     assert len(eng.fir_taps(0)) == 4097 and worst["filtered_n"] >= 6 * 2 * 4096 - 2 * 4352 and sum(len(o.text("chars_log")) for o in orcs) > 0
+    assert eng.timing()["lowpass_fft_calls"] == (5 if route == "transforms" else 0)     # (six runs; the first starts from zeros: direct)
+
+
+def test_fast_mode_long_lowpass_through_a_tap_count_change(hd):
+    """The transform route of the long low-pass across a runtime change of the tap count (4097 -> 2049 -> 4097: the reference's stale-buffer transient, FirHistory,
+    rebuilt by k_lp_gather exactly as k_fir_demod's tile loader rebuilds it) and with a DC blocker switched on in between (another launch sequence, same route):
+    floats within tolerance of the oracle's, bits and text identical."""
+    import bench
+    from oracle import pyoracle
+    S, fs, big = 2, 10e6, 1 << 20
+    b = synth.rtty_bits(synth.make_sentence("LONG", "4,5,6") * 2, 8, 2, 4, 4)
+    iq = np.stack([synth.fsk_iq(b, fs, 300, sigma=0.05, seed=40 + s, n_samples=8 * big) for s in range(S)])
+    eng = hd.Engine(n_streams=S, max_chunk=big, sampling_rate=fs, decimation=256, lowpass_trans=4.0 / 4096, keep_filtered=True, arith=1)
+    orcs = [pyoracle.Decoder("oracle", factor=256, lowpass_trans=4.0 / 4096) for _ in range(S)]
+    ntaps = set()
+    for k in range(8):
+        if k in (3, 6):
+            t = 8.0 / 4096 if k == 3 else 4.0 / 4096
+            for s in range(S):
+                hd.capi.check(eng.L.hd_stream_set_lowpass_trans(eng.h, s, t)); orcs[s].lowpass_trans(t)
+        piece = np.ascontiguousarray(iq[:, k * big:(k + 1) * big])
+        eng.process_host(piece)
+        for s in range(S):
+            o = orcs[s]
+            o(piece[s], fs)
+            ntaps.add(len(eng.fir_taps(s)))
+            assert np.array_equal(eng.fir_taps(s).view(np.uint32), o.array("fir_taps").view(np.uint32)), (k, s)
+            fo, do = o.array("last_filtered"), o.array("last_decimated")
+            assert bench.normwise(eng.decimated(s), do) <= TOL, (k, s)
+            assert bench.fir_normwise(eng.filtered(s), fo, do) <= TOL, ("filtered", k, s, bench.fir_normwise(eng.filtered(s), fo, do))
+            assert np.array_equal(eng.bits(s), o.bits()), ("bits", k, s)
+    assert len(ntaps) == 2 and min(ntaps) >= 1024, ntaps
+    assert eng.timing()["lowpass_fft_calls"] >= 7
+    for s in range(S):
+        assert eng.take_chars(s) == orcs[s].text("chars_log") and eng.take_sentences(s) == orcs[s].sentences()
 
 
 @pytest.mark.parametrize("ctx", ["mathh", "cmath"])
