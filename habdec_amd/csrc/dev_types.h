@@ -20,7 +20,8 @@ struct StreamCall {
     uint32_t pend_before;   // decimated samples already pending in front of the FIR
     uint32_t fft_fill;      // samples already collected for the next spectrum
     uint32_t fft_take;      // samples of this chunk's head to append (0..n2)
-    uint32_t fft_run;       // 1 = the spectrum buffer completes in this call
+    uint32_t fft_run;       // 1 = the spectrum buffer completes in this call; 2 = ... and this call's chunk alone fills it: the spectrum launch reads the chunk's head in place
+                            //     (fft_take = 0: nothing is copied into the collection buffer; separate-kernels path only)
     uint32_t fir_m;         // samples to filter/demodulate this call (0 = FIR does not run)
     uint32_t fir_taps;      // tap count in use
     uint32_t fir_zero_hist; // Q5 for the low-pass

@@ -130,7 +130,7 @@ struct hd_engine {
     int last_fuse = -1;
     // Step mode (batch decoding, kernels/decimate.hip k_step): the stream tails of call k ride in the stage-1 launch of call k+1.
     struct PendingTail { bool valid = false; hd::TailArgs ta{}; int slot = 0; bool any_fft = false; int r2 = 0, t2 = 0; } pend;
-    bool own_fft = false;      // HD_OWN_FFT: the spectrum as one launch of single-wave workgroups instead of rocFFT + commit where no tail does it (measured: no faster)
+    bool own_fft = false;      // the spectrum, where it is a launch of its own, as single-wave workgroups (kernels/spectrum_wave.hip) instead of rocFFT + commit: the default; HD_ROCFFT=1 without HD_OWN_FFT=1 switches it off
     bool tail_fft = true;      // a stream tail transforms its stream's completed spectrum buffer itself (kernels/spectrum_wave.h); HD_ROCFFT=1: separate launches
     DevBuf<float2> fft_tw;     // (cos, -sin)(2 pi m / 4096), rounded once from double
     bool no_claim = false;     // HD_NO_CLAIM: step launches with fixed shares of tiles (A/B measurements)
@@ -475,8 +475,10 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
             }
             HD_HIP(e->fft_tw.alloc(hd::kFftBins));
             HD_HIP(hipMemcpy(e->fft_tw.p, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
-            e->own_fft = getenv("HD_OWN_FFT") != nullptr;
             e->tail_fft = getenv("HD_ROCFFT") == nullptr;
+            // (round 6: where the spectrum is a launch of its own -- the separate-kernels path -- it is the single-wave kernel by default: it reads a chunk that
+            // fills the buffer by itself in place, and transform + commit are one pass; HD_ROCFFT=1 alone: rocFFT + k_spectrum_commit)
+            e->own_fft = e->tail_fft || getenv("HD_OWN_FFT") != nullptr;
         }
         std::call_once(g_rocfft_once, [] { rocfft_setup(); });
         const size_t len = hd::kFftBins;
@@ -665,10 +667,10 @@ int hd_stream_reset_frequency_correction(hd_engine* e, uint32_t s, double c)
 namespace {
 
 // rocFFT + commit for the streams whose 4096-sample buffer completed in the call that owns `sl` (Decoder.h:475-489)
-int transform_and_commit(hd_engine* e, hipStream_t q, hd::SpectrumStatsDev* stats_dev, const hd::StreamCall* dcall, uint32_t seq)
+int transform_and_commit(hd_engine* e, hipStream_t q, hd::SpectrumStatsDev* stats_dev, const hd::StreamCall* dcall, uint32_t seq, const float2* chunk = nullptr)
 {
     if (e->own_fft) {   // one launch, one wave per stream (kernels/spectrum_wave.hip)
-        hd::launch_spectrum_wave(q, e->S, e->fft_in.p, e->fft_tw.p, e->spec.p, e->power.p, stats_dev, dcall, e->fsd, e->bins_sep, seq);
+        hd::launch_spectrum_wave(q, e->S, e->fft_in.p, e->fft_tw.p, e->spec.p, e->power.p, stats_dev, dcall, e->fsd, e->bins_sep, seq, chunk, e->fbuf_stride, e->fir_hist_cap);
         return HD_OK;
     }
     void* in[1] = {e->fft_in.p};
@@ -960,6 +962,15 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
     }
     e->last_fuse = path;
     e->last_timing.path = (uint32_t)path;
+    if (path == 0 && e->own_fft && e->cfg.enable_spectrum && !any_dc && any_fft) {
+        // A call whose decimated chunk alone fills a stream's (empty) spectrum buffer: the spectrum launch reads the chunk's head in place and nothing is copied
+        // into the collection buffer (fft_take = 0 for the stage that would have fed it; fft_run = 2 for the spectrum kernel) -- at 4096 and more decimated
+        // samples per call that is every call: 8 + 8 bytes per decimated sample less traffic, and transform + commit are one pass instead of three.
+        for (uint32_t s = 0; s < S; ++s) {
+            hd::StreamCall& c = sl.h_call.p[s];
+            if (c.fft_run == 1 && c.fft_fill == 0 && c.fft_take == (uint32_t)hd::kFftBins) { c.fft_take = 0; c.fft_run = 2; }
+        }
+    }
     // Cross-queue event waits cost ~18 us each on this platform (kernel trace: stage 1 of call k+1 started 37 us after stage 1
     // of call k ended, two barrier packets later).  On the fused path the stage-1 queue therefore waits for NOTHING: it reads the
     // call's parameters straight from the mapped host block (32 bytes per workgroup), its output rotates over three buffers --
@@ -1208,7 +1219,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         if (!(e->cfg.enable_spectrum && max_n2)) return HD_OK;
         if (!fuse && (any_dc || nst == 0)) HDK(launch_fft_feed, q, S, fcur, e->fbuf_stride, e->fft_in.p, dcall, e->fir_hist_cap);
         if (any_fft) {   // only when some stream's 4096-sample buffer completed (every call at >= 4096 decimated samples per push)
-            if (const int r = transform_and_commit(e, q, sl.h_stats.dev, dcall, sl.seq)) return r;
+            if (const int r = transform_and_commit(e, q, sl.h_stats.dev, dcall, sl.seq, fcur)) return r;
         }
         return HD_OK;
     };

@@ -94,15 +94,19 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
     if (fbuf_next) {
         // Slide [history | leftover pending] to the front of the OTHER buffer for the next call (ping-pong instead of
         // an overlapping in-place move): next[k] = buf[k + fir_m], k < hist_cap + pend_after.  The stream's tiles share it.
+        // (Round 6: after a run only the LAST T-1 history slots are moved -- whatever tap count the next run has, it reads its history out of those and out of the
+        // FirHistory head (dev_types.h).  The whole region used to move on every call: fir_hist_cap is the filter's CAPACITY -- 133 KB per stream and call at /4,
+        // 35 KB at /16, a quarter of k_fir_demod's traffic.  A call without a run moves the buffer as it is: what the last run left is not known here.)
         float2* nx = fbuf_next + (size_t)s * stride;
-        const uint32_t cnt = fir_hist_cap + c.pend_after, off = c.clear_pending ? 0u : m;
+        const uint32_t lo = (m && T) ? fir_hist_cap - (T - 1u) : 0u;
+        const uint32_t cnt = fir_hist_cap + c.pend_after - lo, off = c.clear_pending ? 0u : m;
         constexpr int SB = 4;
         for (uint32_t k0 = blockIdx.x * kFirLanes + threadIdx.x; k0 < cnt; k0 += SB * gridDim.x * kFirLanes) {
             float2 v[SB];
 #pragma unroll
-            for (int u = 0; u < SB; ++u) { const uint32_t k = k0 + u * gridDim.x * kFirLanes; v[u] = k < cnt ? buf[k + off] : make_float2(0.f, 0.f); }
+            for (int u = 0; u < SB; ++u) { const uint32_t k = k0 + u * gridDim.x * kFirLanes; v[u] = k < cnt ? buf[lo + k + off] : make_float2(0.f, 0.f); }
 #pragma unroll
-            for (int u = 0; u < SB; ++u) { const uint32_t k = k0 + u * gridDim.x * kFirLanes; if (k < cnt) nx[k] = v[u]; }
+            for (int u = 0; u < SB; ++u) { const uint32_t k = k0 + u * gridDim.x * kFirLanes; if (k < cnt) nx[lo + k] = v[u]; }
         }
     }
     // head of this run's input for a later run with a different tap count (FirHistory, dev_types.h); an idle stream keeps its old one

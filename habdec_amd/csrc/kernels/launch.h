@@ -59,7 +59,9 @@ void launch_spectrum_commit(hipStream_t st, uint32_t n_streams, const float2* ra
                             uint32_t seq /* the call's tag, stored last into every SpectrumStatsDev written (SpectrumStatsDev::seq) */);
 // The transform and the commit in one launch, one wave per stream (kernels/spectrum_wave.hip); tw4096[m] = (cos, -sin)(2 pi m / 4096).
 void launch_spectrum_wave(hipStream_t st, uint32_t n_streams, const float2* fft_in, const float2* tw4096, float2* spec, float* power,
-                          SpectrumStatsDev* stats, const StreamCall* call, double rate, int bins_sep, uint32_t seq);
+                          SpectrumStatsDev* stats, const StreamCall* call, double rate, int bins_sep, uint32_t seq,
+                          const float2* chunk = nullptr /* the low-pass input buffers [S][chunk_stride]: streams with StreamCall::fft_run == 2 take their 4096 samples from the head of this call's decimated chunk */,
+                          size_t chunk_stride = 0, uint32_t fir_hist_cap = 0);
 
 // ---- launchers of the mode-dependent kernels, once per arithmetic mode (arith.h)
 namespace exact {

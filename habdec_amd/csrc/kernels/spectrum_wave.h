@@ -119,12 +119,13 @@ __device__ __forceinline__ void wave_argmax(float& v, int& idx)
 
 constexpr uint32_t kSpecWaveLds = 64 * 65 * 4;                      // the transpose plane
 
-__device__ __forceinline__ void spectrum_wave_body(const float2* __restrict__ fft_in, const float2* __restrict__ tw4096, float2* __restrict__ spec,
+// x: the stream's 4096 input samples (wave-uniform pointer) -- its row of the spectrum input collection, or, where one call's chunk alone fills the
+// buffer, the head of that chunk where the last decimation stage left it (StreamCall::fft_run == 2: no second copy of the samples)
+__device__ __forceinline__ void spectrum_wave_body(const float2* __restrict__ x, const float2* __restrict__ tw4096, float2* __restrict__ spec,
                                                    float* __restrict__ power, SpectrumStatsDev* __restrict__ stats, const uint32_t s, const double rate,
                                                    const int bins_sep, float* __restrict__ plane, const uint32_t seq)
 {
     const uint32_t l = threadIdx.x & 63u;
-    const float2* x = fft_in + (size_t)s * kFftBins;
     f32x2 a[64];
     // ---- pass 1: transform over n1 for this lane's n2 = l
     // (rows in groups of eight behind a scalar base the compiler cannot fold into the lane offset: one offset register and immediate

@@ -989,7 +989,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         __threadfence_block();
         tb_sync<NT>();                                                  // every wave is done with the LDS images
         if (wave == 0)
-            spectrum_wave_body(a.fft_in, a.fft_tw, a.spec, a.power, a.stats, s, a.rate, a.bins_sep, reinterpret_cast<float*>(lds + kTailHdrBytes), a.seq);
+            spectrum_wave_body(a.fft_in + (size_t)s * kFftBins, a.fft_tw, a.spec, a.power, a.stats, s, a.rate, a.bins_sep, reinterpret_cast<float*>(lds + kTailHdrBytes), a.seq);
     }
     // the call's tag, LAST: every store this wave has issued -- header, bits, spectrum statistics, all by wave 0 -- has been acknowledged before it goes out
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
