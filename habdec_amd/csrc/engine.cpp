@@ -209,12 +209,12 @@ struct hd_engine {
         PinBuf<uint32_t> h_slots;                 // written by the symbol scan kernel over PCIe (zero-copy), read after ev_done
         PinBuf<hd::SpectrumStatsDev> h_stats;    // written by the spectrum kernel
         bool timed = false, timed_step = false;   // this call carries the timing events (a step call: only the two around its one launch)
-        hipEvent_t ev_front = nullptr, ev_done = nullptr, ev_params = nullptr, t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr;
+        hipEvent_t ev_front = nullptr, ev_done = nullptr, ev_params = nullptr, ev_spec = nullptr, t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr;
         bool busy = false;
         uint32_t seq = 0;                         // this call's tag: what every result slot's BitsHeader::seq must read before the slot is taken as delivered
         uint64_t total_in = 0;
         uint32_t r1 = 1;
-        ~CallSlot() { for (hipEvent_t ev : {ev_front, ev_done, ev_params, t0, t1, t2, t3}) if (ev) (void)hipEventDestroy(ev); }
+        ~CallSlot() { for (hipEvent_t ev : {ev_front, ev_done, ev_params, ev_spec, t0, t1, t2, t3}) if (ev) (void)hipEventDestroy(ev); }
     } slot[kSlots];
     uint64_t calls = 0;
     uint64_t delivered = 0;   // calls whose results have been delivered; calls - delivered <= 2 (pipelined mode)
@@ -377,6 +377,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         HD_HIP(hipEventCreateWithFlags(&sl.ev_front, hipEventDisableTiming | ev_flags));
         HD_HIP(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming | done_flags));
         HD_HIP(hipEventCreateWithFlags(&sl.ev_params, hipEventDisableTiming | ev_flags));
+        HD_HIP(hipEventCreateWithFlags(&sl.ev_spec, hipEventDisableTiming | ev_flags));
         for (hipEvent_t* ev : {&sl.t0, &sl.t1, &sl.t2, &sl.t3}) HD_HIP(hipEventCreateWithFlags(ev, ev_flags));
     }
 
@@ -1223,11 +1224,24 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         }
         return HD_OK;
     };
+    // Where every spectrum of the call is read in place out of this call's chunk (fft_run == 2 for all of them), the spectrum launch hangs on nothing but that
+    // chunk: it goes to the third queue behind the front half's event, off the queue a step waits for (round 5 could not: the next call's second stage refilled
+    // the collection buffer a transform on another queue was still reading -- there is no collection buffer on this route).
+    bool spectrum_on_qc = false;
     if (!fuse) {
         if (any_dc) HDK(launch_dc_remove, qa, S, fcur, e->fbuf_stride, dcall, e->fir_hist_cap);
-        if (const int r = spectrum(qa)) return r;
+        if (path == 0 && !e->one_stream && e->own_fft && e->cfg.enable_spectrum && !any_dc && any_fft && nst != 0) {
+            spectrum_on_qc = true;
+            for (uint32_t s = 0; s < S && spectrum_on_qc; ++s) spectrum_on_qc = sl.h_call.p[s].fft_run != 1u;
+        }
+        if (!spectrum_on_qc) { if (const int r = spectrum(qa)) return r; }
     }
     if (!e->one_stream) HD_HIP(hipEventRecord(sl.ev_front, qa));
+    if (spectrum_on_qc) {
+        HD_HIP(hipStreamWaitEvent(e->qc, sl.ev_front, 0));
+        if (const int r = spectrum(e->qc)) return r;
+        HD_HIP(hipEventRecord(sl.ev_spec, e->qc));
+    }
     // ---- back half on qb: [stage 2 +] low-pass + discriminator + buffer slide, [spectrum,] symbol extractor, results.  It may
     // still be running when the NEXT call's front half starts on qa: the two halves touch disjoint buffers (DESIGN.md
     // "two-stream pipeline").
@@ -1291,6 +1305,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
                        fuse ? nullptr : e->demod_ck_acc.p);      // (the fused back end, k_backend, leaves no checksum: its slots say demod_n = 0xFFFFFFFF)
     if (!tail && ev_ride) done_on_dispatch = true;
     if (sl.timed) HD_HIP(hipEventRecord(sl.t3, qb));
+    if (spectrum_on_qc) HD_HIP(hipStreamWaitEvent(qb, sl.ev_spec, 0));      // the call is complete when its spectra are
     if (!done_on_dispatch) HD_HIP(hipEventRecord(sl.ev_done, qb));
     HD_HIP(hipGetLastError());
     sl.busy = true;
