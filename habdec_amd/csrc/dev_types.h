@@ -1,6 +1,12 @@
 // Structures shared by the host engine (engine.cpp) and the gfx950 kernels (kernels/*.hip).
 #pragma once
 #include <stdint.h>
+#ifndef __HIPCC__
+#ifndef __host__
+#define __host__
+#define __device__
+#endif
+#endif
 
 namespace hd {
 
@@ -28,8 +34,20 @@ struct StreamCall {
     uint32_t pend_after;    // pending decimated samples left for the next call
     uint32_t dc_remove;     // 1 = per-chunk DC blocker on the decimated chunk
     uint32_t clear_pending; // 1 = rate gate hit: drop everything pending (Decoder.h:522-527)
-    uint32_t fir_taps_prev; // tap count of the stream's previous low-pass run (== fir_taps unless the design changed; see FirHistory)
+    uint32_t fir_taps_prev; // bits 0-15: tap count of the stream's previous low-pass run (== fir_taps unless the design changed; see FirHistory);
+                            // bits 16-29: head_n, bit 30: head_prev, bit 31: head_save -- where the FirHistory head is (sc_* below)
 };
+// FirHistory head, lazily (round 6).  The head -- the first samples of the previous run's input -- is only read by the first run after a tap-count INCREASE, and
+// the previous run's input still sits where that run read it: in the low-pass buffer of the call it ran in, which nothing overwrites for two more calls (three
+// buffers take turns).  So no run writes a head any more (33 MB per step at /16, 67 at /4, 8.4 in the headline launch, for a change that may never come):
+//   head_prev = 1: the stream's previous run was the PREVIOUS call -- a consumer reads head[j] = prev_buf[fir_hist_cap + j], j < head_n;
+//   head_prev = 0: it was earlier -- the head was copied aside (head_save = 1) by the first call in which the stream did not run, and sits in the side buffer.
+__host__ __device__ inline uint32_t sc_taps_prev(const StreamCall& c) { return c.fir_taps_prev & 0xFFFFu; }
+__host__ __device__ inline uint32_t sc_head_n(const StreamCall& c) { return (c.fir_taps_prev >> 16) & 0x3FFFu; }
+__host__ __device__ inline bool sc_head_prev(const StreamCall& c) { return (c.fir_taps_prev >> 30) & 1u; }
+__host__ __device__ inline bool sc_head_save(const StreamCall& c) { return (c.fir_taps_prev >> 31) & 1u; }
+__host__ __device__ inline uint32_t sc_pack_taps_prev(uint32_t taps_prev, uint32_t head_n, bool head_prev, bool head_save)
+{ return (taps_prev & 0xFFFFu) | ((head_n & 0x3FFFu) << 16) | ((head_prev ? 1u : 0u) << 30) | ((head_save ? 1u : 0u) << 31); }
 
 // Low-pass history across a change of the tap count.  The reference keeps ONE buffer [history (T-1) | input (m)] per filter
 // (FirFilter.h:141-167): after a run its first T-1 slots hold the last T-1 inputs, the slots behind still hold the run's

@@ -88,6 +88,9 @@ struct StreamHost {
     uint64_t spectra = 0;
     size_t fir_buf = 0;             // FirFilter::buff_.size()
     uint32_t fir_T_run = 0;         // tap count of the last low-pass run (FirHistory, dev_types.h)
+    uint32_t head_n = 0;            // FirHistory head, lazily: how many samples of the last run's input a later run may ask for ...
+    uint64_t head_call = ~0ull;     // ... the call that run was in (its input sits in THAT call's low-pass buffer until the buffer's turn comes again) ...
+    bool head_aside = false;        // ... or: the head has been copied to the side buffer (the stream did not run in the call behind its last run)
     hd::LowpassDesigner lp;
     bool taps_dirty = false;
     // data-dependent state learned back from the device
@@ -194,8 +197,8 @@ struct hd_engine {
     DevBuf<uint32_t> flips_dbg;
     DevBuf<hd::SymState> d_symstate;
     DevBuf<hd::DemodCarry> carry[2];
-    DevBuf<float2> fir_head;          // [2][S][head_cap]: first samples of the previous low-pass run's input (FirHistory, dev_types.h), halves alternate like the carries
-    DevBuf<uint32_t> fir_head_n;      // [2][S]
+    DevBuf<float2> fir_head;          // [S][head_cap]: FirHistory heads moved aside -- the first samples of a stream's last low-pass run's input, copied here by the first call in
+                                      // which the stream did not run (dev_types.h: the head, lazily); a stream that ran in the previous call finds them in that call's buffer
     DevBuf<uint32_t> demod_ck_acc;    // [S][2]: the discriminator checksum of the call in the back half of the separate-kernels path (k_fir_demod adds, k_symbols collects and clears)
     uint32_t head_cap = 0;
     DevBuf<hd::SymbolParams> d_sym;
@@ -452,8 +455,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
     if (e->flips_cap) HD_HIP(e->flips_dbg.alloc((size_t)S * e->flips_cap));
     for (auto& c : e->carry) HD_HIP(c.alloc(S));
     e->head_cap = std::min<uint32_t>(e->taps_cap, 8192u);   // a tap-count jump of more than 8192 reads zeros beyond (documented)
-    HD_HIP(e->fir_head.alloc((size_t)2 * S * e->head_cap));
-    HD_HIP(e->fir_head_n.alloc((size_t)2 * S));
+    HD_HIP(e->fir_head.alloc((size_t)S * e->head_cap));
     HD_HIP(e->demod_ck_acc.alloc((size_t)2 * S));
     HD_HIP(e->d_sym.alloc(S));
     HD_HIP(e->h_sym.alloc(S));
@@ -538,7 +540,7 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         }
         HDK(launch_fir_demod, q, S, 0, 0, e->fbuf[0].p, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S, nullptr, e->carry[0].p,
                              e->carry[1].p, sl.d_call.p, e->fir_hist_cap, e->tail.p, e->tail_cap, e->d_symstate.p, e->fbuf[1].p,
-                             e->fir_head.p, e->fir_head_n.p, e->fir_head.p + (size_t)S * e->head_cap, e->fir_head_n.p + S, e->head_cap);
+                             e->fir_head.p, e->head_cap, e->fbuf[2].p);
         HDK(launch_symbols, q, S, 1, 1, e->max_R, e->tail.p, e->tail_cap, e->d_symstate.p, e->flipmask.p, e->weight.p, e->d_sym.p, sl.d_call.p,
                            sl.h_slots.dev, e->slot_words, nullptr, 0, e->min_R, 0u);
         HD_HIP(hipStreamSynchronize(q));
@@ -547,7 +549,6 @@ int hd_engine_create(const hd_engine_config* cfg, hd_engine** out)
         for (auto& h : e->hist1) if (h.p) HD_HIP(hipMemset(h.p, 0, h.n * sizeof(float2)));
         for (auto& h : e->hist2) if (h.p) HD_HIP(hipMemset(h.p, 0, h.n * sizeof(float2)));
         for (auto& c : e->carry) HD_HIP(hipMemset(c.p, 0, c.n * sizeof(hd::DemodCarry)));
-        HD_HIP(hipMemset(e->fir_head_n.p, 0, e->fir_head_n.n * sizeof(uint32_t)));
         HD_HIP(hipMemset(e->d_symstate.p, 0, S * sizeof(hd::SymState)));
         if (const char* b0 = getenv("HD_SYM_BASE0")) {
             // test hook: start every stream's monotonic 32-bit sample position somewhere else than 0 (e.g. just below 2^32, which
@@ -909,8 +910,10 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             if (T > e->taps_cap) return fail(HD_ERR_CAPACITY, "low-pass tap count exceeds engine capacity");
             if (st.fir_buf < (size_t)m + T) { st.fir_buf = (size_t)m + T; c.fir_zero_hist = 1; }   // FirFilter.h:141-147
             c.fir_m = m; c.fir_taps = T;
-            c.fir_taps_prev = st.fir_T_run ? st.fir_T_run : T;
+            // (tap count of the previous run, and where the first samples of that run's input are: in the previous call's buffer if that is where it ran, else aside)
+            c.fir_taps_prev = hd::sc_pack_taps_prev(st.fir_T_run ? st.fir_T_run : T, st.head_n, !st.head_aside && st.head_call + 1 == e->calls, false);
             st.fir_T_run = T;
+            st.head_n = std::min<uint32_t>(m, std::min<uint32_t>(e->head_cap, 0x3FFFu)); st.head_call = e->calls; st.head_aside = false;
             st.pending -= m;
             st.last_m = m;
             max_m = std::max(max_m, m);
@@ -920,6 +923,12 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
             max_new = std::max(max_new, pending_windows + m + 64u);
             st.inflight_m += m;
             st.win_ub += m;
+        }
+        if (!c.fir_m && st.head_n && !st.head_aside) {
+            // no run in this call: a head that still sits in the previous call's buffer moves aside now (that buffer is rewritten two calls on)
+            if (st.head_call + 1 == e->calls) c.fir_taps_prev = hd::sc_pack_taps_prev(0, st.head_n, false, true);
+            else st.head_n = 0;          // (cannot happen: the call behind a run either runs or saves)
+            st.head_aside = true;
         }
         c.pend_after = (uint32_t)st.pending;
         max_pend = std::max(max_pend, std::max(c.pend_before, c.pend_after));
@@ -1034,8 +1043,8 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         t.fbuf = fcur; t.fbuf_next = fnext; t.fbuf_stride = e->fbuf_stride; t.fir_hist_cap = e->fir_hist_cap;
         t.lp_taps = e->lp_taps.p; t.taps_stride = e->taps_cap; t.demod = e->demod.p; t.demod_stride = e->demod.n / S;
         t.filtered = e->cfg.keep_filtered ? e->filtered.p : nullptr; t.carry_in = e->carry[cin].p; t.carry_out = e->carry[cout].p;
-        t.call = dcall; t.fft_in = feed; t.head_buf = e->fir_head.p; t.head_cnt = e->fir_head_n.p; t.head_cap = e->head_cap;
-        t.head_par = (uint32_t)cin; t.n_streams = S;
+        t.call = dcall; t.fft_in = feed; t.head_buf = e->fir_head.p; t.fbuf_prev = e->fbuf[(e->cur + 2) % 3].p; t.head_cap = e->head_cap;
+        t.n_streams = S;
         t.ring = e->tail.p; t.ring_cap = e->tail_cap; t.sym = e->d_symstate.p; t.flipmask = e->flipmask.p; t.wsum = e->weight.p;
         t.sp = e->d_sym.p; t.slots = sl.h_slots.dev; t.slot_words = e->slot_words; t.seq = sl.seq;
         t.flips_dbg = e->flips_cap ? e->flips_dbg.p : nullptr; t.flips_cap = e->flips_cap;
@@ -1260,7 +1269,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         if (!HDK(launch_backend, qb, (int)R2, (int)T2, S, max_n1, max_n2, max_taps, d1, e->n1_cap, e->hist2[hin].p, e->hist2[hout].p,
                                 e->stage_taps[1].p, fcur, fcur, fnext, e->fbuf_stride, e->fir_hist_cap, e->lp_taps.p, e->taps_cap, e->demod.p,
                                 e->demod.n / S, e->cfg.keep_filtered ? e->filtered.p : nullptr, e->carry[cin].p, e->carry[cout].p, dcall, feed,
-                                e->tail.p, e->tail_cap, e->d_symstate.p, e->fir_head.p, e->fir_head_n.p, e->head_cap, (uint32_t)cin))
+                                e->tail.p, e->tail_cap, e->d_symstate.p, e->fir_head.p, e->head_cap, e->fbuf[(e->cur + 2) % 3].p))
             return fail(HD_ERR_INVALID, "fused back end refused a shape it was selected for");
         if (const int r = spectrum(qb)) return r;
     } else {
@@ -1284,8 +1293,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
                     if (rocfft_execute(e->lpf_fwd[w], kb, nullptr, e->lpf_info) != rocfft_status_success) return fail(HD_ERR_DEVICE, "rocfft_execute (low-pass taps) failed");
                     e->lpf_k_N = lpN; e->lpf_k_stale = false;
                 }
-                HDK(launch_lp_gather, qb, S, fcur, e->fbuf_stride, e->lpf_x.p, lpN, dcall, e->fir_hist_cap, e->fir_head.p + (size_t)cin * S * e->head_cap,
-                    e->fir_head_n.p + (size_t)cin * S, e->head_cap);
+                HDK(launch_lp_gather, qb, S, fcur, e->fbuf_stride, e->lpf_x.p, lpN, dcall, e->fir_hist_cap, e->fir_head.p, e->head_cap, e->fbuf[(e->cur + 2) % 3].p);
                 void* xb[1] = {e->lpf_x.p};
                 if (rocfft_execute(e->lpf_fwd[w], xb, nullptr, e->lpf_info) != rocfft_status_success) return fail(HD_ERR_DEVICE, "rocfft_execute (low-pass forward) failed");
                 HDK(launch_lp_mul, qb, S, e->lpf_x.p, e->lpf_k.p, lpN, dcall);
@@ -1295,8 +1303,7 @@ int hd_process_device(hd_engine* e, const void* d_iq, size_t stride, const uint3
         }
         HDK(launch_fir_demod, qb, S, max_m, lpN ? 0u : max_taps, fcur, e->fbuf_stride, e->lp_taps.p, e->taps_cap, e->demod.p, e->demod.n / S,
                              e->cfg.keep_filtered ? e->filtered.p : nullptr, e->carry[cin].p, e->carry[cout].p, dcall, e->fir_hist_cap,
-                             e->tail.p, e->tail_cap, e->d_symstate.p, fnext, e->fir_head.p + (size_t)cin * S * e->head_cap, e->fir_head_n.p + (size_t)cin * S,
-                             e->fir_head.p + (size_t)cout * S * e->head_cap, e->fir_head_n.p + (size_t)cout * S, e->head_cap, e->demod_ck_acc.p,
+                             e->tail.p, e->tail_cap, e->d_symstate.p, fnext, e->fir_head.p, e->head_cap, e->fbuf[(e->cur + 2) % 3].p, e->demod_ck_acc.p,
                              lpN ? e->lpf_x.p : nullptr, lpN, lpN ? 1.0f / (float)lpN : 1.0f);
     }
     if (!tail)

@@ -55,8 +55,8 @@ __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__
                                                        const StreamCall* __restrict__ call, float2* __restrict__ fft_in,
                                                        float* __restrict__ sym_ring, uint32_t ring_cap, const SymState* __restrict__ sym,
                                                        uint32_t xin_cap /* float2 slots of the stage-2 input image, even */,
-                                                       float2* __restrict__ head_buf /* [2][S][head_cap] */, uint32_t* __restrict__ head_cnt /* [2][S] */,
-                                                       uint32_t head_cap, uint32_t head_par /* 0/1: which half holds the previous run's head */)
+                                                       float2* __restrict__ head_buf /* [S][head_cap]: FirHistory heads moved aside (dev_types.h) */,
+                                                       uint32_t head_cap, const float2* __restrict__ fbuf_prev /* the previous call's low-pass buffers */)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     // [xin: (T2-1) history + n1 chunk samples; reused for the low-pass outputs of a pass][fin: (T-1) history | pending | new]
@@ -71,12 +71,10 @@ __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__
     float2* cur_w = fbuf_w + (size_t)s * fbuf_stride;
     float2* nxt = fbuf_next + (size_t)s * fbuf_stride;
     const uint32_t H = T ? T - 1 : 0;                       // low-pass history length in use
-    const uint32_t Tp = c.fir_taps_prev ? c.fir_taps_prev : T;   // tap count of the previous run (FirHistory, dev_types.h)
-    const uint32_t nS = gridDim.x;
-    const float2* head_in = head_buf + ((size_t)head_par * nS + s) * head_cap;
-    float2* head_out = head_buf + ((size_t)(head_par ^ 1u) * nS + s) * head_cap;
-    const uint32_t* head_n_in = head_cnt + (size_t)head_par * nS + s;
-    uint32_t* head_n_out = head_cnt + (size_t)(head_par ^ 1u) * nS + s;
+    const uint32_t Tp = sc_taps_prev(c) ? sc_taps_prev(c) : T;   // tap count of the previous run (FirHistory, dev_types.h)
+    float2* head_side = head_buf + (size_t)s * head_cap;
+    const float2* head_prevbuf = fbuf_prev + (size_t)s * fbuf_stride + fir_hist_cap;
+    const float2* head_in = sc_head_prev(c) ? head_prevbuf : head_side;
     const uint32_t f_old = H + pb;                          // fin slots that come from global memory
 
     BSTAMP(0);
@@ -101,7 +99,7 @@ __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__
         // element k of the low-pass image [history (H) | pending]: the buffer as it is, or -- first run after a tap-count change
         // -- the reference's view of its one buffer (FirHistory, dev_types.h)
         const bool refold = Tp != T && !c.fir_zero_hist;          // wave-uniform, and false except right after a redesign
-        const uint32_t head_n = refold ? head_n_in[0] : 0u;
+        const uint32_t head_n = refold ? sc_head_n(c) : 0u;
         auto fold = [&](uint32_t k) -> float2 {
             if (k < H && c.fir_zero_hist) return make_float2(0.f, 0.f);
             if (!refold || k >= H) return cur[fir_hist_cap - H + k];
@@ -216,11 +214,8 @@ __global__ __launch_bounds__(kBeLanes) void k_backend(const float2* __restrict__
         } else v = cur[j];
         nxt[k] = v;
     }
-    {   // head of this run's input, for a later run with a different tap count (FirHistory); an idle stream keeps its old one
-        const bool ran = m && T;
-        const uint32_t hn = ran ? min(m, head_cap) : head_n_in[0];
-        for (uint32_t k = tid; k < hn; k += kBeLanes) head_out[k] = ran ? fin[H + k] : head_in[k];
-        if (tid == 0) head_n_out[0] = hn;
+    if (sc_head_save(c)) {   // FirHistory head, lazily (dev_types.h): the stream ran in the previous call and does not in this one -- its head moves aside
+        for (uint32_t k = tid; k < sc_head_n(c); k += kBeLanes) head_side[k] = head_prevbuf[k];
     }
     if (!m || !T) {
         if (tid == 0) carry_out[s] = carry_in[s];           // low-pass did not run: discriminator carry passes through
@@ -329,7 +324,7 @@ bool launch_backend(hipStream_t st, int ratio2, int ntaps2, uint32_t n_streams, 
                     const float2* fbuf, float2* fbuf_w, float2* fbuf_next, size_t fbuf_stride, uint32_t fir_hist_cap, const float* lp_taps,
                     uint32_t taps_stride, float* demod, size_t demod_stride, float2* filtered, const DemodCarry* carry_in,
                     DemodCarry* carry_out, const StreamCall* call, float2* fft_in, float* sym_ring, uint32_t ring_cap, const SymState* sym,
-                    float2* head_buf, uint32_t* head_cnt, uint32_t head_cap, uint32_t head_par)
+                    float2* head_buf, uint32_t head_cap, const float2* fbuf_prev)
 {
     const size_t lds = backend_lds_bytes(ntaps2, max_n1, max_n2, max_taps);
     if (lds > 64 * 1024) return false;
@@ -339,7 +334,7 @@ bool launch_backend(hipStream_t st, int ratio2, int ntaps2, uint32_t n_streams, 
     if (ratio2 == D && ntaps2 == T) {                                                                                                 \
         hipLaunchKernelGGL((k_backend<D, T>), dim3(n_streams), dim3(kBeLanes), lds, st, dec1, dec1_stride, hist2_in, hist2_out, taps2, \
                            fbuf, fbuf_w, fbuf_next, fbuf_stride, fir_hist_cap, lp_taps, taps_stride, demod, demod_stride, filtered,   \
-                           carry_in, carry_out, call, fft_in, sym_ring, ring_cap, sym, (uint32_t)xin_cap, head_buf, head_cnt, head_cap, head_par);                            \
+                           carry_in, carry_out, call, fft_in, sym_ring, ring_cap, sym, (uint32_t)xin_cap, head_buf, head_cap, fbuf_prev);                            \
         return true;                                                                                                                  \
     }
     HD_BE_CASE(2, 69) HD_BE_CASE(4, 139)

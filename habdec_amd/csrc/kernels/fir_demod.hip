@@ -77,8 +77,8 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
                                                           const StreamCall* __restrict__ call, uint32_t fir_hist_cap,
                                                           float* __restrict__ sym_ring, uint32_t ring_cap,
                                                           const SymState* __restrict__ sym, float2* __restrict__ fbuf_next,
-                                                          const float2* __restrict__ head_in, const uint32_t* __restrict__ head_n_in,
-                                                          float2* __restrict__ head_out, uint32_t* __restrict__ head_n_out, uint32_t head_cap,
+                                                          float2* __restrict__ head_side /* [S][head_cap]: FirHistory heads moved aside (dev_types.h) */, uint32_t head_cap,
+                                                          const float2* __restrict__ fbuf_prev /* the previous call's low-pass buffers */,
                                                           uint32_t* __restrict__ ck_acc /* [S][2]: the call's discriminator checksum, accumulated by the stream's tiles (or null) */,
                                                           const float2* __restrict__ pre /* fast mode, long filters: the low-pass output already computed by FFT (k_lp_gather ... below), [S][pre_stride], to be scaled by pre_scale; null = filter here */,
                                                           const uint32_t pre_stride, const float pre_scale)
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
     FSTAMP_DECL;
     const StreamCall c = call[s];
     const uint32_t m = c.fir_m, T = c.fir_taps;
-    const uint32_t Tp = c.fir_taps_prev ? c.fir_taps_prev : T;     // tap count of the previous run
+    const uint32_t Tp = sc_taps_prev(c) ? sc_taps_prev(c) : T;     // tap count of the previous run
     const float2* buf = fbuf + (size_t)s * stride;                 // history occupies [fir_hist_cap-(T-1), fir_hist_cap)
     if (fbuf_next) {
         // Slide [history | leftover pending] to the front of the OTHER buffer for the next call (ping-pong instead of
@@ -109,14 +109,13 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
             for (int u = 0; u < SB; ++u) { const uint32_t k = k0 + u * gridDim.x * kFirLanes; if (k < cnt) nx[lo + k] = v[u]; }
         }
     }
-    // head of this run's input for a later run with a different tap count (FirHistory, dev_types.h); an idle stream keeps its old one
-    if (blockIdx.x == 0) {
-        const float2* hi = head_in + (size_t)s * head_cap;
-        float2* ho = head_out + (size_t)s * head_cap;
-        const uint32_t hn = (m && T) ? min(m, head_cap) : head_n_in[s];
-        for (uint32_t k = threadIdx.x; k < hn; k += kFirLanes) ho[k] = (m && T) ? buf[fir_hist_cap + k] : hi[k];
-        if (threadIdx.x == 0) head_n_out[s] = hn;
+    // FirHistory head (dev_types.h): no run writes one; a stream that ran in the previous call and does not run in this one has its head moved aside
+    const float2* head_prevbuf = fbuf_prev + (size_t)s * stride + fir_hist_cap;
+    if (blockIdx.x == 0 && sc_head_save(c)) {
+        float2* ho = head_side + (size_t)s * head_cap;
+        for (uint32_t k = threadIdx.x; k < sc_head_n(c); k += kFirLanes) ho[k] = head_prevbuf[k];
     }
+    const float2* head_in = sc_head_prev(c) ? head_prevbuf : head_side + (size_t)s * head_cap;
     if (blockIdx.x == 0 && threadIdx.x == 0 && m == 0) carry_out[s] = carry_in[s];   // idle stream: carry passes through
     if (!m || !T) return;
     FSTAMP(0);
@@ -151,7 +150,7 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
             if (j0 + u * kFirLanes < need && b >= 0 && b < end && !(c.fir_zero_hist && b < (long)fir_hist_cap)) v[u] = buf[b];
         }
         if (Tp != T && !c.fir_zero_hist) {                       // first run after a tap-count change (wave-uniform, rare): FirHistory
-            const uint32_t head_n = head_n_in[s];
+            const uint32_t head_n = sc_head_n(c);
 #pragma unroll
             for (int u = 0; u < LB; ++u) {
                 const long b = b0 + (long)(j0 + u * kFirLanes);
@@ -159,7 +158,7 @@ __global__ __launch_bounds__(kFirLanes) void k_fir_demod(const float2* __restric
                     const uint32_t j = (uint32_t)(b - ((long)fir_hist_cap - (long)(T - 1)));      // history slot, 0 = oldest
                     v[u] = make_float2(0.f, 0.f);
                     if (j < Tp - 1) v[u] = buf[fir_hist_cap - (Tp - 1) + j];
-                    else if (j - (Tp - 1) < head_n) v[u] = head_in[(size_t)s * head_cap + j - (Tp - 1)];
+                    else if (j - (Tp - 1) < head_n) v[u] = head_in[j - (Tp - 1)];
                 }
             }
         }
@@ -303,14 +302,14 @@ void launch_fir_demod(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32
                       const float* taps, uint32_t taps_stride, float* demod, size_t demod_stride, float2* filtered,
                       const DemodCarry* carry_in, DemodCarry* carry_out, const StreamCall* call, uint32_t fir_hist_cap,
                       float* sym_ring, uint32_t ring_cap, const SymState* sym, float2* fbuf_next,
-                      const float2* head_in, const uint32_t* head_n_in, float2* head_out, uint32_t* head_n_out, uint32_t head_cap, uint32_t* ck_acc,
+                      float2* head_side, uint32_t head_cap, const float2* fbuf_prev, uint32_t* ck_acc,
                       const float2* pre, uint32_t pre_stride, float pre_scale)
 {
     const uint32_t tiles = max_m ? (max_m + kFirAdvance - 1) / kFirAdvance : 1;
     const size_t lds = (size_t)(kFirTile + (max_taps ? max_taps : 1) + kFirSlack + 4) * sizeof(float2);
     dim3 grid(tiles, n_streams);
     hipLaunchKernelGGL(k_fir_demod, grid, dim3(kFirLanes), lds, st, fbuf, stride, taps, taps_stride, demod, demod_stride, filtered,
-                       carry_in, carry_out, call, fir_hist_cap, sym_ring, ring_cap, sym, fbuf_next, head_in, head_n_in, head_out, head_n_out, head_cap, ck_acc, pre, pre_stride, pre_scale);
+                       carry_in, carry_out, call, fir_hist_cap, sym_ring, ring_cap, sym, fbuf_next, head_side, head_cap, fbuf_prev, ck_acc, pre, pre_stride, pre_scale);
 }
 
 // ---- Fast mode, long low-pass filters (configs[4]: 4097 taps over 4096 samples per call = 67 MFLOP per stream and call done directly): the same correlation
@@ -320,16 +319,17 @@ void launch_fir_demod(hipStream_t st, uint32_t n_streams, uint32_t max_m, uint32
 // multiply the spectra; k_fir_demod then runs with `pre` set.  The result differs from the direct sum by the transforms' rounding (~1e-6 of the input's peak,
 // tests/test_gpu_fast.py); the exact mode never takes this route.
 __global__ __launch_bounds__(256) void k_lp_gather(const float2* __restrict__ fbuf, size_t stride, float2* __restrict__ work, uint32_t N, const StreamCall* __restrict__ call,
-                                                    uint32_t fir_hist_cap, const float2* __restrict__ head_in, const uint32_t* __restrict__ head_n_in, uint32_t head_cap)
+                                                    uint32_t fir_hist_cap, const float2* __restrict__ head_side, uint32_t head_cap, const float2* __restrict__ fbuf_prev)
 {
     const uint32_t s = blockIdx.y;
     const StreamCall c = call[s];
     const uint32_t m = c.fir_m, T = c.fir_taps;
     if (!m || !T) return;
-    const uint32_t Tp = c.fir_taps_prev ? c.fir_taps_prev : T, H = T - 1, L = H + m;
+    const uint32_t Tp = sc_taps_prev(c) ? sc_taps_prev(c) : T, H = T - 1, L = H + m;
     const float2* buf = fbuf + (size_t)s * stride;
     const bool refold = Tp != T && !c.fir_zero_hist;
-    const uint32_t head_n = refold ? head_n_in[s] : 0u;
+    const uint32_t head_n = refold ? sc_head_n(c) : 0u;
+    const float2* head_in = sc_head_prev(c) ? fbuf_prev + (size_t)s * stride + fir_hist_cap : head_side + (size_t)s * head_cap;
     float2* w = work + (size_t)s * N;
     for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < N; j += gridDim.x * 256u) {
         float2 v = make_float2(0.f, 0.f);
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void k_lp_gather(const float2* __restrict__ fb
             else if (c.fir_zero_hist) v = make_float2(0.f, 0.f);              // history restarts from zeros
             else if (!refold) v = buf[fir_hist_cap - H + j];
             else if (j < Tp - 1) v = buf[fir_hist_cap - (Tp - 1) + j];        // first run after a tap-count change (FirHistory, dev_types.h)
-            else if (j - (Tp - 1) < head_n) v = head_in[(size_t)s * head_cap + j - (Tp - 1)];
+            else if (j - (Tp - 1) < head_n) v = head_in[j - (Tp - 1)];
         }
         w[j] = v;
     }
@@ -361,9 +361,9 @@ __global__ __launch_bounds__(256) void k_lp_mul(float2* __restrict__ work, const
     }
 }
 void launch_lp_gather(hipStream_t st, uint32_t n_streams, const float2* fbuf, size_t stride, float2* work, uint32_t N, const StreamCall* call, uint32_t fir_hist_cap,
-                      const float2* head_in, const uint32_t* head_n_in, uint32_t head_cap)
+                      const float2* head_side, uint32_t head_cap, const float2* fbuf_prev)
 {
-    hipLaunchKernelGGL(k_lp_gather, dim3((N + 1023) / 1024, n_streams), dim3(256), 0, st, fbuf, stride, work, N, call, fir_hist_cap, head_in, head_n_in, head_cap);
+    hipLaunchKernelGGL(k_lp_gather, dim3((N + 1023) / 1024, n_streams), dim3(256), 0, st, fbuf, stride, work, N, call, fir_hist_cap, head_side, head_cap, fbuf_prev);
 }
 void launch_lp_taps_gather(hipStream_t st, uint32_t n_streams, const float* taps, uint32_t taps_stride, const uint32_t* ntaps, float2* kf, uint32_t N)
 {

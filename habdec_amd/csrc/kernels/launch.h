@@ -37,7 +37,7 @@ struct TailArgs {
     float* demod; size_t demod_stride; float2* filtered;
     const DemodCarry* carry_in; DemodCarry* carry_out;
     const StreamCall* call; float2* fft_in;
-    float2* head_buf; uint32_t* head_cnt; uint32_t head_cap, head_par, n_streams;
+    float2* head_buf /* [S][head_cap]: FirHistory heads moved aside */; const float2* fbuf_prev /* the previous call's low-pass buffers (dev_types.h: FirHistory head, lazily) */; uint32_t head_cap, n_streams;
     // symbol extractor (same rings and state as launch_symbols)
     float* ring; uint32_t ring_cap; SymState* sym; unsigned long long* flipmask; float* wsum; const SymbolParams* sp;
     uint32_t* slots; uint32_t slot_words; uint32_t* flips_dbg; uint32_t flips_cap;

@@ -156,20 +156,19 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     const StreamCall c = a.call[s];
     const uint32_t n1 = c.n1, n2 = c.n2, m = c.fir_m, T = c.fir_taps, pb = c.pend_before;
     const uint32_t H = T ? T - 1 : 0;
-    const uint32_t Tp = c.fir_taps_prev ? c.fir_taps_prev : T;
+    const uint32_t Tp = sc_taps_prev(c) ? sc_taps_prev(c) : T;
     const bool run = m && T;
     const bool keepf = !c.clear_pending;
-    const uint32_t nS = a.n_streams;
     const float2* in_s = a.dec1 + (size_t)s * a.dec1_stride;
     float2* cur = a.fbuf + (size_t)s * a.fbuf_stride;
     float2* nxt = a.fbuf_next + (size_t)s * a.fbuf_stride;
-    const float2* head_in = a.head_buf + ((size_t)a.head_par * nS + s) * a.head_cap;
-    float2* head_out = a.head_buf + ((size_t)(a.head_par ^ 1u) * nS + s) * a.head_cap;
-    const uint32_t* head_n_in = a.head_cnt + (size_t)a.head_par * nS + s;
-    uint32_t* head_n_out = a.head_cnt + (size_t)(a.head_par ^ 1u) * nS + s;
+    // FirHistory head (dev_types.h): in the previous call's low-pass buffer, or in the side buffer a non-running call copied it to
+    float2* head_side = a.head_buf + (size_t)s * a.head_cap;
+    const float2* head_prevbuf = a.fbuf_prev + (size_t)s * a.fbuf_stride + a.fir_hist_cap;
+    const float2* head_in = sc_head_prev(c) ? head_prevbuf : head_side;
     const float* tp = a.lp_taps + (size_t)s * a.taps_stride;
     const uint32_t fhc = a.fir_hist_cap;
-    const uint32_t hn = run ? min(m, a.head_cap) : 0u;
+
 
     // ---- symbol extractor: state after this call's push (SymbolExtractor.h:116-124), what this call has to do
     const uint32_t ring_cap = a.ring_cap, rmask = ring_cap - 1;
@@ -200,7 +199,7 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     // stream's low-pass taps (scalar cache), stage-2 history, the first piece of the stage-1 chunk, low-pass history + pending,
     // the backlog samples and window sums the first window sums build on, the boundary word of the flag mask.
     const bool refold = Tp != T && !c.fir_zero_hist && run;           // first run after a tap-count change (FirHistory, dev_types.h)
-    const uint32_t head_n = refold ? head_n_in[0] : 0u;
+    const uint32_t head_n = refold ? sc_head_n(c) : 0u;
     auto fold = [&](uint32_t k) -> float2 {                             // element k of [history (H) | pending]
         if (k < H && c.fir_zero_hist) return make_float2(0.f, 0.f);
         if (!refold || k >= H) return cur[fhc - H + k];
@@ -316,7 +315,6 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
     vcnt = take0;
     tb_sync<NT>();
     TSTAMP(0);
-    for (uint32_t k = tid; k < pb && k < hn; k += NT) head_out[k] = F[H + k];     // pending samples open this run's input (FirHistory)
 
     // ---- window sums + flags for every position whose right window is complete: positions [c0, c0 + vcnt - R + 1).
     // W(p) = v[p] + ... + v[p+R-1] is both the reference's right window of p and its left window of p + R (symbols.hip).
@@ -499,13 +497,6 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
                             for (int q = 0; q < 4; ++q) if (oo + q < c.fft_take) fi[q] = make_float2(acc[q].x, acc[q].y);
                         }
                     }
-                    if (pb + oo < hn) {
-                        if (pb + oo + 3 < hn) { float4* h4 = reinterpret_cast<float4*>(head_out + pb + oo); h4[0] = y01; h4[1] = y23; }
-                        else {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) if (pb + oo + q < hn) head_out[pb + oo + q] = make_float2(acc[q].x, acc[q].y);
-                        }
-                    }
                     done4 = true;
                 }
             }
@@ -519,7 +510,6 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
                         if (keepF) F[f_old + oo - fbase] = y;
                         cur[fhc + pb + oo] = y;
                         if (a.fft_in && oo < c.fft_take) a.fft_in[(size_t)s * kFftBins + c.fft_fill + oo] = y;
-                        if (pb + oo < hn) head_out[pb + oo] = y;
                     }
                 }
             }
@@ -739,10 +729,9 @@ __device__ __forceinline__ void tail_body(const TailArgs& a, const uint32_t s, u
         const uint32_t cnt = fhc + c.pend_after;
         for (uint32_t k = tid; k < cnt; k += NT) nxt[k] = cur[k];
     }
-    {
-        const uint32_t hk = run ? hn : head_n_in[0];
-        if (!run) for (uint32_t k = tid; k < hk; k += NT) head_out[k] = head_in[k];
-        if (tid == 0) head_n_out[0] = hk;
+    if (sc_head_save(c)) {      // the stream ran in the previous call and does not in this one: its head moves aside before that buffer's turn comes again
+        const uint32_t hk = sc_head_n(c);
+        for (uint32_t k = tid; k < hk; k += NT) head_side[k] = head_prevbuf[k];
     }
     if (!run && tid == 0) a.carry_out[s] = kin;
     TSTAMP(7);

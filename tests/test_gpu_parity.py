@@ -657,3 +657,44 @@ def test_host_pushes_from_page_locked_memory_are_read_in_place(hd):
     eng.flush()
     assert eng.timing()["host_calls_in_place"] == 0
     eng.close()
+
+
+@pytest.mark.parametrize("dc", [False, True])
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_tap_count_increase_after_idle_calls(hd, dc, pipeline):
+    """The FirHistory head, lazily (dev_types.h, round 6): no run writes the first samples of its input aside any more -- a later run with MORE taps finds them in the
+    previous call's low-pass buffer, or, when the stream sat out one or more calls in between, in the side buffer the first of those calls copied them to.  Streams
+    that run every call, skip exactly one call, skip three calls, and skip the call in which the others change -- then 161 -> 1001 taps (840 head samples), back, and
+    up again with other gaps -- against the oracle bit for bit, through the stream tail and (DC blocker on) through the separate kernels, synchronous and batch."""
+    import habdec_amd
+    from oracle import pyoracle
+    S, fs = 4, 2.048e6
+    iq, _ = make_streams(S, fs, 300, 8, 2, seed0=1700, repeat=6)
+    nch = iq.shape[1] // C
+    assert nch >= 16
+    eng = habdec_amd.Engine(n_streams=S, max_chunk=C, sampling_rate=fs, decimation=64, baud=300, rtty_bits=8, rtty_stops=2, keep_filtered=True, dc_remove=dc, pipeline=pipeline)
+    orcs = [pyoracle.Decoder("oracle", factor=64, baud=300, bits=8, stops=2, dc_remove=dc) for _ in range(S)]
+    idle = {1: {5}, 2: {3, 4, 5}, 3: {6, 11, 12}}                # stream -> calls it sits out
+    plan = {6: 0.004, 9: 0.025, 13: 0.004}                         # 161 -> 1001 -> 161 -> 1001 taps
+    pos = [0] * S
+    for k in range(16):
+        if k in plan:
+            for s in range(S):
+                eng.set_lowpass_trans(s, plan[k]); orcs[s].lowpass_trans(plan[k])
+        n = np.array([0 if k in idle.get(s, ()) else C for s in range(S)], np.uint32)
+        buf = np.zeros((S, C), np.complex64)
+        for s in range(S):
+            buf[s, :n[s]] = iq[s, pos[s]:pos[s] + n[s]]
+        habdec_amd.capi.check(eng.L.hd_process_host(eng.h, buf.ctypes.data, C, n.ctypes.data, 0))
+        for s in range(S):
+            if n[s]:
+                orcs[s](iq[s, pos[s]:pos[s] + n[s]], fs)
+                assert same_bits(eng.filtered(s), orcs[s].array("last_filtered")), ("filtered", k, s)
+                assert same_bits(eng.demodulated(s), orcs[s].array("last_demod")), ("demod", k, s)
+                assert np.array_equal(eng.bits(s), orcs[s].bits()), ("bits", k, s)
+            pos[s] += int(n[s])
+    eng.flush()
+    taps = {len(eng.fir_taps(s)) for s in range(S)}
+    assert taps == {len(orcs[0].array("fir_taps"))} and max(taps) > 900, taps          # the long design is the one in force at the end
+    for s in range(S):
+        assert eng.take_chars(s) == orcs[s].text("chars_log") and eng.take_sentences(s) == orcs[s].sentences()
