@@ -39,6 +39,8 @@ VALU-bound single-GPU configuration) measured in the same run.
 from __future__ import annotations
 
 import argparse
+import collections
+import gc
 import json
 import math
 import os
@@ -177,6 +179,10 @@ def cpu_baseline(w, host_iq, chunks, C, lookup_mode=1):
     return total / dt / 1e6, best, sample, {str(k): round(v, 1) for k, v in table.items()}
 
 
+OracleLog = collections.namedtuple("OracleLog", "sentences chars bits demod_hash")
+ORACLE_LOG_CACHE = {}        # (decoder parameters, chunk sequence, sums over the samples, stream) -> OracleLog; this process only
+
+
 def oracle_sample_check(w, eng, ring, chunks, C, streams, lookup_mode=1, group=64, exact_floats=True):
     """The self-check every bench line carries: the oracle decodes the chunk sequence the engine consumed on `streams` (one pass, one thread per
     stream, `group` streams at a time: a group's share of the ring is transposed on the GPU and brought over in one copy) and the engine's symbols
@@ -190,19 +196,36 @@ def oracle_sample_check(w, eng, ring, chunks, C, streams, lookup_mode=1, group=6
     n_chars = n_bits = n_sent = n_ck = 0
     diff = []
     contiguous = streams == list(range(streams[0], streams[0] + len(streams)))
+    # The oracle's answer is a function of its input alone: a second check over the SAME samples in the same order (the fast leg behind the exact leg of one
+    # command; the suite's fast twin of an exact all-stream test) reads it from here instead of decoding everything again.  The key carries the decoder's
+    # parameters, the chunk sequence and two 64-bit sums over the bit patterns of every sample the check touches.
+    import torch
+    fp = [0, 0]
+    for i in range(nuse):
+        v = ring[i].view(torch.int32)
+        fp[0] += int(v.sum(dtype=torch.int64)); fp[1] += (i + 1) * int(v[..., 0].sum(dtype=torch.int64)) + int((v[..., 1] >> 3).sum(dtype=torch.int64))
+    key0 = (json.dumps(kw, sort_keys=True), tuple(chunks), C, tuple(ring.shape), fp[0], fp[1])
+    reused = 0
     for g0 in range(0, len(streams), group):
         grp = streams[g0:g0 + group]
-        if contiguous:      # [nuse, G, C, 2] -> [G, nuse * C] complex64 on the device, one D2H copy
-            blk = ring[:nuse, grp[0]:grp[0] + len(grp)].transpose(0, 1).contiguous().cpu().numpy().view(np.complex64).reshape(len(grp), -1)
-            host_iq = [blk[i] for i in range(len(grp))]
+        logs = [ORACLE_LOG_CACHE.get(key0 + (s,)) for s in grp]
+        if any(lg is None for lg in logs):
+            if contiguous:      # [nuse, G, C, 2] -> [G, nuse * C] complex64 on the device, one D2H copy
+                blk = ring[:nuse, grp[0]:grp[0] + len(grp)].transpose(0, 1).contiguous().cpu().numpy().view(np.complex64).reshape(len(grp), -1)
+                host_iq = [blk[i] for i in range(len(grp))]
+            else:
+                host_iq = [ring[:nuse, s].cpu().numpy().view(np.complex64).reshape(-1) for s in grp]
+            _, blogs = pyoracle.bench_run(host_iq, chunks, C, 1, **kw)
+            del host_iq
+            logs = [OracleLog(list(lg), lg.chars, lg.bits, lg.demod_hash) for lg in blogs]
+            for s, lg in zip(grp, logs):
+                ORACLE_LOG_CACHE[key0 + (s,)] = lg
         else:
-            host_iq = [ring[:nuse, s].cpu().numpy().view(np.complex64).reshape(-1) for s in grp]
-        _, logs = pyoracle.bench_run(host_iq, chunks, C, 1, **kw)
-        del host_iq
+            reused += len(grp)
         for s, lg in zip(grp, logs):
             got = (eng.take_sentences(s), eng.take_chars(s), eng.bits_total(s))
-            want = (list(lg), lg.chars, lg.bits)
-            n_chars += len(lg.chars); n_bits += lg.bits; n_sent += len(lg)
+            want = (lg.sentences, lg.chars, lg.bits)
+            n_chars += len(lg.chars); n_bits += lg.bits; n_sent += len(lg.sentences)
             if exact_floats:                                # exact mode: every call's discriminator output, bit for bit, through the folded checksums
                 nck, unk, h = eng.demod_checksum_total(s)
                 if unk == 0 and nck == len(chunks):
@@ -217,6 +240,7 @@ def oracle_sample_check(w, eng, ring, chunks, C, streams, lookup_mode=1, group=6
             "compared": "per stream: symbols produced, characters emitted, sentences" + (", and every call's discriminator output bit for bit (folded checksums)" if exact_floats else "") + " -- GPU engine vs oracle over every step the engine took (both timed regions, pre-warm, warm-up, sampling pass)",
             "streams_in_sample": [int(x) for x in streams] if len(streams) <= 8 else len(streams), "all_streams_of_the_shard": len(streams) == eng.S,
             "bits_in_sample": n_bits, "chars_in_sample": n_chars, "sentences_in_sample": n_sent, "steps_checked": len(chunks),
+            "oracle_logs_reused": reused,                   # streams whose oracle log came from an earlier check over the same samples in this process (0 = all decoded here)
             "discriminator_checksums_compared": n_ck,       # (stream, call) pairs whose discriminator output was compared bit for bit (exact mode; 0 in fast mode)
             "check_seconds": round(time.perf_counter() - t0, 1)}
 
@@ -429,7 +453,7 @@ def gpu_sensor_reader(torch, dev):
     return read
 
 
-def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync, cpu_leg, threads=0, prewarm=None, arith=0):
+def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync, cpu_leg, threads=0, prewarm=None, arith=0, min_kernel_samples=32):
     """Time K steps of one workload (after W warm-up steps) and describe the result; rank 0 gets the full dictionary.
     cpu_leg: "full" = the CPU baseline (oracle timed on the host cores) + the self-check on every stream; "check" = the self-check alone on a few
     streams; "check_all" = the self-check alone on every stream of the shard (every line carries one of them); threads = N > 0: one process, a Shard +
@@ -476,6 +500,8 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
         """W untimed warm-up steps, then EXACTLY K timed steps between barriers; the whole job's time (MAX over ranks / shards)."""
         for x in shards:
             x.warm(W)
+        gc.collect()
+        gc.disable()        # (as timeit does: a full collection over the heap an all-stream self-check leaves behind is milliseconds -- steps -- of a 20 ms region)
         barrier()
         t0 = time.perf_counter()
         if threads > 1:
@@ -486,6 +512,7 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
             sh.timed(K, 1)
         barrier()
         d = time.perf_counter() - t0
+        gc.enable()
         if threads > 1:
             d = max(x.t_end for x in shards) - t0      # (the slowest device's region: MAX over shards, as job_time does over ranks)
         return job_time(dist, d, dev)
@@ -506,10 +533,10 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     # least 32 launches (the driver's 20 steps alone carry six or seven).  The device's shader clock and board power are read at the end of that pass,
     # with its last launches still queued (two sysfs reads, ~0.3 ms of driver time: NOT inside a timed region).
     n_region = len(front_ms)
-    need = max(0, 32 - n_region)
+    need = max(0, min_kernel_samples - n_region)
     if not threads:
         seen = eng.timing()["timed_calls"]
-        for _ in range(max(3 * need + 3, 48)):
+        for _ in range(max(3 * need + 3, 48 if min_kernel_samples >= 32 else 6)):      # (the suite's all-stream tests ask for a handful: every step taken is a step the oracle decodes)
             sh.step()
             t = eng.timing()
             if t["timed_calls"] != seen:
@@ -816,7 +843,7 @@ def main():
         return {"arith": "fast: v_pk_fma_f32 in every FIR of the chain (hd_engine_config.arith = HD_ARITH_FAST); discriminator and symbol extractor as in the exact mode",
                 "value": f["value"], "unit": "MS/s", "ms_per_step": f["ms_per_step"], "steps": f["steps"], "timed_region_ms": f["timed_region_ms"], "cold": f.get("cold"),
                 "roofline": f["roofline"], "hbm_frac_end_to_end": f["pipeline"]["hbm_frac_end_to_end"], "launch_path": f["pipeline"]["launch_path"],
-                "per_rank": f.get("per_rank"),
+                "host_us_per_step": f["pipeline"].get("host_us_per_step"), "per_rank": f.get("per_rank"),
                 "parity": {"float": f.get("float_parity"), "streams": cb.get("streams_in_sample"), "all_streams_of_the_shard": cb.get("all_streams_of_the_shard"),
                            "symbols_characters_sentences_equal": cb.get("gpu_matches_oracle_on_sample"), "all_ranks_match_oracle": f.get("all_ranks_match_oracle"),
                            "bits": cb.get("bits_in_sample"), "chars": cb.get("chars_in_sample"), "sentences": cb.get("sentences_in_sample"), "steps_checked": cb.get("steps_checked"),

@@ -250,7 +250,7 @@ def test_fast_mode_every_stream_at_bench_size(name, steps, S):
     every step taken, and the float probe of the same run stays within 1e-5."""
     torch = pytest.importorskip("torch")
     import bench
-    r = bench.run_workload(torch, None, torch.device("cuda", 0), 0, 0, 1, name, steps, 2, S, False, cpu_leg="check_all", prewarm=0, arith=1)
+    r = bench.run_workload(torch, None, torch.device("cuda", 0), 0, 0, 1, name, steps, 2, S, False, cpu_leg="check_all", prewarm=0, arith=1, min_kernel_samples=4)
     cb = r["cpu_baseline"]
     assert r["arith"] == "fast" and cb["all_streams_of_the_shard"] is True and cb["streams_in_sample"] == bench.WORKLOADS[name]["S"], cb
     assert cb["gpu_matches_oracle_on_sample"] is True, cb

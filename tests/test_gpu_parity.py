@@ -532,7 +532,7 @@ def test_pipelined_mode_delivers_identical_text(hd):
     torch = pytest.importorskip("torch")
     import habdec_amd
     from oracle import pyoracle
-    S, fs = 64, 2.048e6
+    S, fs = 32, 2.048e6
     iq, _ = make_streams(S, fs, 300, 8, 2, seed0=4000, repeat=2)
     dev = torch.from_numpy(iq.view(np.float32)).cuda()
     nch = iq.shape[1] // C

@@ -502,7 +502,7 @@ def test_every_stream_of_the_workload_against_the_oracle(name, steps):
     engine took (cfg4: 1024 streams through k_step_cu; cfg2 / cfg3 / cfg5: the separate kernels on two queues)."""
     torch = pytest.importorskip("torch")
     import bench
-    r = bench.run_workload(torch, None, torch.device("cuda", 0), 0, 0, 1, name, steps, 2, 0, False, cpu_leg="check_all", prewarm=0)
+    r = bench.run_workload(torch, None, torch.device("cuda", 0), 0, 0, 1, name, steps, 2, 0, False, cpu_leg="check_all", prewarm=0, min_kernel_samples=4)
     cb = r["cpu_baseline"]
     S = bench.WORKLOADS[name]["S"]
     assert r["arith"] == "exact" and cb["all_streams_of_the_shard"] is True and cb["streams_in_sample"] == S, cb

@@ -118,3 +118,40 @@ def test_bench_under_torchrun_without_gpus_flag_adopts_the_world_size():
     assert p.returncode == 0 and lines, p.stderr[-2000:]
     line = json.loads(lines[-1])
     assert line["n_gpus"] == 2 and len(line["per_rank"]) == 2
+
+
+def test_self_check_reads_an_earlier_checks_oracle_logs_only_for_the_same_samples():
+    """bench.oracle_sample_check keeps the oracle's per-stream logs of a check (sentences, characters, symbols, the folded discriminator hash) for a later check
+    over the SAME samples in the same order in this process (the fast leg behind the exact leg): reused when parameters, chunk sequence and the sums over
+    the samples' bit patterns agree, decoded again when one sample differs.  The engine here is a stand-in that answers with the oracle's own first log."""
+    import torch
+    sys.path.insert(0, str(ROOT))
+    import bench
+    from habdec_amd import synth
+    w = dict(bench.WORKLOADS["cfg4"], baud=300.0)
+    C, S, n = 16384, 2, 8
+    x = np.stack([synth.fsk_iq(synth.rtty_bits("$$CALL,1,2*ABCD\n", w["bits"], w["stops"], 2, 2), w["fs"], w["baud"], sigma=0.08, seed=s, n_samples=n * C) for s in range(S)])
+    ring = torch.from_numpy(np.ascontiguousarray(x.reshape(S, n, C).transpose(1, 0, 2)).view(np.float32).reshape(n, S, C, 2).copy())
+
+    class Eng:
+        S = 2
+        logs = None
+        def take_sentences(self, s): return list(self.logs[s].sentences) if self.logs else []
+        def take_chars(self, s): return self.logs[s].chars if self.logs else ""
+        def bits_total(self, s): return self.logs[s].bits if self.logs else 0
+        def demod_checksum_total(self, s): return (n, 0, self.logs[s].demod_hash if self.logs else 0)
+    eng = Eng()
+    bench.ORACLE_LOG_CACHE.clear()
+    chunks = list(range(n))
+    a = bench.oracle_sample_check(w, eng, ring, chunks, C, [0, 1], group=2)
+    assert a["oracle_logs_reused"] == 0 and len(bench.ORACLE_LOG_CACHE) == 2
+    eng.logs = {k[-1]: v for k, v in bench.ORACLE_LOG_CACHE.items()}
+    b = bench.oracle_sample_check(w, eng, ring, chunks, C, [0, 1], group=2)
+    assert b["oracle_logs_reused"] == 2 and b["gpu_matches_oracle_on_sample"] in (True, None) and b["bits_in_sample"] == a["bits_in_sample"] and not b["mismatches"]
+    assert b["discriminator_checksums_compared"] == 2 * n
+    ring2 = ring.clone(); ring2[1, 1, 77, 0] += 1e-3                      # one sample of one stream: nothing is reused
+    c = bench.oracle_sample_check(w, eng, ring2, chunks, C, [0, 1], group=2)
+    assert c["oracle_logs_reused"] == 0 and len(bench.ORACLE_LOG_CACHE) == 4
+    d = bench.oracle_sample_check(w, eng, ring, chunks[:2], C, [0, 1], group=2)      # another chunk sequence: nothing is reused
+    assert d["oracle_logs_reused"] == 0
+    bench.ORACLE_LOG_CACHE.clear()
