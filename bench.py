@@ -463,6 +463,12 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     w = dict(WORKLOADS[name])
     S = S or w["S"]
     C = w["C"]
+    # No garbage collection from here until the last timed step is sampled (timeit does the same).  A full collection over the heap an earlier leg's all-stream
+    # self-check left behind takes tens of milliseconds: inside a region that is the region; between the pre-warm pass and a region it is worse than it
+    # looks -- an idle GPU drops its clocks within ~20 ms and the next ~150 launches run 10 % slower (tools/micro/r06_warm.py: gap rows).  So the collection runs
+    # here, before the ring is generated, and nothing between the warm-up passes and the regions leaves the GPU idle.
+    gc.collect()
+    gc.disable()
     if threads:
         world = threads
         shards = [None] * threads
@@ -500,8 +506,6 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
         """W untimed warm-up steps, then EXACTLY K timed steps between barriers; the whole job's time (MAX over ranks / shards)."""
         for x in shards:
             x.warm(W)
-        gc.collect()
-        gc.disable()        # (as timeit does: a full collection over the heap an all-stream self-check leaves behind is milliseconds -- steps -- of a 20 ms region)
         barrier()
         t0 = time.perf_counter()
         if threads > 1:
@@ -512,7 +516,6 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
             sh.timed(K, 1)
         barrier()
         d = time.perf_counter() - t0
-        gc.enable()
         if threads > 1:
             d = max(x.t_end for x in shards) - t0      # (the slowest device's region: MAX over shards, as job_time does over ranks)
         return job_time(dist, d, dev)
@@ -548,6 +551,7 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     else:
         for x, rd in zip(shards, sensors):
             x.sensors = rd()
+    gc.enable()
     rank_sensors = [x.sensors or {"sclk_mhz": None, "power_w": None} for x in shards]
     if dist is not None:                                # every rank's clock and power, gathered on rank 0 (a 2-float all-gather, outside the timed regions)
         mine = torch.tensor([rank_sensors[0]["sclk_mhz"] or -1.0, rank_sensors[0]["power_w"] or -1.0], dtype=torch.float64)
