@@ -851,6 +851,7 @@ def main():
                 "parity": {"float": f.get("float_parity"), "streams": cb.get("streams_in_sample"), "all_streams_of_the_shard": cb.get("all_streams_of_the_shard"),
                            "symbols_characters_sentences_equal": cb.get("gpu_matches_oracle_on_sample"), "all_ranks_match_oracle": f.get("all_ranks_match_oracle"),
                            "bits": cb.get("bits_in_sample"), "chars": cb.get("chars_in_sample"), "sentences": cb.get("sentences_in_sample"), "steps_checked": cb.get("steps_checked"),
+                           "oracle_logs_reused": cb.get("oracle_logs_reused"),      # streams whose oracle log is the exact leg's (same samples, same chunk sequence): decoded once per line
                            "mismatches": cb.get("mismatches")}}
     if fast:
         line["fast"] = fast_block(fast)
