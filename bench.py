@@ -514,10 +514,10 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
             for t in th: t.join()
         else:
             sh.timed(K, 1)
+        # This rank's region ends at ITS device synchronize behind the flush of the K-th step (Shard.timed); the closing barrier is the bracket the ranks meet
+        # at, and its own latency -- 0.3 / 0.6 / 0.8 ms for 2 / 4 / 8 ranks over gloo, a tenth to a quarter of a 20-step region -- is not time the K steps took.
+        d = max(x.t_end for x in shards) - t0          # (several shards in one process: the slowest device's region, as job_time takes the MAX over ranks)
         barrier()
-        d = time.perf_counter() - t0
-        if threads > 1:
-            d = max(x.t_end for x in shards) - t0      # (the slowest device's region: MAX over shards, as job_time does over ranks)
         return job_time(dist, d, dev)
 
     dt_cold = region()                                  # behind --warmup only: what rounds 1-3 timed
@@ -824,6 +824,7 @@ def main():
         "timed_region_ms": r["timed_region_ms"],
         "cold": r["cold"],
         "prewarm_steps": r["prewarm_steps"],
+        "timed_region_note": "per rank: from the opening barrier (device synchronize + gloo barrier) to the device synchronize behind the flush that delivers the K-th step's text; MAX over ranks; the closing barrier follows and is not timed",
         "prewarm_note": "`value` / `ms_per_step` are the K steps timed behind the pre-warm pass (untimed steps of the same loop: whole passes over the ring, at least 120) and --warmup more steps: the sustained regime, at the board's 1400 W cap; `cold` is the same K steps timed right behind --warmup alone, before that pass (the protocol of rounds 1-3: the loop's first ~150 launches, DESIGN.md section 6)",
         "per_rank": r["per_rank"],
         "roofline": r["roofline"], "pipeline": r["pipeline"], "box": r.get("box"),
