@@ -740,6 +740,9 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    same_device = bool(os.environ.get("HD_BENCH_SAME_DEVICE")) and not args.threads and int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if same_device:
+        local_rank = 0          # (tests on a one-GPU box: every rank's shard on device 0 -- the process group, the per-rank self-checks and the gather are what is exercised; the line says so)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not args.threads and "--gpus" not in " ".join(sys.argv[1:]).replace("=", " ").split() and world > 1:
         args.gpus = world                                 # `torchrun --nproc-per-node N bench.py` without --gpus: the job's size is what was asked for
@@ -841,6 +844,8 @@ def main():
                         "gpu_matches_oracle_on_sample": also["cpu_baseline"]["gpu_matches_oracle_on_sample"],
                         "self_check": {k: also["cpu_baseline"][k] for k in ("streams_in_sample", "bits_in_sample", "chars_in_sample", "sentences_in_sample")}}
     line["arith"] = r["arith"]
+    if same_device:
+        line["same_device"] = "HD_BENCH_SAME_DEVICE: every rank ran its shard on device 0 -- a plumbing test, not a scaling measurement"
     line["all_ranks_match_oracle"] = r.get("all_ranks_match_oracle")
 
     def fast_block(f):

@@ -158,3 +158,32 @@ def test_bench_threads_mode_two_shards(monkeypatch):
     assert r["value"] > 0 and r["steps"] == 12
     # value counts both shards' samples over the slower shard's region
     assert r["value"] == pytest.approx(2 * 256 * 65536 * 12 / (r["timed_region_ms"] * 1e-3) / 1e6, rel=1e-2)
+
+
+def test_bench_two_ranks_over_gloo_on_one_device():
+    """The driver's N > 1 launch on hardware, as far as a one-GPU box can take it: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...`
+    with HD_BENCH_SAME_DEVICE=1 (both ranks put their shard on device 0; the line says so).  What is exercised: two processes with an engine and a ring each,
+    the gloo process group, the barriers around the regions, the MAX of the ranks' own region times, every rank's self-check on sampled streams of ITS shard
+    (exact leg, fast leg) and the gather of the verdicts on rank 0 -- tests/test_sharding_gloo.py covers the same plumbing without a GPU."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = dict(os.environ, HD_BENCH_SAME_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(root / "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--prewarm", "0", "--streams", "128", "--no-cpu-baseline", "--no-also"]
+    p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)          # (a child process: this one's GPU context stays as it is)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "same_device" in line
+    assert line["value"] == pytest.approx(2 * 128 * 65536 * 8 / (line["timed_region_ms"] * 1e-3) / 1e6, rel=1e-2)
+    assert [r["rank"] for r in line["per_rank"]] == [0, 1]
+    assert all(r["gpu_matches_oracle"] is True for r in line["per_rank"]) and line["all_ranks_match_oracle"] is True
+    f = line["fast"]
+    assert f["parity"]["all_ranks_match_oracle"] is True and f["parity"]["symbols_characters_sentences_equal"] is True
+    assert [r["gpu_matches_oracle"] for r in f["per_rank"]] == [True, True]
