@@ -453,7 +453,21 @@ def gpu_sensor_reader(torch, dev):
     return read
 
 
-def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync, cpu_leg, threads=0, prewarm=None, arith=0, min_kernel_samples=32):
+def run_workload(*args, **kwargs):
+    """_run_workload with the garbage collector off from before the engines and rings are built until the last timed step is sampled (timeit does the same).  A
+    full collection over the heap an earlier leg's all-stream self-check left behind takes tens of milliseconds: inside a region that is the region; between the
+    pre-warm pass and a region it is worse than it looks -- an idle GPU drops its clocks within ~20 ms and the next ~150 launches run 10 % slower
+    (tools/micro/r06_warm.py: gap rows).  So the collection runs here, before the ring is generated, and nothing between the warm-up passes and the regions leaves
+    the GPU idle; _run_workload switches the collector back on behind its sampling pass, this wrapper on every other way out."""
+    gc.collect()
+    gc.disable()
+    try:
+        return _run_workload(*args, **kwargs)
+    finally:
+        gc.enable()
+
+
+def _run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync, cpu_leg, threads=0, prewarm=None, arith=0, min_kernel_samples=32):
     """Time K steps of one workload (after W warm-up steps) and describe the result; rank 0 gets the full dictionary.
     cpu_leg: "full" = the CPU baseline (oracle timed on the host cores) + the self-check on every stream; "check" = the self-check alone on a few
     streams; "check_all" = the self-check alone on every stream of the shard (every line carries one of them); threads = N > 0: one process, a Shard +
@@ -463,12 +477,6 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     w = dict(WORKLOADS[name])
     S = S or w["S"]
     C = w["C"]
-    # No garbage collection from here until the last timed step is sampled (timeit does the same).  A full collection over the heap an earlier leg's all-stream
-    # self-check left behind takes tens of milliseconds: inside a region that is the region; between the pre-warm pass and a region it is worse than it
-    # looks -- an idle GPU drops its clocks within ~20 ms and the next ~150 launches run 10 % slower (tools/micro/r06_warm.py: gap rows).  So the collection runs
-    # here, before the ring is generated, and nothing between the warm-up passes and the regions leaves the GPU idle.
-    gc.collect()
-    gc.disable()
     if threads:
         world = threads
         shards = [None] * threads
@@ -551,7 +559,7 @@ def run_workload(torch, dist, dev, rank, local_rank, world, name, K, W, S, sync,
     else:
         for x, rd in zip(shards, sensors):
             x.sensors = rd()
-    gc.enable()
+    gc.enable()                                         # (the self-check and the CPU baseline below allocate in earnest)
     rank_sensors = [x.sensors or {"sclk_mhz": None, "power_w": None} for x in shards]
     if dist is not None:                                # every rank's clock and power, gathered on rank 0 (a 2-float all-gather, outside the timed regions)
         mine = torch.tensor([rank_sensors[0]["sclk_mhz"] or -1.0, rank_sensors[0]["power_w"] or -1.0], dtype=torch.float64)
